@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X: stereo PCM samples/s through the
+IIR + 50 ms RMS + histogram path, with the dB delta against the CPU oracle.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one pass of the hot path over one batch of synthetic PCM that is already resident
+in HBM (generated there by the library's rg_synth kernel; include/rg_synth.h):
+
+  N == 1   BASELINE configs[1]: one 10-minute 44.1 kHz stereo track (26 460 000 frames, 211.7 MB
+           planar f32) -> per-track histogram, percentile, gain, peak.
+  N  > 1   album mode, weak scaling: every rank owns one such 10-minute track per step; after the
+           per-rank kernels the 12 000-bin album histogram is all-reduced (sum) and the album peak
+           (max) over RCCL, then every rank runs the album percentile.  One rank per GPU, launched
+           by torch.distributed.run.
+
+Timing: W warm-up steps, then exactly K steps between barrier + torch.cuda.synchronize() pairs;
+the time is the MAX over ranks; value = frames processed by all ranks / that time.
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (IIR+RMS+histogram),
+measured with HIP events on the stream it is launched on; `cpu_baseline` is the CPU oracle
+(a C restatement of the reference's sequential algorithm -- not the Rust binary, which cannot
+be built in this image) on the same track, one thread.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+RATE = 44100
+FRAMES_10MIN = 600 * RATE          # 26 460 000
+ALGO_BYTES_PER_FRAME = 8           # 2 channels x f32, read once
+HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+class _DevArray:
+    """Zero-copy view of a raw device pointer for torch.as_tensor (CUDA array interface)."""
+
+    def __init__(self, ptr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 3}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--kernel", type=int, default=0, help="kernel variant (0 = library default)")
+    ap.add_argument("--tracks-per-rank", type=int, default=1)
+    ap.add_argument("--minutes", type=float, default=10.0, help="track length (default: BASELINE's 10 min)")
+    ap.add_argument("--cpu-reps", type=int, default=8, help="oracle repetitions for cpu_baseline (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import mp3rgain_amd as rg
+    from mp3rgain_amd import _capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: PLC0415
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    frames = int(round(args.minutes * 60 * RATE))
+    ntr = args.tracks_per_rank
+    an = rg.Analyzer(local_rank)
+    if args.kernel:
+        an.set_kernel(args.kernel)
+    stream = torch.cuda.current_stream()
+    an.set_stream(stream.cuda_stream)
+
+    # ---- synthetic PCM straight into HBM ---------------------------------------------------
+    pcm = torch.empty((ntr, 2, frames), dtype=torch.float32, device="cuda")
+    descs = (_capi.TrackDesc * ntr)()
+    seeds = [0x5EED0000 + rank * ntr + t for t in range(ntr)]
+    for t in range(ntr):
+        for c in range(2):
+            an.synth_fill_device(pcm[t, c].data_ptr(), seeds[t], c, RATE, 0, frames)
+        descs[t].offset_bytes = t * 2 * frames * 4
+        descs[t].frames = frames
+        descs[t].sample_rate = RATE
+        descs[t].channels = 2
+        descs[t].format = _capi.FMT_F32_PLANAR
+    pcm_bytes = pcm.numel() * 4
+    torch.cuda.synchronize()
+
+    album = world > 1
+    view = None
+    hist_t = peak_t = None
+
+    def step():
+        nonlocal view, hist_t, peak_t
+        an.enqueue_device(descs, ntr, pcm.data_ptr(), pcm_bytes, album=album)
+        if album:
+            if view is None:
+                view = an.device_view()
+                hist_t = torch.as_tensor(_DevArray(view.d_album_hist, (_capi.HISTOGRAM_SIZE,), "<i4"), device="cuda")
+                peak_t = torch.as_tensor(_DevArray(view.d_album_peak, (1,), "<f8"), device="cuda")
+            # LoudnessHistogram::accumulate / album_peak.max across ranks (replaygain.rs:1056-1059);
+            # int32 two's-complement sum == the reference's u32 bins
+            dist.all_reduce(hist_t, op=dist.ReduceOp.SUM)
+            dist.all_reduce(peak_t, op=dist.ReduceOp.MAX)
+            an.album_result_enqueue()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    an.timing_enable(True)
+    an.timing_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    k1_ms_sum, k1_launches = an.timing_read(reset=True)
+    an.timing_enable(False)
+
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- results of the last step + parity against the oracle (outside the timed region) ----
+    res = an.collect(ntr)
+    alb = an.album_finish() if album else None
+
+    total_frames = frames * ntr * world * args.steps
+    value = total_frames / dt
+    k1_ms = k1_ms_sum / max(1, k1_launches)
+    achieved = ALGO_BYTES_PER_FRAME * frames * ntr / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+
+    out = None
+    if rank == 0:
+        cpu = None
+        parity = None
+        if args.cpu_reps > 0:
+            from oracle import pyoracle as po
+
+            l = po.synth_f32(seeds[0], 0, RATE, frames)
+            r = po.synth_f32(seeds[0], 1, RATE, frames)
+            host = pcm[0].cpu().numpy()
+            same_input = bool(np.array_equal(host[0], l) and np.array_equal(host[1], r))
+            want, _ = po.analyze_pcm(l, r, RATE)  # warm + parity
+            c0 = time.perf_counter()
+            for _ in range(args.cpu_reps):
+                po.analyze_pcm(l, r, RATE)
+            cdt = time.perf_counter() - c0
+            cpu = {"value": frames * args.cpu_reps / cdt, "unit": "stereo samples/s", "cores": 1, "kind": "port",
+                   "sample": f"the bench track ({frames} stereo frames @44.1 kHz) x{args.cpu_reps}, "
+                             f"oracle/rg_oracle.c (C restatement of replaygain.rs, not the Rust binary), 1 thread, "
+                             f"host has {os.cpu_count()} cores"}
+            parity = {"same_input_bits": same_input, "loudness_db_gpu": res[0].loudness_db,
+                      "loudness_db_oracle": want["loudness_db"],
+                      "db_delta": res[0].loudness_db - want["loudness_db"], "peak_equal": res[0].peak == want["peak"]}
+        out = {
+            "metric": "stereo PCM samples/s through IIR+RMS+histogram",
+            "value": value,
+            "unit": "stereo samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": ("configs[1]: 1 track, 10 min synthetic 44.1 kHz stereo PCM resident in HBM" if world == 1 and ntr == 1 and frames == FRAMES_10MIN
+                             else f"album mode: {ntr} x {frames / RATE / 60:.1f}-min 44.1 kHz stereo track(s) per GPU, {world} GPU(s)"),
+                "tracks_per_gpu": ntr, "frames_per_track": frames, "sample_rate": RATE,
+                "mode": "album (-a), RCCL all-reduce of the 12000-bin histogram + peak" if album else "track (-r)",
+            },
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel_ms": k1_ms, "kernel_launches": int(k1_launches),
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * frames * ntr},
+            "cpu_baseline": cpu,
+            "parity": parity,
+            "result": {"loudness_db": res[0].loudness_db, "gain_db": res[0].gain_db, "peak": res[0].peak,
+                       "album_loudness_db": alb.album_loudness_db if alb else None},
+        }
+        print(json.dumps(out), flush=True)
+    an.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

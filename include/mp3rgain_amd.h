@@ -1,0 +1,187 @@
+/* mp3rgain_amd.h -- C ABI of the MI355X (gfx950) ReplayGain 1.0 analysis path.
+ *
+ * Drop-in boundary for mp3rgain's `replaygain` module (reference v1.5.0,
+ * citations are file:line under /root/reference).  The reference has no FFI
+ * seam of its own; its per-packet hot loop is
+ *     process_audio_buffer(&AudioBufferRef, &mut [EqualLoudnessFilter],
+ *                          &mut ReplayGainAnalyzer, &mut f64)   src/replaygain.rs:953-958
+ * fed by the decode loop of analyze_track_internal (src/replaygain.rs:866-925)
+ * and merged by analyze_album_with_index (src/replaygain.rs:1044-1074).  This
+ * library replaces everything from "decoded planar PCM" to "ReplayGainResult /
+ * AlbumGainResult": a Rust host binds these symbols with a ~40-line
+ * `extern "C"` block and calls them where it used to run the
+ * per-sample loop.
+ *
+ * Plain C types only: pointers, sizes, PODs.  No torch / HIP types appear in a
+ * signature; a HIP stream or an RCCL communicator crosses as `void *`.
+ *
+ * There is NO CPU fallback.  Every compute entry point fails with
+ * RG_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef MP3RGAIN_AMD_H
+#define MP3RGAIN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RG_ABI_VERSION 1
+#define RG_HISTOGRAM_SIZE 12000         /* HISTOGRAM_SIZE        src/replaygain.rs:630 */
+#define RG_HISTOGRAM_OFFSET 2000        /* HISTOGRAM_OFFSET      src/replaygain.rs:635 */
+#define RG_REPLAYGAIN_REFERENCE_DB 89.0 /* REPLAYGAIN_REFERENCE_DB src/replaygain.rs:37 */
+#define RG_PINK_REF 64.82               /* PINK_REF              src/replaygain.rs:44  */
+#define RG_GAIN_STEP_DB 1.5             /* GAIN_STEP_DB          src/lib.rs:48         */
+
+/* status codes; the text a Rust caller would put in anyhow::Error comes from rg_last_error() */
+typedef enum rg_status {
+    RG_OK = 0,
+    RG_ERR_INVALID_ARG = -1,
+    RG_ERR_UNSUPPORTED_RATE = -2, /* "Unsupported sample rate: {} Hz. Supported rates: ..." src/replaygain.rs:868-873 */
+    RG_ERR_DEVICE = -3,           /* a HIP call failed */
+    RG_ERR_NO_DEVICE = -4,        /* no usable gfx950 device: there is no CPU path */
+    RG_ERR_NOMEM = -5,
+    RG_ERR_STATE = -6,            /* e.g. collect with nothing enqueued */
+    RG_ERR_COLLECTIVE = -7        /* RCCL symbol lookup or call failed */
+} rg_status;
+
+/* planar sample formats, the three AudioBufferRef arms of src/replaygain.rs:959-1024 */
+typedef enum rg_sample_format {
+    RG_FMT_F32_PLANAR = 0, /* normalised [-1,1]; scaled by 32768 before filtering (:969) */
+    RG_FMT_S16_PLANAR = 1, /* used as-is (:990); peak on x/32768                          */
+    RG_FMT_S32_PLANAR = 2  /* x * 32768/2^31 (:1005); peak on that /32768                 */
+} rg_sample_format;
+
+/* AudioFileType, src/replaygain.rs:48-53 (carried through, set by the caller's demuxer) */
+typedef enum rg_file_type { RG_FILE_MP3 = 0, RG_FILE_AAC = 1 } rg_file_type;
+
+/* One decoded track inside a caller-owned PCM arena.  Channel c of the track starts at
+ * pcm_base + offset_bytes + c * frames * bytes_per_sample (planar, the layout
+ * `buf.chan(c)[frame]` of src/replaygain.rs:966,972).  Only channels 0 and 1 are read
+ * (src/replaygain.rs:971); channels == 1 selects add_mono_sample (:731-740). */
+typedef struct rg_track_desc {
+    uint64_t offset_bytes;
+    uint64_t frames;
+    uint32_t sample_rate;
+    uint16_t channels;
+    uint16_t format; /* rg_sample_format */
+} rg_track_desc;
+
+/* ReplayGainResult (src/replaygain.rs:57-68) + gain_steps() (:72-74) */
+typedef struct rg_track_result {
+    double loudness_db;
+    double gain_db;
+    double peak;
+    uint32_t sample_rate;
+    int32_t gain_steps;
+    uint32_t windows; /* number of 50 ms windows that landed in the histogram */
+    uint32_t file_type;
+} rg_track_result;
+
+/* AlbumGainResult minus the per-track vector (src/replaygain.rs:79-95) */
+typedef struct rg_album_result {
+    double album_loudness_db;
+    double album_gain_db;
+    double album_peak;
+    int32_t album_gain_steps;
+    uint32_t windows;
+} rg_album_result;
+
+/* PeakAmplitudeResult, src/replaygain.rs:1125-1132 */
+typedef struct rg_peak_result {
+    double peak;
+    double peak_pcm;
+    uint32_t sample_rate;
+    uint32_t reserved;
+} rg_peak_result;
+
+/* device-side views for callers that keep results in HBM (pipelines, multi-GPU album) */
+typedef struct rg_device_view {
+    void *d_track_hist;   /* uint32_t [n_tracks][RG_HISTOGRAM_SIZE]                 */
+    void *d_track_result; /* rg_track_result [n_tracks]                             */
+    void *d_album_hist;   /* uint32_t [RG_HISTOGRAM_SIZE] (sum over this ctx's tracks) */
+    void *d_album_peak;   /* double [1] (max over this ctx's tracks)                */
+    uint64_t n_tracks;
+} rg_device_view;
+
+typedef struct rg_ctx rg_ctx;
+
+/* ---- pure helpers (host) ---------------------------------------------------------------- */
+int rg_abi_version(void);
+int rg_is_available(void);                         /* replaygain::is_available  src/replaygain.rs:1119-1121 */
+int rg_supported_rate(uint32_t sample_rate);       /* EqualLoudnessFilter::new -> Option  :555-584 */
+uint32_t rg_window_samples(uint32_t sample_rate);  /* ReplayGainAnalyzer::new   :702-704 */
+double rg_hist_loudness(const uint32_t *hist);     /* LoudnessHistogram::get_loudness :665-682 */
+double rg_gain_from_loudness(double loudness_db);  /* PINK_REF - loudness        :911 */
+int32_t rg_gain_steps(double gain_db);             /* gain_steps()               :72-74 */
+int32_t rg_db_to_steps(double db);                 /* db_to_steps                src/lib.rs:632-634 */
+double rg_steps_to_db(int32_t steps);              /* steps_to_db                src/lib.rs:637-639 */
+/* -k clip limiting of the CLI, src/main.rs:2033-2058 */
+int32_t rg_clip_limit_steps(int32_t steps, double gain_db, double peak, int prevent_clipping, int wrap_gain);
+
+/* diagnostic: what the library derived from one coefficient row (host only, no GPU needed).
+ * stable = 0 for the 88.2 kHz row, whose recursion diverges in the reference as written. */
+int rg_rate_design_info(uint32_t sample_rate, int *stable, uint32_t *halo_frames, double *decay_ratio);
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* One context per GPU (the reference is single-threaded; a ctx is not thread-safe, several
+ * ctxs may run concurrently).  device = HIP ordinal.  Returns NULL on failure; the reason is
+ * then available from rg_last_error(NULL). */
+rg_ctx *rg_create(int device);
+void rg_destroy(rg_ctx *ctx);
+const char *rg_last_error(const rg_ctx *ctx);
+/* run on a caller-owned HIP stream (hipStream_t as void*); NULL restores the ctx's own stream */
+int rg_set_stream(rg_ctx *ctx, void *hip_stream);
+/* kernel variant: 0 = auto, 1 = halo-tiled reference kernel, 2 = transient-moment kernel */
+int rg_set_kernel(rg_ctx *ctx, int variant);
+
+/* ---- synchronous analysis (mirrors analyze_track / analyze_album minus the decoder) -------- */
+/* analyze_track_internal from the filters onwards, for n independent tracks (`-r` mode).
+ * pcm_on_device: 0 = pcm_base is host memory (copied H2D), 1 = pcm_base is a device pointer.
+ * hist_out: NULL or host uint32_t[n][RG_HISTOGRAM_SIZE]. */
+int rg_analyze_pcm_batch(rg_ctx *ctx, const rg_track_desc *tracks, size_t n, const void *pcm_base,
+                         size_t pcm_bytes, int pcm_on_device, rg_track_result *out, uint32_t *hist_out);
+/* analyze_album_with_index (src/replaygain.rs:1044-1074): per-track results in input order
+ * plus the merged-histogram album result, on this GPU's tracks only. */
+int rg_analyze_album_pcm(rg_ctx *ctx, const rg_track_desc *tracks, size_t n, const void *pcm_base,
+                         size_t pcm_bytes, int pcm_on_device, rg_track_result *tracks_out,
+                         rg_album_result *album_out, uint32_t *album_hist_out);
+/* find_peak_amplitude's scan (src/replaygain.rs:1210-1241): max |x| over ALL channels */
+int rg_find_peak_pcm(rg_ctx *ctx, const rg_track_desc *track, const void *pcm_base, size_t pcm_bytes,
+                     int pcm_on_device, rg_peak_result *out);
+
+/* ---- asynchronous / device-resident pipeline ------------------------------------------------ */
+/* Enqueue the whole analysis for a batch whose PCM is already in HBM; nothing is copied back.
+ * album != 0 also produces d_album_hist / d_album_peak for this ctx's tracks. */
+int rg_enqueue_pcm_batch(rg_ctx *ctx, const rg_track_desc *tracks, size_t n, const void *d_pcm_base,
+                         size_t pcm_bytes, int album);
+int rg_device_view_get(rg_ctx *ctx, rg_device_view *view);
+/* wait for the stream and copy back; any of the outputs may be NULL */
+int rg_collect(rg_ctx *ctx, rg_track_result *tracks_out, uint32_t *hist_out);
+/* album across GPUs (src/replaygain.rs:1056-1066 as a collective): in-place
+ * all-reduce(sum) of d_album_hist and all-reduce(max) of d_album_peak over `nccl_comm`
+ * (an ncclComm_t; NULL = single GPU, no-op).  The RCCL entry points are resolved from the
+ * already-loaded process image first, then from librccl.so. */
+int rg_album_allreduce(rg_ctx *ctx, void *nccl_comm);
+/* percentile scan of d_album_hist on the device, result to host */
+int rg_album_finish(rg_ctx *ctx, rg_album_result *album_out, uint32_t *album_hist_out);
+/* the same scan, enqueued only: the rg_album_result stays in HBM until rg_album_finish */
+int rg_album_result_enqueue(rg_ctx *ctx);
+
+/* ---- measurement hooks ------------------------------------------------------------------------ */
+/* When enabled, every enqueue brackets the dominant kernel (IIR+RMS+histogram) with HIP events
+ * on the stream it is launched on. */
+int rg_timing_enable(rg_ctx *ctx, int on);
+/* sum of bracketed kernel durations and their count since the last reset; synchronises */
+int rg_timing_read(rg_ctx *ctx, double *sum_ms, uint64_t *launches, int reset);
+
+/* ---- synthetic PCM directly in HBM (bench / tests; include/rg_synth.h) --------------------- */
+int rg_synth_fill_device(rg_ctx *ctx, void *d_dst_f32, uint64_t seed, uint32_t channel,
+                         uint32_t sample_rate, uint64_t first_frame, uint64_t frames);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MP3RGAIN_AMD_H */

@@ -1,0 +1,131 @@
+"""ctypes binding of include/mp3rgain_amd.h (the C-ABI drop-in boundary).
+
+This module only loads the in-tree shared library and declares signatures; there is no
+Python or CPU compute path behind it.  If the library is missing it raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libmp3rgain_amd.so"
+
+HISTOGRAM_SIZE = 12000
+HISTOGRAM_OFFSET = 2000
+FMT_F32_PLANAR, FMT_S16_PLANAR, FMT_S32_PLANAR = 0, 1, 2
+
+RG_OK = 0
+RG_ERR_INVALID_ARG = -1
+RG_ERR_UNSUPPORTED_RATE = -2
+RG_ERR_DEVICE = -3
+RG_ERR_NO_DEVICE = -4
+RG_ERR_NOMEM = -5
+RG_ERR_STATE = -6
+RG_ERR_COLLECTIVE = -7
+
+
+class TrackDesc(C.Structure):
+    _fields_ = [
+        ("offset_bytes", C.c_uint64),
+        ("frames", C.c_uint64),
+        ("sample_rate", C.c_uint32),
+        ("channels", C.c_uint16),
+        ("format", C.c_uint16),
+    ]
+
+
+class TrackResult(C.Structure):
+    _fields_ = [
+        ("loudness_db", C.c_double),
+        ("gain_db", C.c_double),
+        ("peak", C.c_double),
+        ("sample_rate", C.c_uint32),
+        ("gain_steps", C.c_int32),
+        ("windows", C.c_uint32),
+        ("file_type", C.c_uint32),
+    ]
+
+
+class AlbumResult(C.Structure):
+    _fields_ = [
+        ("album_loudness_db", C.c_double),
+        ("album_gain_db", C.c_double),
+        ("album_peak", C.c_double),
+        ("album_gain_steps", C.c_int32),
+        ("windows", C.c_uint32),
+    ]
+
+
+class PeakResult(C.Structure):
+    _fields_ = [
+        ("peak", C.c_double),
+        ("peak_pcm", C.c_double),
+        ("sample_rate", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class DeviceView(C.Structure):
+    _fields_ = [
+        ("d_track_hist", C.c_void_p),
+        ("d_track_result", C.c_void_p),
+        ("d_album_hist", C.c_void_p),
+        ("d_album_peak", C.c_void_p),
+        ("n_tracks", C.c_uint64),
+    ]
+
+
+# every symbol include/mp3rgain_amd.h declares: (name, restype, argtypes)
+_vp, _sz, _u32, _i32, _u64, _dbl, _int = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int32, C.c_uint64, C.c_double, C.c_int
+_P = C.POINTER
+SYMBOLS = [
+    ("rg_abi_version", _int, []),
+    ("rg_is_available", _int, []),
+    ("rg_supported_rate", _int, [_u32]),
+    ("rg_window_samples", _u32, [_u32]),
+    ("rg_hist_loudness", _dbl, [_vp]),
+    ("rg_gain_from_loudness", _dbl, [_dbl]),
+    ("rg_gain_steps", _i32, [_dbl]),
+    ("rg_db_to_steps", _i32, [_dbl]),
+    ("rg_steps_to_db", _dbl, [_i32]),
+    ("rg_clip_limit_steps", _i32, [_i32, _dbl, _dbl, _int, _int]),
+    ("rg_rate_design_info", _int, [_u32, _P(_int), _P(_u32), _P(_dbl)]),
+    ("rg_create", _vp, [_int]),
+    ("rg_destroy", None, [_vp]),
+    ("rg_last_error", C.c_char_p, [_vp]),
+    ("rg_set_stream", _int, [_vp, _vp]),
+    ("rg_set_kernel", _int, [_vp, _int]),
+    ("rg_analyze_pcm_batch", _int, [_vp, _P(TrackDesc), _sz, _vp, _sz, _int, _P(TrackResult), _vp]),
+    ("rg_analyze_album_pcm", _int, [_vp, _P(TrackDesc), _sz, _vp, _sz, _int, _P(TrackResult), _P(AlbumResult), _vp]),
+    ("rg_find_peak_pcm", _int, [_vp, _P(TrackDesc), _vp, _sz, _int, _P(PeakResult)]),
+    ("rg_enqueue_pcm_batch", _int, [_vp, _P(TrackDesc), _sz, _vp, _sz, _int]),
+    ("rg_device_view_get", _int, [_vp, _P(DeviceView)]),
+    ("rg_collect", _int, [_vp, _P(TrackResult), _vp]),
+    ("rg_album_allreduce", _int, [_vp, _vp]),
+    ("rg_album_finish", _int, [_vp, _P(AlbumResult), _vp]),
+    ("rg_album_result_enqueue", _int, [_vp]),
+    ("rg_timing_enable", _int, [_vp, _int]),
+    ("rg_timing_read", _int, [_vp, _P(_dbl), _P(_u64), _int]),
+    ("rg_synth_fill_device", _int, [_vp, _vp, _u64, _u32, _u32, _u64, _u64]),
+]
+
+_lib = None
+
+
+def load():
+    """Load libmp3rgain_amd.so from the package directory (built by __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C mp3rgain_amd/csrc). There is no fallback path."
+            )
+        L = C.CDLL(str(LIB_PATH))
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib

@@ -1,0 +1,622 @@
+// rg_capi.hip -- host orchestration behind include/mp3rgain_amd.h.
+//
+// Mirrors analyze_track_internal from the filters onwards (src/replaygain.rs:866-925) and
+// analyze_album_with_index (src/replaygain.rs:1044-1074) on decoded planar PCM.  Everything after
+// the H2D copy (or nothing at all when the PCM is already in HBM) runs on one HIP stream:
+//   memset(hist, peak) -> K1 IIR+RMS+histogram+peak -> per-track percentile/result
+//   [album] -> merge -> (caller's all-reduce) -> album percentile
+// There is no CPU compute path in this file by design.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "rg_design.h"
+#include "rg_device.h"
+
+// ---- kernel launchers (defined in the kernel translation units) --------------------------------
+extern "C" {
+hipError_t rg_launch_k1_halo(const RgTrackDev *, uint32_t, uint32_t, const RgCoefDev *, uint32_t *,
+                             unsigned long long *, hipStream_t);
+hipError_t rg_launch_track_results(const uint32_t *, const unsigned long long *, const RgTrackDev *,
+                                   rg_track_result *, uint32_t, hipStream_t);
+hipError_t rg_launch_album_merge(const uint32_t *, const unsigned long long *, uint32_t, uint32_t *, double *,
+                                 hipStream_t);
+hipError_t rg_launch_album_result(const uint32_t *, const double *, rg_album_result *, hipStream_t);
+hipError_t rg_launch_peak_all(const void *, uint64_t, uint32_t, unsigned long long *, hipStream_t);
+hipError_t rg_launch_synth_fill(float *, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, hipStream_t);
+}
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 16;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+template <typename T>
+struct PinnedBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 16;
+        hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct rg_ctx {
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int kernel_variant = 0;
+
+    RgRateDesign design[RG_NUM_RATES];
+    DevBuf<RgCoefDev> d_coefs;
+
+    DevBuf<RgTrackDev> d_tracks;
+    PinnedBuf<RgTrackDev> h_tracks;
+    DevBuf<uint32_t> d_hist;
+    DevBuf<unsigned long long> d_peak_bits;
+    DevBuf<rg_track_result> d_results;
+    PinnedBuf<rg_track_result> h_results;
+    DevBuf<uint32_t> d_album_hist;
+    DevBuf<double> d_album_peak;
+    DevBuf<rg_album_result> d_album_result;
+    PinnedBuf<rg_album_result> h_album_result;
+    DevBuf<unsigned char> d_arena;  // staging for host PCM
+
+    size_t n_enqueued = 0;
+    bool album_ready = false;
+
+    // timing of the dominant kernel
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    double timing_sum_ms = 0.0;
+    uint64_t timing_count = 0;
+};
+
+namespace {
+
+int set_err(rg_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define RG_HIP(ctx, call)                                                                       \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return set_err((ctx), RG_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+int rate_index(uint32_t sr) {
+    for (int i = 0; i < RG_NUM_RATES; ++i)
+        if (RG_RATE_TABLE[i].sample_rate == sr) return i;
+    return -1;
+}
+
+size_t bytes_per_sample(uint32_t fmt) { return fmt == RG_FMT_S16_PLANAR ? 2 : 4; }
+
+int32_t round_to_i32(double v) {  // Rust: f64::round() as i32
+    double r = round(v);
+    if (r != r) return 0;
+    if (r >= 2147483647.0) return INT32_MAX;
+    if (r <= -2147483648.0) return INT32_MIN;
+    return (int32_t)r;
+}
+
+int bind_device(rg_ctx *c) {
+    RG_HIP(c, hipSetDevice(c->device));
+    return RG_OK;
+}
+
+// flush finished timing events into the running sum (requires the stream to be idle)
+int drain_timing(rg_ctx *c) {
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float ms = 0.f;
+        RG_HIP(c, hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second));
+        c->timing_sum_ms += ms;
+        c->timing_count += 1;
+    }
+    c->ev_used = 0;
+    return RG_OK;
+}
+
+}  // namespace
+
+// ================================ pure helpers =====================================================
+extern "C" int rg_abi_version(void) { return RG_ABI_VERSION; }
+extern "C" int rg_is_available(void) { return 1; }
+extern "C" int rg_supported_rate(uint32_t sr) { return rate_index(sr) >= 0 ? 1 : 0; }
+extern "C" uint32_t rg_window_samples(uint32_t sr) { return (uint32_t)(((uint64_t)sr * 50u) / 1000u); }
+
+extern "C" double rg_hist_loudness(const uint32_t *hist) {
+    if (!hist) return -20.0;
+    uint64_t total = 0;
+    for (int i = 0; i < RG_HISTOGRAM_SIZE; ++i) total += hist[i];
+    if (total == 0) return -20.0;
+    const uint64_t threshold = (uint64_t)ceil((double)total * RG_ONE_MINUS_PERCENTILE);
+    uint64_t count = 0;
+    for (int i = RG_HISTOGRAM_SIZE - 1; i >= 0; --i) {
+        count += hist[i];
+        if (count >= threshold) return (double)(i - RG_HISTOGRAM_OFFSET) / 100.0;
+    }
+    return -20.0;
+}
+
+extern "C" double rg_gain_from_loudness(double l) { return RG_PINK_REF - l; }
+extern "C" int32_t rg_gain_steps(double gain_db) { return round_to_i32(gain_db / RG_GAIN_STEP_DB); }
+extern "C" int32_t rg_db_to_steps(double db) { return round_to_i32(db / RG_GAIN_STEP_DB); }
+extern "C" double rg_steps_to_db(int32_t steps) { return (double)steps * RG_GAIN_STEP_DB; }
+
+extern "C" int32_t rg_clip_limit_steps(int32_t steps, double gain_db, double peak, int prevent_clipping, int wrap) {
+    int32_t actual = steps;
+    if (steps > 0 && !wrap) {
+        const double new_peak = peak * pow(10.0, gain_db / 20.0);
+        if (new_peak > 1.0 && prevent_clipping) {
+            const int32_t safe = rg_db_to_steps(-20.0 * log10(peak));
+            actual = safe > 0 ? safe : 0;
+        }
+    }
+    return actual;
+}
+
+extern "C" int rg_rate_design_info(uint32_t sr, int *stable, uint32_t *halo, double *decay) {
+    const int ri = rate_index(sr);
+    if (ri < 0) return RG_ERR_UNSUPPORTED_RATE;
+    RgRateDesign d;
+    rg_design_rate(RG_RATE_TABLE[ri], &d);
+    if (stable) *stable = d.stable ? 1 : 0;
+    if (halo) *halo = d.halo_frames;
+    if (decay) *decay = d.pole_radius;
+    return RG_OK;
+}
+
+// ================================ context ==========================================================
+extern "C" const char *rg_last_error(const rg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" rg_ctx *rg_create(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_err(nullptr, RG_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= count) {
+        set_err(nullptr, RG_ERR_INVALID_ARG, "device ordinal %d out of range (have %d)", device, count);
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
+        set_err(nullptr, RG_ERR_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_err(nullptr, RG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
+                prop.gcnArchName);
+        return nullptr;
+    }
+    rg_ctx *c = new rg_ctx();
+    c->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+        set_err(nullptr, RG_ERR_DEVICE, "stream creation: %s", hipGetErrorString(e));
+        delete c;
+        return nullptr;
+    }
+    c->stream = c->own_stream;
+
+    std::vector<RgCoefDev> coefs(RG_NUM_RATES);
+    for (int i = 0; i < RG_NUM_RATES; ++i) {
+        rg_design_rate(RG_RATE_TABLE[i], &c->design[i]);
+        memcpy(coefs[i].ya, RG_RATE_TABLE[i].yule_a, sizeof coefs[i].ya);
+        memcpy(coefs[i].yb, RG_RATE_TABLE[i].yule_b, sizeof coefs[i].yb);
+        memcpy(coefs[i].ba, RG_RATE_TABLE[i].butter_a, sizeof coefs[i].ba);
+        memcpy(coefs[i].bb, RG_RATE_TABLE[i].butter_b, sizeof coefs[i].bb);
+    }
+    if ((e = c->d_coefs.reserve(RG_NUM_RATES)) != hipSuccess ||
+        (e = hipMemcpy(c->d_coefs.p, coefs.data(), sizeof(RgCoefDev) * RG_NUM_RATES, hipMemcpyHostToDevice)) !=
+            hipSuccess ||
+        (e = c->d_album_hist.reserve(RG_HISTOGRAM_SIZE)) != hipSuccess ||
+        (e = c->d_album_peak.reserve(1)) != hipSuccess || (e = c->d_album_result.reserve(1)) != hipSuccess ||
+        (e = c->h_album_result.reserve(1)) != hipSuccess) {
+        set_err(nullptr, RG_ERR_DEVICE, "context allocation: %s", hipGetErrorString(e));
+        rg_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" void rg_destroy(rg_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &p : c->ev_pool) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    c->d_coefs.release();
+    c->d_tracks.release();
+    c->h_tracks.release();
+    c->d_hist.release();
+    c->d_peak_bits.release();
+    c->d_results.release();
+    c->h_results.release();
+    c->d_album_hist.release();
+    c->d_album_peak.release();
+    c->d_album_result.release();
+    c->h_album_result.release();
+    c->d_arena.release();
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" int rg_set_stream(rg_ctx *c, void *s) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    if (bind_device(c) != RG_OK) return RG_ERR_DEVICE;
+    RG_HIP(c, hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return RG_OK;
+}
+
+extern "C" int rg_set_kernel(rg_ctx *c, int variant) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    if (variant < 0 || variant > 1) return set_err(c, RG_ERR_INVALID_ARG, "unknown kernel variant %d", variant);
+    c->kernel_variant = variant;
+    return RG_OK;
+}
+
+extern "C" int rg_timing_enable(rg_ctx *c, int on) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    c->timing = on != 0;
+    return RG_OK;
+}
+
+extern "C" int rg_timing_read(rg_ctx *c, double *sum_ms, uint64_t *launches, int reset) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    if (bind_device(c) != RG_OK) return RG_ERR_DEVICE;
+    RG_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = drain_timing(c);
+    if (rc != RG_OK) return rc;
+    if (sum_ms) *sum_ms = c->timing_sum_ms;
+    if (launches) *launches = c->timing_count;
+    if (reset) {
+        c->timing_sum_ms = 0.0;
+        c->timing_count = 0;
+    }
+    return RG_OK;
+}
+
+// ================================ enqueue ===========================================================
+namespace {
+
+// Validate the batch and build the per-track launch descriptors (host side of
+// analyze_track_internal's set-up, src/replaygain.rs:848-878).
+int build_descs(rg_ctx *c, const rg_track_desc *tracks, size_t n, const unsigned char *d_base, size_t pcm_bytes,
+                uint32_t *total_items_out) {
+    uint64_t total_windows = 0;
+    for (size_t t = 0; t < n; ++t) {
+        const rg_track_desc &d = tracks[t];
+        if (rate_index(d.sample_rate) < 0)
+            return set_err(c, RG_ERR_UNSUPPORTED_RATE,
+                           "Unsupported sample rate: %u Hz. Supported rates: 96000, 88200, 64000, 48000, 44100, "
+                           "32000, 24000, 22050, 16000, 12000, 11025, 8000",
+                           d.sample_rate);
+        if (d.channels == 0) return set_err(c, RG_ERR_INVALID_ARG, "track %zu: channels == 0", t);
+        if (d.format > RG_FMT_S32_PLANAR) return set_err(c, RG_ERR_INVALID_ARG, "track %zu: unknown format %u", t, d.format);
+        const size_t bps = bytes_per_sample(d.format);
+        if (d.offset_bytes % bps) return set_err(c, RG_ERR_INVALID_ARG, "track %zu: offset not sample-aligned", t);
+        const uint64_t need = d.offset_bytes + (uint64_t)d.channels * d.frames * bps;
+        if (need > pcm_bytes)
+            return set_err(c, RG_ERR_INVALID_ARG, "track %zu: extends past the PCM arena (%llu > %zu)", t,
+                           (unsigned long long)need, pcm_bytes);
+        const uint32_t W = rg_window_samples(d.sample_rate);
+        total_windows += (d.frames + W - 1) / W;
+    }
+    // segment length: enough work items to fill the chip, long enough to amortise the halo
+    uint32_t seg_windows = 1;
+    if (total_windows > (1u << 18)) {
+        uint64_t s = total_windows >> 17;
+        seg_windows = (uint32_t)(s > 16 ? 16 : s);
+    }
+    uint64_t items = 0;
+    for (size_t t = 0; t < n; ++t) {
+        const rg_track_desc &d = tracks[t];
+        const int ri = rate_index(d.sample_rate);
+        const size_t bps = bytes_per_sample(d.format);
+        RgTrackDev &o = c->h_tracks.p[t];
+        o.ch0 = d_base + d.offset_bytes;
+        o.ch1 = d.channels >= 2 ? d_base + d.offset_bytes + d.frames * bps : nullptr;
+        o.frames = d.frames;
+        o.window = rg_window_samples(d.sample_rate);
+        const uint64_t nw = (d.frames + o.window - 1) / o.window;
+        if (nw > 0xFFFFFFFFull) return set_err(c, RG_ERR_INVALID_ARG, "track %zu: too long", t);
+        o.n_windows = (uint32_t)nw;
+        if (c->design[ri].stable) {
+            o.seg_windows = seg_windows;
+            o.halo = c->design[ri].halo_frames;
+        } else {  // 88.2 kHz row: the recursion diverges, only the sequential order is defined
+            o.seg_windows = o.n_windows ? o.n_windows : 1;
+            o.halo = 0xFFFFFFFFu;
+        }
+        o.n_segments = (o.n_windows + o.seg_windows - 1) / o.seg_windows;
+        o.coef_idx = (uint32_t)ri;
+        o.format = d.format;
+        o.item_base = (uint32_t)items;
+        o.sample_rate = d.sample_rate;
+        o.file_type = RG_FILE_MP3;
+        items += o.n_segments;
+        if (items > 0x7FFFFFFFull) return set_err(c, RG_ERR_INVALID_ARG, "batch too large");
+    }
+    *total_items_out = (uint32_t)items;
+    return RG_OK;
+}
+
+int enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *d_pcm_base, size_t pcm_bytes,
+                 int album) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    if (n && (!tracks || !d_pcm_base)) return set_err(c, RG_ERR_INVALID_ARG, "null tracks / pcm_base");
+    if (n > 0x7FFFFFFFull) return set_err(c, RG_ERR_INVALID_ARG, "too many tracks");
+    int rc = bind_device(c);
+    if (rc != RG_OK) return rc;
+    hipStream_t s = c->stream;
+
+    RG_HIP(c, c->h_tracks.reserve(n));
+    RG_HIP(c, c->d_tracks.reserve(n));
+    RG_HIP(c, c->d_hist.reserve(n * (size_t)RG_HISTOGRAM_SIZE));
+    RG_HIP(c, c->d_peak_bits.reserve(n));
+    RG_HIP(c, c->d_results.reserve(n));
+    RG_HIP(c, c->h_results.reserve(n));
+
+    uint32_t total_items = 0;
+    rc = build_descs(c, tracks, n, (const unsigned char *)d_pcm_base, pcm_bytes, &total_items);
+    if (rc != RG_OK) return rc;
+
+    c->n_enqueued = n;
+    c->album_ready = false;
+    if (n) {
+        RG_HIP(c, hipMemcpyAsync(c->d_tracks.p, c->h_tracks.p, n * sizeof(RgTrackDev), hipMemcpyHostToDevice, s));
+        RG_HIP(c, hipMemsetAsync(c->d_hist.p, 0, n * (size_t)RG_HISTOGRAM_SIZE * sizeof(uint32_t), s));
+        RG_HIP(c, hipMemsetAsync(c->d_peak_bits.p, 0, n * sizeof(unsigned long long), s));
+
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (c->timing) {
+            if (c->ev_used == c->ev_pool.size()) {
+                hipEvent_t a, b;
+                RG_HIP(c, hipEventCreate(&a));
+                RG_HIP(c, hipEventCreate(&b));
+                c->ev_pool.emplace_back(a, b);
+            }
+            e0 = c->ev_pool[c->ev_used].first;
+            e1 = c->ev_pool[c->ev_used].second;
+            c->ev_used += 1;
+            RG_HIP(c, hipEventRecord(e0, s));
+        }
+        RG_HIP(c, rg_launch_k1_halo(c->d_tracks.p, (uint32_t)n, total_items, c->d_coefs.p, c->d_hist.p,
+                                    c->d_peak_bits.p, s));
+        if (c->timing) RG_HIP(c, hipEventRecord(e1, s));
+        RG_HIP(c, rg_launch_track_results(c->d_hist.p, c->d_peak_bits.p, c->d_tracks.p, c->d_results.p, (uint32_t)n, s));
+    }
+    if (album) {
+        RG_HIP(c, rg_launch_album_merge(c->d_hist.p, c->d_peak_bits.p, (uint32_t)n, c->d_album_hist.p,
+                                        c->d_album_peak.p, s));
+        c->album_ready = true;
+    }
+    return RG_OK;
+}
+
+// copy a host PCM arena to the device staging buffer
+int stage_pcm(rg_ctx *c, const void *pcm_base, size_t pcm_bytes, int on_device, const void **d_base) {
+    if (on_device) {
+        *d_base = pcm_base;
+        return RG_OK;
+    }
+    int rc = bind_device(c);
+    if (rc != RG_OK) return rc;
+    RG_HIP(c, hipStreamSynchronize(c->stream));  // the arena may still be read by a previous batch
+    RG_HIP(c, c->d_arena.reserve(pcm_bytes ? pcm_bytes : 1));
+    if (pcm_bytes) RG_HIP(c, hipMemcpyAsync(c->d_arena.p, pcm_base, pcm_bytes, hipMemcpyHostToDevice, c->stream));
+    *d_base = c->d_arena.p;
+    return RG_OK;
+}
+
+}  // namespace
+
+extern "C" int rg_enqueue_pcm_batch(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *d_pcm_base,
+                                    size_t pcm_bytes, int album) {
+    return enqueue_impl(c, tracks, n, d_pcm_base, pcm_bytes, album);
+}
+
+extern "C" int rg_device_view_get(rg_ctx *c, rg_device_view *v) {
+    if (!c || !v) return RG_ERR_INVALID_ARG;
+    v->d_track_hist = c->d_hist.p;
+    v->d_track_result = c->d_results.p;
+    v->d_album_hist = c->d_album_hist.p;
+    v->d_album_peak = c->d_album_peak.p;
+    v->n_tracks = c->n_enqueued;
+    return RG_OK;
+}
+
+extern "C" int rg_collect(rg_ctx *c, rg_track_result *out, uint32_t *hist_out) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    int rc = bind_device(c);
+    if (rc != RG_OK) return rc;
+    const size_t n = c->n_enqueued;
+    if (n && out)
+        RG_HIP(c, hipMemcpyAsync(c->h_results.p, c->d_results.p, n * sizeof(rg_track_result), hipMemcpyDeviceToHost,
+                                 c->stream));
+    if (n && hist_out)
+        RG_HIP(c, hipMemcpyAsync(hist_out, c->d_hist.p, n * (size_t)RG_HISTOGRAM_SIZE * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, c->stream));
+    RG_HIP(c, hipStreamSynchronize(c->stream));
+    if (n && out) memcpy(out, c->h_results.p, n * sizeof(rg_track_result));
+    return RG_OK;
+}
+
+extern "C" int rg_album_result_enqueue(rg_ctx *c) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    if (!c->album_ready) return set_err(c, RG_ERR_STATE, "rg_album_result_enqueue without an album enqueue");
+    int rc = bind_device(c);
+    if (rc != RG_OK) return rc;
+    RG_HIP(c, rg_launch_album_result(c->d_album_hist.p, c->d_album_peak.p, c->d_album_result.p, c->stream));
+    return RG_OK;
+}
+
+extern "C" int rg_album_finish(rg_ctx *c, rg_album_result *album_out, uint32_t *album_hist_out) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    if (!c->album_ready) return set_err(c, RG_ERR_STATE, "rg_album_finish without an album enqueue");
+    int rc = bind_device(c);
+    if (rc != RG_OK) return rc;
+    RG_HIP(c, rg_launch_album_result(c->d_album_hist.p, c->d_album_peak.p, c->d_album_result.p, c->stream));
+    RG_HIP(c, hipMemcpyAsync(c->h_album_result.p, c->d_album_result.p, sizeof(rg_album_result), hipMemcpyDeviceToHost,
+                             c->stream));
+    if (album_hist_out)
+        RG_HIP(c, hipMemcpyAsync(album_hist_out, c->d_album_hist.p, RG_HISTOGRAM_SIZE * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, c->stream));
+    RG_HIP(c, hipStreamSynchronize(c->stream));
+    if (album_out) *album_out = *c->h_album_result.p;
+    return RG_OK;
+}
+
+// ---- RCCL, resolved at run time so that a host that already loaded RCCL (e.g. through
+// torch.distributed) shares its copy -------------------------------------------------------------
+namespace {
+typedef int (*nccl_allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef int (*nccl_group_fn)(void);
+const int kNcclUint32 = 3, kNcclFloat64 = 8, kNcclSum = 0, kNcclMax = 2;  // rccl.h enum values
+
+void *resolve(const char *name) {
+    void *p = dlsym(RTLD_DEFAULT, name);
+    if (p) return p;
+    static void *h = nullptr;
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    return h ? dlsym(h, name) : nullptr;
+}
+}  // namespace
+
+extern "C" int rg_album_allreduce(rg_ctx *c, void *comm) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    if (!c->album_ready) return set_err(c, RG_ERR_STATE, "rg_album_allreduce without an album enqueue");
+    if (!comm) return RG_OK;  // single GPU: nothing to exchange
+    nccl_allreduce_fn ar = (nccl_allreduce_fn)resolve("ncclAllReduce");
+    nccl_group_fn gs = (nccl_group_fn)resolve("ncclGroupStart");
+    nccl_group_fn ge = (nccl_group_fn)resolve("ncclGroupEnd");
+    if (!ar || !gs || !ge) return set_err(c, RG_ERR_COLLECTIVE, "RCCL entry points not found (librccl.so)");
+    int rc = bind_device(c);
+    if (rc != RG_OK) return rc;
+    int r = gs();
+    if (r == 0) r = ar(c->d_album_hist.p, c->d_album_hist.p, RG_HISTOGRAM_SIZE, kNcclUint32, kNcclSum, comm, c->stream);
+    if (r == 0) r = ar(c->d_album_peak.p, c->d_album_peak.p, 1, kNcclFloat64, kNcclMax, comm, c->stream);
+    int r2 = ge();
+    if (r != 0 || r2 != 0) return set_err(c, RG_ERR_COLLECTIVE, "ncclAllReduce failed (%d/%d)", r, r2);
+    return RG_OK;
+}
+
+// ================================ synchronous API ====================================================
+extern "C" int rg_analyze_pcm_batch(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *pcm_base,
+                                    size_t pcm_bytes, int on_device, rg_track_result *out, uint32_t *hist_out) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    if (n && !pcm_base) return set_err(c, RG_ERR_INVALID_ARG, "null pcm_base");
+    const void *d_base = nullptr;
+    int rc = stage_pcm(c, pcm_base, pcm_bytes, on_device, &d_base);
+    if (rc != RG_OK) return rc;
+    rc = enqueue_impl(c, tracks, n, d_base, pcm_bytes, 0);
+    if (rc != RG_OK) return rc;
+    return rg_collect(c, out, hist_out);
+}
+
+extern "C" int rg_analyze_album_pcm(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *pcm_base,
+                                    size_t pcm_bytes, int on_device, rg_track_result *tracks_out,
+                                    rg_album_result *album_out, uint32_t *album_hist_out) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    if (n && !pcm_base) return set_err(c, RG_ERR_INVALID_ARG, "null pcm_base");
+    const void *d_base = nullptr;
+    int rc = stage_pcm(c, pcm_base, pcm_bytes, on_device, &d_base);
+    if (rc != RG_OK) return rc;
+    rc = enqueue_impl(c, tracks, n, d_base, pcm_bytes, 1);
+    if (rc != RG_OK) return rc;
+    rc = rg_collect(c, tracks_out, nullptr);
+    if (rc != RG_OK) return rc;
+    return rg_album_finish(c, album_out, album_hist_out);
+}
+
+extern "C" int rg_find_peak_pcm(rg_ctx *c, const rg_track_desc *track, const void *pcm_base, size_t pcm_bytes,
+                                int on_device, rg_peak_result *out) {
+    if (!c || !track || !out) return RG_ERR_INVALID_ARG;
+    if (track->format > RG_FMT_S32_PLANAR) return set_err(c, RG_ERR_INVALID_ARG, "unknown format");
+    const size_t bps = bytes_per_sample(track->format);
+    const uint64_t total = (uint64_t)track->channels * track->frames;
+    if (track->offset_bytes + total * bps > pcm_bytes) return set_err(c, RG_ERR_INVALID_ARG, "track extends past arena");
+    const void *d_base = nullptr;
+    int rc = stage_pcm(c, pcm_base, pcm_bytes, on_device, &d_base);
+    if (rc != RG_OK) return rc;
+    RG_HIP(c, c->d_peak_bits.reserve(1));
+    RG_HIP(c, hipMemsetAsync(c->d_peak_bits.p, 0, sizeof(unsigned long long), c->stream));
+    RG_HIP(c, rg_launch_peak_all((const unsigned char *)d_base + track->offset_bytes, total, track->format,
+                                 c->d_peak_bits.p, c->stream));
+    unsigned long long bits = 0;
+    RG_HIP(c, hipMemcpyAsync(&bits, c->d_peak_bits.p, sizeof bits, hipMemcpyDeviceToHost, c->stream));
+    RG_HIP(c, hipStreamSynchronize(c->stream));
+    double pk;
+    memcpy(&pk, &bits, sizeof pk);
+    out->peak = pk;
+    out->peak_pcm = pk * 32768.0;  // src/replaygain.rs:1246
+    out->sample_rate = track->sample_rate;
+    out->reserved = 0;
+    return RG_OK;
+}
+
+extern "C" int rg_synth_fill_device(rg_ctx *c, void *d_dst, uint64_t seed, uint32_t channel, uint32_t sample_rate,
+                                    uint64_t first_frame, uint64_t frames) {
+    if (!c || (!d_dst && frames)) return RG_ERR_INVALID_ARG;
+    int rc = bind_device(c);
+    if (rc != RG_OK) return rc;
+    RG_HIP(c, rg_launch_synth_fill((float *)d_dst, seed, channel, sample_rate, first_frame, frames, c->stream));
+    return RG_OK;
+}

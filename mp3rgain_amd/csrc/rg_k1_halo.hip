@@ -1,0 +1,157 @@
+// rg_k1_halo.hip -- variant 1: halo-tiled, operation-order-faithful IIR + RMS + histogram kernel.
+//
+// COMPILED WITH -ffp-contract=off.  One work item (lane) owns `seg_windows` consecutive 50 ms
+// windows of one track, both channels.  It first runs the filter cascade over `halo` frames
+// before its segment from a zero state (or from the true track start when the segment is
+// closer than `halo` to it, in which case the state is exact), then processes its segment
+// exactly as the reference's per-sample loop does:
+//   process_audio_buffer           src/replaygain.rs:953-1029  (sample conversion, peak)
+//   EqualLoudnessFilter::process   src/replaygain.rs:586-616   (direct form I, same sum order)
+//   add_sample / add_mono_sample   src/replaygain.rs:720-740
+//   finish_window                  src/replaygain.rs:743-765   (mean square -> dB*100 -> bin)
+// With halo == UINT32_MAX and one segment per track the kernel is the reference's sequential
+// algorithm verbatim (used for the unstable 88.2 kHz coefficient row and as a parity anchor).
+// This variant is the correctness anchor; variant 2 (rg_k2_tm.hip) is the fast path.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+
+#include "rg_device.h"
+#include "rg_device_inl.h"
+
+namespace {
+
+struct Df1State {
+    double yx[11], yy[11], bx[3], by[3];
+};
+
+__device__ __forceinline__ void df1_reset(Df1State &f) {
+#pragma unroll
+    for (int i = 0; i < 11; ++i) { f.yx[i] = 0.0; f.yy[i] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { f.bx[i] = 0.0; f.by[i] = 0.0; }
+}
+
+// EqualLoudnessFilter::process, src/replaygain.rs:586-616 -- same shifts, same fold order.
+__device__ __forceinline__ double df1_process(Df1State &f, const RgCoefDev &c, double s) {
+#pragma unroll
+    for (int i = 10; i >= 1; --i) { f.yx[i] = f.yx[i - 1]; f.yy[i] = f.yy[i - 1]; }
+    f.yx[0] = s;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 1; i < 11; ++i) {
+        double t = c.yb[i] * f.yx[i] - c.ya[i] * f.yy[i];
+        acc = acc + t;
+    }
+    const double y = (1e-10 + c.yb[0] * f.yx[0]) + acc;
+    f.yy[0] = y;
+
+    f.bx[2] = f.bx[1]; f.bx[1] = f.bx[0];
+    f.by[2] = f.by[1]; f.by[1] = f.by[0];
+    f.bx[0] = y;
+    double acc2 = 0.0;
+#pragma unroll
+    for (int i = 1; i < 3; ++i) {
+        double t = c.bb[i] * f.bx[i] - c.ba[i] * f.by[i];
+        acc2 = acc2 + t;
+    }
+    const double z = (1e-10 + c.bb[0] * f.bx[0]) + acc2;
+    f.by[0] = z;
+    return z;
+}
+
+// sample conversion arms of process_audio_buffer (src/replaygain.rs:959-1024):
+// returns the filter input, writes the normalised magnitude used for the peak.
+__device__ __forceinline__ double load_input(const void *base, uint64_t i, uint32_t fmt, double &mag) {
+    if (fmt == RG_FMT_F32_PLANAR) {
+        const double xn = (double)((const float *)base)[i];
+        mag = fabs(xn);
+        return xn * 32768.0;
+    } else if (fmt == RG_FMT_S16_PLANAR) {
+        const double v = (double)((const int16_t *)base)[i];
+        mag = fabs(v / 32768.0);
+        return v;
+    } else {
+        const double v = (double)((const int32_t *)base)[i] * (32768.0 / 2147483648.0);
+        mag = fabs(v / 32768.0);
+        return v;
+    }
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(256) rg_k1_halo_kernel(const RgTrackDev *__restrict__ tracks, uint32_t n_tracks,
+                                                         uint32_t total_items, const RgCoefDev *__restrict__ coefs,
+                                                         uint32_t *__restrict__ hist,
+                                                         unsigned long long *__restrict__ peak_bits) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total_items) return;
+
+    // largest t with item_base[t] <= g (tracks with zero items share a base with their successor)
+    uint32_t lo = 0, hi = n_tracks - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (tracks[mid].item_base <= g) lo = mid; else hi = mid - 1;
+    }
+    const uint32_t t = lo;
+    const RgTrackDev tr = tracks[t];
+    const uint32_t seg = g - tr.item_base;
+    if (seg >= tr.n_segments) return;
+    const RgCoefDev c = coefs[tr.coef_idx];
+
+    const uint64_t W = tr.window;
+    const uint64_t first = (uint64_t)seg * tr.seg_windows * W;
+    uint64_t last = first + (uint64_t)tr.seg_windows * W;
+    if (last > tr.frames) last = tr.frames;
+    const uint64_t warm = (tr.halo != 0xFFFFFFFFu && first > tr.halo) ? first - tr.halo : 0;
+    const bool stereo = tr.ch1 != nullptr;
+    const uint32_t fmt = tr.format;
+
+    Df1State fl, fr;
+    df1_reset(fl);
+    df1_reset(fr);
+    double mag;
+
+    for (uint64_t i = warm; i < first; ++i) {
+        (void)df1_process(fl, c, load_input(tr.ch0, i, fmt, mag));
+        if (stereo) (void)df1_process(fr, c, load_input(tr.ch1, i, fmt, mag));
+    }
+
+    double peak = 0.0, lsum = 0.0, rsum = 0.0;
+    uint32_t n = 0;
+    uint32_t *const h = hist + (size_t)t * RG_HISTOGRAM_SIZE;
+    for (uint64_t i = first; i < last; ++i) {
+        const double lf = df1_process(fl, c, load_input(tr.ch0, i, fmt, mag));
+        if (mag > peak) peak = mag;
+        if (stereo) {
+            const double rf = df1_process(fr, c, load_input(tr.ch1, i, fmt, mag));
+            if (mag > peak) peak = mag;
+            lsum += lf * lf;
+            rsum += rf * rf;
+        } else {
+            const double sq = lf * lf;
+            lsum += sq;
+            rsum += sq;
+        }
+        if (++n >= W) {
+            const int idx = rg_window_bin(lsum, rsum, n);
+            if (idx >= 0) atomicAdd(&h[idx], 1u);
+            lsum = 0.0; rsum = 0.0; n = 0;
+        }
+    }
+    if (n > 0) {  // final partial window, src/replaygain.rs:907
+        const int idx = rg_window_bin(lsum, rsum, n);
+        if (idx >= 0) atomicAdd(&h[idx], 1u);
+    }
+    atomicMax(&peak_bits[t], (unsigned long long)__double_as_longlong(peak));
+}
+
+extern "C" hipError_t rg_launch_k1_halo(const RgTrackDev *d_tracks, uint32_t n_tracks, uint32_t total_items,
+                                        const RgCoefDev *d_coefs, uint32_t *d_hist,
+                                        unsigned long long *d_peak_bits, hipStream_t stream) {
+    if (total_items == 0) return hipSuccess;
+    const uint32_t block = 64;  // one wave per workgroup: spreads a small item count over all CUs
+    const uint32_t grid = (total_items + block - 1) / block;
+    hipLaunchKernelGGL(rg_k1_halo_kernel, dim3(grid), dim3(block), 0, stream, d_tracks, n_tracks, total_items,
+                       d_coefs, d_hist, d_peak_bits);
+    return hipGetLastError();
+}

@@ -1,0 +1,305 @@
+"""Host-side mirror of mp3rgain's `replaygain` module on decoded PCM, over the C ABI.
+
+Names, fields, argument meaning and error behaviour follow the reference
+(src/replaygain.rs, v1.5.0):
+
+  REPLAYGAIN_REFERENCE_DB                          :37
+  AudioFileType {Mp3, Aac}                         :48-53
+  ReplayGainResult {loudness_db, gain_db, peak, sample_rate, file_type} + gain_steps()   :57-75
+  AlbumGainResult {tracks, album_loudness_db, album_gain_db, album_peak} + album_gain_steps()  :79-95
+  analyze_track / analyze_album                    :929-941 / :1033-1074
+  PeakAmplitudeResult / find_peak_amplitude        :1125-1132 / :1140-1249
+  is_available                                     :1119-1121
+
+The reference's functions take a file path and decode with symphonia; the decoder is outside
+this path, so the functions here take a `PcmTrack` -- what the
+reference's decode loop hands to process_audio_buffer, as whole planar channels.  All
+arithmetic happens in libmp3rgain_amd.so on the GPU; this file is plumbing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _capi
+
+REPLAYGAIN_REFERENCE_DB = 89.0
+GAIN_STEP_DB = 1.5
+SUPPORTED_RATES = (96000, 88200, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000)
+
+
+class ReplayGainError(RuntimeError):
+    """The anyhow::Error of the reference: carries the library's message."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+class AudioFileType(enum.IntEnum):
+    Mp3 = 0
+    Aac = 1
+
+
+@dataclass
+class ReplayGainResult:
+    loudness_db: float
+    gain_db: float
+    peak: float
+    sample_rate: int
+    file_type: AudioFileType = AudioFileType.Mp3
+    windows: int = 0
+
+    def gain_steps(self) -> int:
+        return _capi.load().rg_gain_steps(self.gain_db)
+
+
+@dataclass
+class AlbumGainResult:
+    tracks: List[ReplayGainResult]
+    album_loudness_db: float
+    album_gain_db: float
+    album_peak: float
+
+    def album_gain_steps(self) -> int:
+        return _capi.load().rg_gain_steps(self.album_gain_db)
+
+
+@dataclass
+class PeakAmplitudeResult:
+    peak: float
+    peak_pcm: float
+    sample_rate: int
+
+
+_NP_FMT = {
+    np.dtype(np.float32): _capi.FMT_F32_PLANAR,
+    np.dtype(np.int16): _capi.FMT_S16_PLANAR,
+    np.dtype(np.int32): _capi.FMT_S32_PLANAR,
+}
+
+
+@dataclass
+class PcmTrack:
+    """Decoded audio of one file: planar channels (float32 in [-1,1], int16 or int32)."""
+
+    channels: Sequence[np.ndarray]
+    sample_rate: int
+    file_type: AudioFileType = AudioFileType.Mp3
+    _fmt: int = field(init=False, default=0)
+
+    def __post_init__(self):
+        if len(self.channels) == 0:
+            raise ValueError("No audio track found")  # src/replaygain.rs:834-836
+        chans = [np.ascontiguousarray(c) for c in self.channels]
+        dt = chans[0].dtype
+        if dt not in _NP_FMT:
+            raise TypeError(f"unsupported sample dtype {dt}")
+        for c in chans:
+            if c.dtype != dt or c.shape != chans[0].shape or c.ndim != 1:
+                raise ValueError("channels must be 1-D arrays of one dtype and length")
+        self.channels = chans
+        self._fmt = _NP_FMT[dt]
+
+    @property
+    def frames(self) -> int:
+        return int(self.channels[0].shape[0])
+
+
+def is_available() -> bool:
+    """replaygain::is_available (src/replaygain.rs:1119-1121): the library is present."""
+    try:
+        return bool(_capi.load().rg_is_available())
+    except (ImportError, OSError):
+        return False
+
+
+def db_to_steps(db: float) -> int:
+    return _capi.load().rg_db_to_steps(db)
+
+
+def steps_to_db(steps: int) -> float:
+    return _capi.load().rg_steps_to_db(steps)
+
+
+def clip_limit_steps(steps: int, gain_db: float, peak: float, prevent_clipping: bool, wrap_gain: bool = False) -> int:
+    """The -k rule of the CLI (src/main.rs:2033-2058)."""
+    return _capi.load().rg_clip_limit_steps(steps, gain_db, peak, int(prevent_clipping), int(wrap_gain))
+
+
+def pack_tracks(tracks: Sequence[PcmTrack]):
+    """Lay the tracks out in one planar arena -> (uint8 arena, TrackDesc array).
+
+    Track t, channel c lives at offset_bytes + c * frames * itemsize; each track starts on a
+    16-byte boundary.  All channels are packed so that find_peak_amplitude sees every channel;
+    the analysis itself reads channels 0 and 1 only (src/replaygain.rs:971).
+    """
+    descs = (_capi.TrackDesc * max(1, len(tracks)))()
+    sizes, off = [], 0
+    for t in tracks:
+        nbytes = sum(c.nbytes for c in t.channels)
+        sizes.append((off, nbytes))
+        off = (off + nbytes + 15) & ~15
+    arena = np.zeros(max(off, 16), dtype=np.uint8)
+    for i, t in enumerate(tracks):
+        o, _ = sizes[i]
+        p = o
+        for c in t.channels:
+            arena[p:p + c.nbytes] = c.view(np.uint8)
+            p += c.nbytes
+        descs[i].offset_bytes = o
+        descs[i].frames = t.frames
+        descs[i].sample_rate = t.sample_rate
+        descs[i].channels = len(t.channels)
+        descs[i].format = t._fmt
+    return arena, descs
+
+
+class Analyzer:
+    """One rg_ctx (one GPU).  Not thread-safe, like the single-threaded reference."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _capi.load()
+        self._ctx = self._lib.rg_create(device)
+        if not self._ctx:
+            msg = self._lib.rg_last_error(None).decode()
+            raise ReplayGainError(_capi.RG_ERR_NO_DEVICE, msg)
+        self.device = device
+
+    # -- lifecycle ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.rg_destroy(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != _capi.RG_OK:
+            raise ReplayGainError(rc, self._lib.rg_last_error(self._ctx).decode())
+
+    @property
+    def handle(self):
+        return self._ctx
+
+    def set_stream(self, hip_stream: Optional[int]):
+        self._check(self._lib.rg_set_stream(self._ctx, hip_stream))
+
+    def set_kernel(self, variant: int):
+        self._check(self._lib.rg_set_kernel(self._ctx, variant))
+
+    # -- synchronous, host PCM ----------------------------------------------------------------
+    def analyze_tracks(self, tracks: Sequence[PcmTrack], return_histograms: bool = False):
+        """`-r` mode: analyze_track for each track (src/replaygain.rs:929-941)."""
+        n = len(tracks)
+        arena, descs = pack_tracks(tracks)
+        out = (_capi.TrackResult * max(1, n))()
+        hist = np.zeros((max(1, n), _capi.HISTOGRAM_SIZE), dtype=np.uint32) if return_histograms else None
+        self._check(self._lib.rg_analyze_pcm_batch(
+            self._ctx, descs, n, arena.ctypes.data, arena.nbytes, 0, out,
+            hist.ctypes.data if hist is not None else None))
+        res = [_to_result(out[i], tracks[i].file_type) for i in range(n)]
+        return (res, hist[:n]) if return_histograms else res
+
+    def analyze_track(self, track: PcmTrack) -> ReplayGainResult:
+        return self.analyze_tracks([track])[0]
+
+    def analyze_album(self, tracks: Sequence[PcmTrack], return_histogram: bool = False):
+        """analyze_album (src/replaygain.rs:1033-1074) on one GPU."""
+        n = len(tracks)
+        arena, descs = pack_tracks(tracks)
+        out = (_capi.TrackResult * max(1, n))()
+        alb = _capi.AlbumResult()
+        hist = np.zeros(_capi.HISTOGRAM_SIZE, dtype=np.uint32) if return_histogram else None
+        self._check(self._lib.rg_analyze_album_pcm(
+            self._ctx, descs, n, arena.ctypes.data, arena.nbytes, 0, out, C.byref(alb),
+            hist.ctypes.data if hist is not None else None))
+        res = AlbumGainResult([_to_result(out[i], tracks[i].file_type) for i in range(n)],
+                              alb.album_loudness_db, alb.album_gain_db, alb.album_peak)
+        return (res, hist) if return_histogram else res
+
+    def find_peak_amplitude(self, track: PcmTrack) -> PeakAmplitudeResult:
+        """find_peak_amplitude's scan over ALL channels (src/replaygain.rs:1210-1249)."""
+        arena, descs = pack_tracks([track])
+        pk = _capi.PeakResult()
+        self._check(self._lib.rg_find_peak_pcm(self._ctx, descs, arena.ctypes.data, arena.nbytes, 0, C.byref(pk)))
+        return PeakAmplitudeResult(pk.peak, pk.peak_pcm, pk.sample_rate)
+
+    # -- device-resident pipeline --------------------------------------------------------------
+    def enqueue_device(self, descs, n: int, d_pcm_base: int, pcm_bytes: int, album: bool = False):
+        self._check(self._lib.rg_enqueue_pcm_batch(self._ctx, descs, n, d_pcm_base, pcm_bytes, int(album)))
+
+    def collect(self, n: int, want_hist: bool = False):
+        out = (_capi.TrackResult * max(1, n))()
+        hist = np.zeros((max(1, n), _capi.HISTOGRAM_SIZE), dtype=np.uint32) if want_hist else None
+        self._check(self._lib.rg_collect(self._ctx, out, hist.ctypes.data if hist is not None else None))
+        res = [_to_result(out[i], AudioFileType.Mp3) for i in range(n)]
+        return (res, hist[:n]) if want_hist else res
+
+    def device_view(self) -> _capi.DeviceView:
+        v = _capi.DeviceView()
+        self._check(self._lib.rg_device_view_get(self._ctx, C.byref(v)))
+        return v
+
+    def album_allreduce(self, nccl_comm: Optional[int] = None):
+        self._check(self._lib.rg_album_allreduce(self._ctx, nccl_comm))
+
+    def album_result_enqueue(self):
+        self._check(self._lib.rg_album_result_enqueue(self._ctx))
+
+    def album_finish(self, want_hist: bool = False):
+        alb = _capi.AlbumResult()
+        hist = np.zeros(_capi.HISTOGRAM_SIZE, dtype=np.uint32) if want_hist else None
+        self._check(self._lib.rg_album_finish(self._ctx, C.byref(alb), hist.ctypes.data if hist is not None else None))
+        return (alb, hist) if want_hist else alb
+
+    def synth_fill_device(self, d_dst: int, seed: int, channel: int, sample_rate: int, first_frame: int, frames: int):
+        self._check(self._lib.rg_synth_fill_device(self._ctx, d_dst, seed, channel, sample_rate, first_frame, frames))
+
+    def timing_enable(self, on: bool = True):
+        self._check(self._lib.rg_timing_enable(self._ctx, int(on)))
+
+    def timing_read(self, reset: bool = True):
+        s, k = C.c_double(), C.c_uint64()
+        self._check(self._lib.rg_timing_read(self._ctx, C.byref(s), C.byref(k), int(reset)))
+        return s.value, k.value
+
+
+def _to_result(r: _capi.TrackResult, file_type: AudioFileType) -> ReplayGainResult:
+    return ReplayGainResult(r.loudness_db, r.gain_db, r.peak, r.sample_rate, AudioFileType(int(file_type)), r.windows)
+
+
+_default: Optional[Analyzer] = None
+
+
+def _default_analyzer() -> Analyzer:
+    global _default
+    if _default is None:
+        _default = Analyzer(0)
+    return _default
+
+
+def analyze_track(track: PcmTrack) -> ReplayGainResult:
+    return _default_analyzer().analyze_track(track)
+
+
+def analyze_album(tracks: Sequence[PcmTrack]) -> AlbumGainResult:
+    return _default_analyzer().analyze_album(tracks)
+
+
+def find_peak_amplitude(track: PcmTrack) -> PeakAmplitudeResult:
+    return _default_analyzer().find_peak_amplitude(track)

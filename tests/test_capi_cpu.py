@@ -1,0 +1,131 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/mp3rgain_amd.h
+declares, its pure host helpers agree with the oracle, and without a GPU it fails loudly
+instead of falling back to anything."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+from hypothesis import given, settings
+from hypothesis import strategies as st
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _declared_functions():
+    txt = (ROOT / "include" / "mp3rgain_amd.h").read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(rg_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(capi):
+    from mp3rgain_amd import _capi
+
+    declared = _declared_functions()
+    bound = sorted(name for name, _, _ in _capi.SYMBOLS)
+    assert declared == bound, "header and ctypes binding disagree"
+    raw = C.CDLL(str(_capi.LIB_PATH))
+    for name in declared:
+        assert hasattr(raw, name), f"{name} not exported"
+    assert capi.rg_abi_version() == 1
+    assert capi.rg_is_available() == 1
+
+
+def test_struct_layouts_match_the_header():
+    from mp3rgain_amd import _capi
+
+    assert C.sizeof(_capi.TrackDesc) == 24
+    assert C.sizeof(_capi.TrackResult) == 40
+    assert C.sizeof(_capi.AlbumResult) == 32
+    assert C.sizeof(_capi.PeakResult) == 24
+    assert C.sizeof(_capi.DeviceView) == 40
+
+
+def test_supported_rates_and_windows(capi):
+    rates = [96000, 88200, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000]
+    for r in rates:
+        assert capi.rg_supported_rate(r) == 1
+        assert capi.rg_window_samples(r) == r * 50 // 1000
+    for r in (0, 99999, 44101, 192000):
+        assert capi.rg_supported_rate(r) == 0
+    assert capi.rg_window_samples(44100) == 2205 and capi.rg_window_samples(11025) == 551
+
+
+def test_design_info(capi):
+    """Every row but 88.2 kHz is stable; the halo grows with the pole radius."""
+    st_, halo, dec = C.c_int(), C.c_uint32(), C.c_double()
+    halos = {}
+    for r in [96000, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000]:
+        assert capi.rg_rate_design_info(r, C.byref(st_), C.byref(halo), C.byref(dec)) == 0
+        assert st_.value == 1 and 256 <= halo.value <= 8192 and 0.9 < dec.value < 1.0
+        halos[r] = halo.value
+    assert halos[96000] > halos[44100] > halos[8000]
+    assert capi.rg_rate_design_info(88200, C.byref(st_), C.byref(halo), C.byref(dec)) == 0
+    assert st_.value == 0
+    assert capi.rg_rate_design_info(12345, None, None, None) == -2
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.lists(st.tuples(st.integers(0, 11999), st.integers(1, 5000)), min_size=0, max_size=40))
+def test_host_percentile_matches_oracle(capi, oracle, entries):
+    h = np.zeros(12000, dtype=np.uint32)
+    for i, c in entries:
+        h[i] += c
+    assert capi.rg_hist_loudness(h.ctypes.data) == oracle.hist_loudness(h)
+
+
+def test_host_gain_helpers_match_oracle(capi, oracle):
+    L = oracle.lib()
+    for v in np.linspace(-30, 30, 241):
+        assert capi.rg_gain_steps(float(v)) == L.rgo_gain_steps(float(v))
+        assert capi.rg_db_to_steps(float(v)) == L.rgo_gain_steps(float(v))
+        assert capi.rg_gain_from_loudness(float(v)) == L.rgo_gain_from_loudness(float(v))
+    assert capi.rg_steps_to_db(3) == 4.5 and capi.rg_steps_to_db(-2) == -3.0
+    for steps in (-3, 0, 1, 4, 9):
+        for gain in (-4.0, 1.4, 6.0, 13.3):
+            for peak in (0.05, 0.5, 0.9, 1.0, 1.3):
+                for k in (0, 1):
+                    for w in (0, 1):
+                        assert capi.rg_clip_limit_steps(steps, gain, peak, k, w) == \
+                            L.rgo_clip_limit_steps(steps, gain, peak, k, w)
+
+
+def test_no_gpu_means_a_loud_failure_not_a_fallback(capi):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import mp3rgain_amd as rg
+
+    assert capi.rg_create(0) is None
+    msg = capi.rg_last_error(None).decode()
+    assert "no CPU path" in msg
+    with pytest.raises(rg.ReplayGainError):
+        rg.Analyzer(0)
+    with pytest.raises(rg.ReplayGainError):
+        rg.analyze_track(rg.PcmTrack([np.zeros(10, np.float32)], 44100))
+
+
+def test_pack_tracks_layout():
+    import mp3rgain_amd as rg
+    from mp3rgain_amd.replaygain import pack_tracks
+
+    a = np.arange(5, dtype=np.float32)
+    b = np.arange(3, dtype=np.int16)
+    arena, descs = pack_tracks([rg.PcmTrack([a, a + 10], 44100), rg.PcmTrack([b], 48000)])
+    assert descs[0].offset_bytes == 0 and descs[0].frames == 5 and descs[0].channels == 2 and descs[0].format == 0
+    assert descs[1].offset_bytes == 48 and descs[1].frames == 3 and descs[1].channels == 1 and descs[1].format == 1
+    assert np.array_equal(arena[:20].view(np.float32), a) and np.array_equal(arena[20:40].view(np.float32), a + 10)
+    assert np.array_equal(arena[48:54].view(np.int16), b)
+    with pytest.raises(ValueError):
+        rg.PcmTrack([], 44100)
+    with pytest.raises(TypeError):
+        rg.PcmTrack([np.zeros(4, np.float64)], 44100)
+
+
+def test_product_does_not_reference_the_oracle():
+    """The shipped path must not import, include or link anything under oracle/."""
+    for p in list((ROOT / "mp3rgain_amd").rglob("*.py")) + list((ROOT / "mp3rgain_amd" / "csrc").glob("*")):
+        if p.suffix in (".py", ".hip", ".cpp", ".h") or p.name == "Makefile":
+            assert "oracle" not in p.read_text().lower().replace("no cpu", ""), p
