@@ -137,6 +137,14 @@ int rg_set_stream(rg_ctx *ctx, void *hip_stream);
 /* kernel variant: 0 = auto, 1 = halo-tiled reference kernel, 2 = transient-moment kernel */
 int rg_set_kernel(rg_ctx *ctx, int variant);
 
+/* tuning knobs (0 restores the default): key 1 = segment length of variant 2 in frames (must divide
+ * the 50 ms window), key 2 = number of segments (lanes) variant 2 aims for when it picks one */
+int rg_set_tuning(rg_ctx *ctx, int key, int64_t value);
+/* diagnostic (host only): variant 2's design for one rate and segment length.  T_out: [L][12],
+ * gram_last_out: [78]; either may be NULL.  RG_ERR_INVALID_ARG when no design exists. */
+int rg_tm_design_info(uint32_t sample_rate, uint32_t L, uint32_t *H10, uint32_t *rounds, uint32_t *rounds_fast,
+                      double *decoupling_residual, double *T_out, double *gram_last_out);
+
 /* ---- synchronous analysis (mirrors analyze_track / analyze_album minus the decoder) -------- */
 /* analyze_track_internal from the filters onwards, for n independent tracks (`-r` mode).
  * pcm_on_device: 0 = pcm_base is host memory (copied H2D), 1 = pcm_base is a device pointer.

@@ -96,6 +96,8 @@ SYMBOLS = [
     ("rg_last_error", C.c_char_p, [_vp]),
     ("rg_set_stream", _int, [_vp, _vp]),
     ("rg_set_kernel", _int, [_vp, _int]),
+    ("rg_set_tuning", _int, [_vp, _int, C.c_int64]),
+    ("rg_tm_design_info", _int, [_u32, _u32, _P(_u32), _P(_u32), _P(_u32), _P(_dbl), _vp, _vp]),
     ("rg_analyze_pcm_batch", _int, [_vp, _P(TrackDesc), _sz, _vp, _sz, _int, _P(TrackResult), _vp]),
     ("rg_analyze_album_pcm", _int, [_vp, _P(TrackDesc), _sz, _vp, _sz, _int, _P(TrackResult), _P(AlbumResult), _vp]),
     ("rg_find_peak_pcm", _int, [_vp, _P(TrackDesc), _vp, _sz, _int, _P(PeakResult)]),
@@ -122,6 +124,13 @@ def load():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(make -C mp3rgain_amd/csrc). There is no fallback path."
             )
+        # When PyTorch shares the process (tests, bench.py), let it bring its bundled HIP runtime in
+        # first: two HIP runtimes in one process cannot both own the device.
+        import importlib.util
+        import sys
+
+        if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
         L = C.CDLL(str(LIB_PATH))
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)  # AttributeError if the library does not export it

@@ -17,8 +17,7 @@
 #include <string>
 #include <vector>
 
-#include "rg_design.h"
-#include "rg_device.h"
+#include "rg_ctx.h"
 
 // ---- kernel launchers (defined in the kernel translation units) --------------------------------
 extern "C" {
@@ -34,89 +33,10 @@ hipError_t rg_launch_synth_fill(float *, uint64_t, uint32_t, uint32_t, uint64_t,
 }
 
 namespace {
-
 thread_local std::string g_create_error;
+}
 
-template <typename T>
-struct DevBuf {
-    T *p = nullptr;
-    size_t cap = 0;  // elements
-    hipError_t reserve(size_t n) {
-        if (n <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = n + n / 4 + 16;
-        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-template <typename T>
-struct PinnedBuf {
-    T *p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t n) {
-        if (n <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = n + n / 4 + 16;
-        hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() {
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-}  // namespace
-
-struct rg_ctx {
-    int device = -1;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    std::string err;
-    int kernel_variant = 0;
-
-    RgRateDesign design[RG_NUM_RATES];
-    DevBuf<RgCoefDev> d_coefs;
-
-    DevBuf<RgTrackDev> d_tracks;
-    PinnedBuf<RgTrackDev> h_tracks;
-    DevBuf<uint32_t> d_hist;
-    DevBuf<unsigned long long> d_peak_bits;
-    DevBuf<rg_track_result> d_results;
-    PinnedBuf<rg_track_result> h_results;
-    DevBuf<uint32_t> d_album_hist;
-    DevBuf<double> d_album_peak;
-    DevBuf<rg_album_result> d_album_result;
-    PinnedBuf<rg_album_result> h_album_result;
-    DevBuf<unsigned char> d_arena;  // staging for host PCM
-
-    size_t n_enqueued = 0;
-    bool album_ready = false;
-
-    // timing of the dominant kernel
-    bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-    size_t ev_used = 0;
-    double timing_sum_ms = 0.0;
-    uint64_t timing_count = 0;
-};
-
-namespace {
-
-int set_err(rg_ctx *c, int code, const char *fmt, ...) {
+int rg_set_err(rg_ctx *c, int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -126,20 +46,18 @@ int set_err(rg_ctx *c, int code, const char *fmt, ...) {
     return code;
 }
 
-#define RG_HIP(ctx, call)                                                                       \
-    do {                                                                                        \
-        hipError_t e__ = (call);                                                                \
-        if (e__ != hipSuccess)                                                                  \
-            return set_err((ctx), RG_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e__)); \
-    } while (0)
-
-int rate_index(uint32_t sr) {
+int rg_rate_index(uint32_t sr) {
     for (int i = 0; i < RG_NUM_RATES; ++i)
         if (RG_RATE_TABLE[i].sample_rate == sr) return i;
     return -1;
 }
 
-size_t bytes_per_sample(uint32_t fmt) { return fmt == RG_FMT_S16_PLANAR ? 2 : 4; }
+int rg_bind_device(rg_ctx *c) {
+    RG_HIP(c, hipSetDevice(c->device));
+    return RG_OK;
+}
+
+namespace {
 
 int32_t round_to_i32(double v) {  // Rust: f64::round() as i32
     double r = round(v);
@@ -147,11 +65,6 @@ int32_t round_to_i32(double v) {  // Rust: f64::round() as i32
     if (r >= 2147483647.0) return INT32_MAX;
     if (r <= -2147483648.0) return INT32_MIN;
     return (int32_t)r;
-}
-
-int bind_device(rg_ctx *c) {
-    RG_HIP(c, hipSetDevice(c->device));
-    return RG_OK;
 }
 
 // flush finished timing events into the running sum (requires the stream to be idle)
@@ -171,7 +84,7 @@ int drain_timing(rg_ctx *c) {
 // ================================ pure helpers =====================================================
 extern "C" int rg_abi_version(void) { return RG_ABI_VERSION; }
 extern "C" int rg_is_available(void) { return 1; }
-extern "C" int rg_supported_rate(uint32_t sr) { return rate_index(sr) >= 0 ? 1 : 0; }
+extern "C" int rg_supported_rate(uint32_t sr) { return rg_rate_index(sr) >= 0 ? 1 : 0; }
 extern "C" uint32_t rg_window_samples(uint32_t sr) { return (uint32_t)(((uint64_t)sr * 50u) / 1000u); }
 
 extern "C" double rg_hist_loudness(const uint32_t *hist) {
@@ -206,7 +119,7 @@ extern "C" int32_t rg_clip_limit_steps(int32_t steps, double gain_db, double pea
 }
 
 extern "C" int rg_rate_design_info(uint32_t sr, int *stable, uint32_t *halo, double *decay) {
-    const int ri = rate_index(sr);
+    const int ri = rg_rate_index(sr);
     if (ri < 0) return RG_ERR_UNSUPPORTED_RATE;
     RgRateDesign d;
     rg_design_rate(RG_RATE_TABLE[ri], &d);
@@ -223,29 +136,30 @@ extern "C" rg_ctx *rg_create(int device) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {
-        set_err(nullptr, RG_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+        rg_set_err(nullptr, RG_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
                 e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
         return nullptr;
     }
     if (device < 0 || device >= count) {
-        set_err(nullptr, RG_ERR_INVALID_ARG, "device ordinal %d out of range (have %d)", device, count);
+        rg_set_err(nullptr, RG_ERR_INVALID_ARG, "device ordinal %d out of range (have %d)", device, count);
         return nullptr;
     }
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
-        set_err(nullptr, RG_ERR_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+        rg_set_err(nullptr, RG_ERR_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
         return nullptr;
     }
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        set_err(nullptr, RG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
+        rg_set_err(nullptr, RG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
                 prop.gcnArchName);
         return nullptr;
     }
     rg_ctx *c = new rg_ctx();
     c->device = device;
     if ((e = hipSetDevice(device)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
-        set_err(nullptr, RG_ERR_DEVICE, "stream creation: %s", hipGetErrorString(e));
+        (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->staging_done, hipEventDisableTiming)) != hipSuccess) {
+        rg_set_err(nullptr, RG_ERR_DEVICE, "stream creation: %s", hipGetErrorString(e));
         delete c;
         return nullptr;
     }
@@ -265,7 +179,7 @@ extern "C" rg_ctx *rg_create(int device) {
         (e = c->d_album_hist.reserve(RG_HISTOGRAM_SIZE)) != hipSuccess ||
         (e = c->d_album_peak.reserve(1)) != hipSuccess || (e = c->d_album_result.reserve(1)) != hipSuccess ||
         (e = c->h_album_result.reserve(1)) != hipSuccess) {
-        set_err(nullptr, RG_ERR_DEVICE, "context allocation: %s", hipGetErrorString(e));
+        rg_set_err(nullptr, RG_ERR_DEVICE, "context allocation: %s", hipGetErrorString(e));
         rg_destroy(c);
         return nullptr;
     }
@@ -283,6 +197,13 @@ extern "C" void rg_destroy(rg_ctx *c) {
     c->d_coefs.release();
     c->d_tracks.release();
     c->h_tracks.release();
+    c->d_k1_tracks.release();
+    c->h_k1_tracks.release();
+    c->d_tm_tracks.release();
+    c->h_tm_tracks.release();
+    c->d_tm_rec.release();
+    rg_tm_tables_release(c);
+    if (c->staging_done) (void)hipEventDestroy(c->staging_done);
     c->d_hist.release();
     c->d_peak_bits.release();
     c->d_results.release();
@@ -298,7 +219,7 @@ extern "C" void rg_destroy(rg_ctx *c) {
 
 extern "C" int rg_set_stream(rg_ctx *c, void *s) {
     if (!c) return RG_ERR_INVALID_ARG;
-    if (bind_device(c) != RG_OK) return RG_ERR_DEVICE;
+    if (rg_bind_device(c) != RG_OK) return RG_ERR_DEVICE;
     RG_HIP(c, hipStreamSynchronize(c->stream));
     c->stream = s ? (hipStream_t)s : c->own_stream;
     return RG_OK;
@@ -306,8 +227,34 @@ extern "C" int rg_set_stream(rg_ctx *c, void *s) {
 
 extern "C" int rg_set_kernel(rg_ctx *c, int variant) {
     if (!c) return RG_ERR_INVALID_ARG;
-    if (variant < 0 || variant > 1) return set_err(c, RG_ERR_INVALID_ARG, "unknown kernel variant %d", variant);
+    if (variant < 0 || variant > 2) return rg_set_err(c, RG_ERR_INVALID_ARG, "unknown kernel variant %d", variant);
     c->kernel_variant = variant;
+    return RG_OK;
+}
+
+extern "C" int rg_set_tuning(rg_ctx *c, int key, int64_t value) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    if (value < 0) return rg_set_err(c, RG_ERR_INVALID_ARG, "negative tuning value");
+    switch (key) {
+        case RG_TUNE_TM_SEGMENT: c->tune_tm_segment = (uint32_t)value; return RG_OK;
+        case RG_TUNE_TM_TARGET_LANES: c->tune_tm_target_lanes = (uint64_t)value; return RG_OK;
+        default: return rg_set_err(c, RG_ERR_INVALID_ARG, "unknown tuning key %d", key);
+    }
+}
+
+extern "C" int rg_tm_design_info(uint32_t sr, uint32_t L, uint32_t *H10, uint32_t *rounds, uint32_t *rounds_fast,
+                                 double *resid, double *T_out, double *gram_last_out) {
+    const int ri = rg_rate_index(sr);
+    if (ri < 0) return RG_ERR_UNSUPPORTED_RATE;
+    RgTmDesign d;
+    rg_tm_design(RG_RATE_TABLE[ri], L, &d);
+    if (!d.ok) return RG_ERR_INVALID_ARG;
+    if (H10) *H10 = d.H10;
+    if (rounds) *rounds = d.rounds;
+    if (rounds_fast) *rounds_fast = d.rounds_fast;
+    if (resid) *resid = d.resid;
+    if (T_out) memcpy(T_out, d.T.data(), d.T.size() * sizeof(double));
+    if (gram_last_out) memcpy(gram_last_out, d.Gp.data() + (size_t)(L - 1) * RG_TM_GRAM, RG_TM_GRAM * sizeof(double));
     return RG_OK;
 }
 
@@ -319,7 +266,7 @@ extern "C" int rg_timing_enable(rg_ctx *c, int on) {
 
 extern "C" int rg_timing_read(rg_ctx *c, double *sum_ms, uint64_t *launches, int reset) {
     if (!c) return RG_ERR_INVALID_ARG;
-    if (bind_device(c) != RG_OK) return RG_ERR_DEVICE;
+    if (rg_bind_device(c) != RG_OK) return RG_ERR_DEVICE;
     RG_HIP(c, hipStreamSynchronize(c->stream));
     int rc = drain_timing(c);
     if (rc != RG_OK) return rc;
@@ -332,123 +279,7 @@ extern "C" int rg_timing_read(rg_ctx *c, double *sum_ms, uint64_t *launches, int
     return RG_OK;
 }
 
-// ================================ enqueue ===========================================================
 namespace {
-
-// Validate the batch and build the per-track launch descriptors (host side of
-// analyze_track_internal's set-up, src/replaygain.rs:848-878).
-int build_descs(rg_ctx *c, const rg_track_desc *tracks, size_t n, const unsigned char *d_base, size_t pcm_bytes,
-                uint32_t *total_items_out) {
-    uint64_t total_windows = 0;
-    for (size_t t = 0; t < n; ++t) {
-        const rg_track_desc &d = tracks[t];
-        if (rate_index(d.sample_rate) < 0)
-            return set_err(c, RG_ERR_UNSUPPORTED_RATE,
-                           "Unsupported sample rate: %u Hz. Supported rates: 96000, 88200, 64000, 48000, 44100, "
-                           "32000, 24000, 22050, 16000, 12000, 11025, 8000",
-                           d.sample_rate);
-        if (d.channels == 0) return set_err(c, RG_ERR_INVALID_ARG, "track %zu: channels == 0", t);
-        if (d.format > RG_FMT_S32_PLANAR) return set_err(c, RG_ERR_INVALID_ARG, "track %zu: unknown format %u", t, d.format);
-        const size_t bps = bytes_per_sample(d.format);
-        if (d.offset_bytes % bps) return set_err(c, RG_ERR_INVALID_ARG, "track %zu: offset not sample-aligned", t);
-        const uint64_t need = d.offset_bytes + (uint64_t)d.channels * d.frames * bps;
-        if (need > pcm_bytes)
-            return set_err(c, RG_ERR_INVALID_ARG, "track %zu: extends past the PCM arena (%llu > %zu)", t,
-                           (unsigned long long)need, pcm_bytes);
-        const uint32_t W = rg_window_samples(d.sample_rate);
-        total_windows += (d.frames + W - 1) / W;
-    }
-    // segment length: enough work items to fill the chip, long enough to amortise the halo
-    uint32_t seg_windows = 1;
-    if (total_windows > (1u << 18)) {
-        uint64_t s = total_windows >> 17;
-        seg_windows = (uint32_t)(s > 16 ? 16 : s);
-    }
-    uint64_t items = 0;
-    for (size_t t = 0; t < n; ++t) {
-        const rg_track_desc &d = tracks[t];
-        const int ri = rate_index(d.sample_rate);
-        const size_t bps = bytes_per_sample(d.format);
-        RgTrackDev &o = c->h_tracks.p[t];
-        o.ch0 = d_base + d.offset_bytes;
-        o.ch1 = d.channels >= 2 ? d_base + d.offset_bytes + d.frames * bps : nullptr;
-        o.frames = d.frames;
-        o.window = rg_window_samples(d.sample_rate);
-        const uint64_t nw = (d.frames + o.window - 1) / o.window;
-        if (nw > 0xFFFFFFFFull) return set_err(c, RG_ERR_INVALID_ARG, "track %zu: too long", t);
-        o.n_windows = (uint32_t)nw;
-        if (c->design[ri].stable) {
-            o.seg_windows = seg_windows;
-            o.halo = c->design[ri].halo_frames;
-        } else {  // 88.2 kHz row: the recursion diverges, only the sequential order is defined
-            o.seg_windows = o.n_windows ? o.n_windows : 1;
-            o.halo = 0xFFFFFFFFu;
-        }
-        o.n_segments = (o.n_windows + o.seg_windows - 1) / o.seg_windows;
-        o.coef_idx = (uint32_t)ri;
-        o.format = d.format;
-        o.item_base = (uint32_t)items;
-        o.sample_rate = d.sample_rate;
-        o.file_type = RG_FILE_MP3;
-        items += o.n_segments;
-        if (items > 0x7FFFFFFFull) return set_err(c, RG_ERR_INVALID_ARG, "batch too large");
-    }
-    *total_items_out = (uint32_t)items;
-    return RG_OK;
-}
-
-int enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *d_pcm_base, size_t pcm_bytes,
-                 int album) {
-    if (!c) return RG_ERR_INVALID_ARG;
-    if (n && (!tracks || !d_pcm_base)) return set_err(c, RG_ERR_INVALID_ARG, "null tracks / pcm_base");
-    if (n > 0x7FFFFFFFull) return set_err(c, RG_ERR_INVALID_ARG, "too many tracks");
-    int rc = bind_device(c);
-    if (rc != RG_OK) return rc;
-    hipStream_t s = c->stream;
-
-    RG_HIP(c, c->h_tracks.reserve(n));
-    RG_HIP(c, c->d_tracks.reserve(n));
-    RG_HIP(c, c->d_hist.reserve(n * (size_t)RG_HISTOGRAM_SIZE));
-    RG_HIP(c, c->d_peak_bits.reserve(n));
-    RG_HIP(c, c->d_results.reserve(n));
-    RG_HIP(c, c->h_results.reserve(n));
-
-    uint32_t total_items = 0;
-    rc = build_descs(c, tracks, n, (const unsigned char *)d_pcm_base, pcm_bytes, &total_items);
-    if (rc != RG_OK) return rc;
-
-    c->n_enqueued = n;
-    c->album_ready = false;
-    if (n) {
-        RG_HIP(c, hipMemcpyAsync(c->d_tracks.p, c->h_tracks.p, n * sizeof(RgTrackDev), hipMemcpyHostToDevice, s));
-        RG_HIP(c, hipMemsetAsync(c->d_hist.p, 0, n * (size_t)RG_HISTOGRAM_SIZE * sizeof(uint32_t), s));
-        RG_HIP(c, hipMemsetAsync(c->d_peak_bits.p, 0, n * sizeof(unsigned long long), s));
-
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (c->timing) {
-            if (c->ev_used == c->ev_pool.size()) {
-                hipEvent_t a, b;
-                RG_HIP(c, hipEventCreate(&a));
-                RG_HIP(c, hipEventCreate(&b));
-                c->ev_pool.emplace_back(a, b);
-            }
-            e0 = c->ev_pool[c->ev_used].first;
-            e1 = c->ev_pool[c->ev_used].second;
-            c->ev_used += 1;
-            RG_HIP(c, hipEventRecord(e0, s));
-        }
-        RG_HIP(c, rg_launch_k1_halo(c->d_tracks.p, (uint32_t)n, total_items, c->d_coefs.p, c->d_hist.p,
-                                    c->d_peak_bits.p, s));
-        if (c->timing) RG_HIP(c, hipEventRecord(e1, s));
-        RG_HIP(c, rg_launch_track_results(c->d_hist.p, c->d_peak_bits.p, c->d_tracks.p, c->d_results.p, (uint32_t)n, s));
-    }
-    if (album) {
-        RG_HIP(c, rg_launch_album_merge(c->d_hist.p, c->d_peak_bits.p, (uint32_t)n, c->d_album_hist.p,
-                                        c->d_album_peak.p, s));
-        c->album_ready = true;
-    }
-    return RG_OK;
-}
 
 // copy a host PCM arena to the device staging buffer
 int stage_pcm(rg_ctx *c, const void *pcm_base, size_t pcm_bytes, int on_device, const void **d_base) {
@@ -456,7 +287,7 @@ int stage_pcm(rg_ctx *c, const void *pcm_base, size_t pcm_bytes, int on_device, 
         *d_base = pcm_base;
         return RG_OK;
     }
-    int rc = bind_device(c);
+    int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
     RG_HIP(c, hipStreamSynchronize(c->stream));  // the arena may still be read by a previous batch
     RG_HIP(c, c->d_arena.reserve(pcm_bytes ? pcm_bytes : 1));
@@ -469,7 +300,7 @@ int stage_pcm(rg_ctx *c, const void *pcm_base, size_t pcm_bytes, int on_device, 
 
 extern "C" int rg_enqueue_pcm_batch(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *d_pcm_base,
                                     size_t pcm_bytes, int album) {
-    return enqueue_impl(c, tracks, n, d_pcm_base, pcm_bytes, album);
+    return rg_enqueue_impl(c, tracks, n, d_pcm_base, pcm_bytes, album);
 }
 
 extern "C" int rg_device_view_get(rg_ctx *c, rg_device_view *v) {
@@ -484,7 +315,7 @@ extern "C" int rg_device_view_get(rg_ctx *c, rg_device_view *v) {
 
 extern "C" int rg_collect(rg_ctx *c, rg_track_result *out, uint32_t *hist_out) {
     if (!c) return RG_ERR_INVALID_ARG;
-    int rc = bind_device(c);
+    int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
     const size_t n = c->n_enqueued;
     if (n && out)
@@ -500,8 +331,8 @@ extern "C" int rg_collect(rg_ctx *c, rg_track_result *out, uint32_t *hist_out) {
 
 extern "C" int rg_album_result_enqueue(rg_ctx *c) {
     if (!c) return RG_ERR_INVALID_ARG;
-    if (!c->album_ready) return set_err(c, RG_ERR_STATE, "rg_album_result_enqueue without an album enqueue");
-    int rc = bind_device(c);
+    if (!c->album_ready) return rg_set_err(c, RG_ERR_STATE, "rg_album_result_enqueue without an album enqueue");
+    int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
     RG_HIP(c, rg_launch_album_result(c->d_album_hist.p, c->d_album_peak.p, c->d_album_result.p, c->stream));
     return RG_OK;
@@ -509,8 +340,8 @@ extern "C" int rg_album_result_enqueue(rg_ctx *c) {
 
 extern "C" int rg_album_finish(rg_ctx *c, rg_album_result *album_out, uint32_t *album_hist_out) {
     if (!c) return RG_ERR_INVALID_ARG;
-    if (!c->album_ready) return set_err(c, RG_ERR_STATE, "rg_album_finish without an album enqueue");
-    int rc = bind_device(c);
+    if (!c->album_ready) return rg_set_err(c, RG_ERR_STATE, "rg_album_finish without an album enqueue");
+    int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
     RG_HIP(c, rg_launch_album_result(c->d_album_hist.p, c->d_album_peak.p, c->d_album_result.p, c->stream));
     RG_HIP(c, hipMemcpyAsync(c->h_album_result.p, c->d_album_result.p, sizeof(rg_album_result), hipMemcpyDeviceToHost,
@@ -542,19 +373,19 @@ void *resolve(const char *name) {
 
 extern "C" int rg_album_allreduce(rg_ctx *c, void *comm) {
     if (!c) return RG_ERR_INVALID_ARG;
-    if (!c->album_ready) return set_err(c, RG_ERR_STATE, "rg_album_allreduce without an album enqueue");
+    if (!c->album_ready) return rg_set_err(c, RG_ERR_STATE, "rg_album_allreduce without an album enqueue");
     if (!comm) return RG_OK;  // single GPU: nothing to exchange
     nccl_allreduce_fn ar = (nccl_allreduce_fn)resolve("ncclAllReduce");
     nccl_group_fn gs = (nccl_group_fn)resolve("ncclGroupStart");
     nccl_group_fn ge = (nccl_group_fn)resolve("ncclGroupEnd");
-    if (!ar || !gs || !ge) return set_err(c, RG_ERR_COLLECTIVE, "RCCL entry points not found (librccl.so)");
-    int rc = bind_device(c);
+    if (!ar || !gs || !ge) return rg_set_err(c, RG_ERR_COLLECTIVE, "RCCL entry points not found (librccl.so)");
+    int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
     int r = gs();
     if (r == 0) r = ar(c->d_album_hist.p, c->d_album_hist.p, RG_HISTOGRAM_SIZE, kNcclUint32, kNcclSum, comm, c->stream);
     if (r == 0) r = ar(c->d_album_peak.p, c->d_album_peak.p, 1, kNcclFloat64, kNcclMax, comm, c->stream);
     int r2 = ge();
-    if (r != 0 || r2 != 0) return set_err(c, RG_ERR_COLLECTIVE, "ncclAllReduce failed (%d/%d)", r, r2);
+    if (r != 0 || r2 != 0) return rg_set_err(c, RG_ERR_COLLECTIVE, "ncclAllReduce failed (%d/%d)", r, r2);
     return RG_OK;
 }
 
@@ -562,11 +393,11 @@ extern "C" int rg_album_allreduce(rg_ctx *c, void *comm) {
 extern "C" int rg_analyze_pcm_batch(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *pcm_base,
                                     size_t pcm_bytes, int on_device, rg_track_result *out, uint32_t *hist_out) {
     if (!c) return RG_ERR_INVALID_ARG;
-    if (n && !pcm_base) return set_err(c, RG_ERR_INVALID_ARG, "null pcm_base");
+    if (n && !pcm_base) return rg_set_err(c, RG_ERR_INVALID_ARG, "null pcm_base");
     const void *d_base = nullptr;
     int rc = stage_pcm(c, pcm_base, pcm_bytes, on_device, &d_base);
     if (rc != RG_OK) return rc;
-    rc = enqueue_impl(c, tracks, n, d_base, pcm_bytes, 0);
+    rc = rg_enqueue_impl(c, tracks, n, d_base, pcm_bytes, 0);
     if (rc != RG_OK) return rc;
     return rg_collect(c, out, hist_out);
 }
@@ -575,11 +406,11 @@ extern "C" int rg_analyze_album_pcm(rg_ctx *c, const rg_track_desc *tracks, size
                                     size_t pcm_bytes, int on_device, rg_track_result *tracks_out,
                                     rg_album_result *album_out, uint32_t *album_hist_out) {
     if (!c) return RG_ERR_INVALID_ARG;
-    if (n && !pcm_base) return set_err(c, RG_ERR_INVALID_ARG, "null pcm_base");
+    if (n && !pcm_base) return rg_set_err(c, RG_ERR_INVALID_ARG, "null pcm_base");
     const void *d_base = nullptr;
     int rc = stage_pcm(c, pcm_base, pcm_bytes, on_device, &d_base);
     if (rc != RG_OK) return rc;
-    rc = enqueue_impl(c, tracks, n, d_base, pcm_bytes, 1);
+    rc = rg_enqueue_impl(c, tracks, n, d_base, pcm_bytes, 1);
     if (rc != RG_OK) return rc;
     rc = rg_collect(c, tracks_out, nullptr);
     if (rc != RG_OK) return rc;
@@ -589,10 +420,10 @@ extern "C" int rg_analyze_album_pcm(rg_ctx *c, const rg_track_desc *tracks, size
 extern "C" int rg_find_peak_pcm(rg_ctx *c, const rg_track_desc *track, const void *pcm_base, size_t pcm_bytes,
                                 int on_device, rg_peak_result *out) {
     if (!c || !track || !out) return RG_ERR_INVALID_ARG;
-    if (track->format > RG_FMT_S32_PLANAR) return set_err(c, RG_ERR_INVALID_ARG, "unknown format");
-    const size_t bps = bytes_per_sample(track->format);
+    if (track->format > RG_FMT_S32_PLANAR) return rg_set_err(c, RG_ERR_INVALID_ARG, "unknown format");
+    const size_t bps = rg_bytes_per_sample(track->format);
     const uint64_t total = (uint64_t)track->channels * track->frames;
-    if (track->offset_bytes + total * bps > pcm_bytes) return set_err(c, RG_ERR_INVALID_ARG, "track extends past arena");
+    if (track->offset_bytes + total * bps > pcm_bytes) return rg_set_err(c, RG_ERR_INVALID_ARG, "track extends past arena");
     const void *d_base = nullptr;
     int rc = stage_pcm(c, pcm_base, pcm_bytes, on_device, &d_base);
     if (rc != RG_OK) return rc;
@@ -615,7 +446,7 @@ extern "C" int rg_find_peak_pcm(rg_ctx *c, const rg_track_desc *track, const voi
 extern "C" int rg_synth_fill_device(rg_ctx *c, void *d_dst, uint64_t seed, uint32_t channel, uint32_t sample_rate,
                                     uint64_t first_frame, uint64_t frames) {
     if (!c || (!d_dst && frames)) return RG_ERR_INVALID_ARG;
-    int rc = bind_device(c);
+    int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
     RG_HIP(c, rg_launch_synth_fill((float *)d_dst, seed, channel, sample_rate, first_frame, frames, c->stream));
     return RG_OK;

@@ -61,3 +61,210 @@ void rg_design_rate(const rg_rate_coeffs &rc, RgRateDesign *out) {
     for (size_t k = b; k < b + w && k < h.size(); ++k) e2 += fabsl(h[k]);
     out->pole_radius = (e1 > 0 && e2 > 0 && b > a) ? (double)powl(e2 / e1, 1.0L / (long double)(b - a)) : 0.0;
 }
+
+// =================================================================================================
+// variant 2: transient-moment tables
+// =================================================================================================
+#include <string.h>
+
+#include "rg_tm.h"
+
+namespace {
+
+typedef long double ld;
+
+// one step of the cascade in transposed direct form II, exactly the kernel's recursion
+// (rg_k2_tm.hip: tm_step), homogeneous part only when x = 0 and c = 0
+void tm_step_ld(const rg_rate_coeffs &rc, ld q[12], ld x, ld c, ld *z_out) {
+    ld n[12];
+    const ld y = (ld)rc.yule_b[0] * x + q[0];
+    for (int i = 0; i < 9; ++i) n[i] = q[i + 1] + (ld)rc.yule_b[i + 1] * x - (ld)rc.yule_a[i + 1] * y;
+    n[9] = (ld)rc.yule_b[10] * x - (ld)rc.yule_a[10] * y + c;
+    const ld z = (ld)rc.butter_b[0] * y + q[10];
+    n[10] = q[11] + (ld)rc.butter_b[1] * y - (ld)rc.butter_a[1] * z;
+    n[11] = (ld)rc.butter_b[2] * y - (ld)rc.butter_a[2] * z + c;
+    memcpy(q, n, sizeof n);
+    *z_out = z;
+}
+
+// dense solve with partial pivoting, in place; returns false when singular
+bool solve_ld(int n, std::vector<ld> &A, std::vector<ld> &b) {
+    for (int col = 0; col < n; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < n; ++r)
+            if (fabsl(A[r * n + col]) > fabsl(A[piv * n + col])) piv = r;
+        if (fabsl(A[piv * n + col]) < 1e-300L) return false;
+        if (piv != col) {
+            for (int k = 0; k < n; ++k) std::swap(A[col * n + k], A[piv * n + k]);
+            std::swap(b[col], b[piv]);
+        }
+        for (int r = col + 1; r < n; ++r) {
+            const ld f = A[r * n + col] / A[col * n + col];
+            if (f == 0.0L) continue;
+            for (int k = col; k < n; ++k) A[r * n + k] -= f * A[col * n + k];
+            b[r] -= f * b[col];
+        }
+    }
+    for (int r = n - 1; r >= 0; --r) {
+        ld s = b[r];
+        for (int k = r + 1; k < n; ++k) s -= A[r * n + k] * b[k];
+        b[r] = s / A[r * n + r];
+    }
+    return true;
+}
+
+void matmul_ld(int n, const ld *A, const ld *B, ld *C) {
+    std::vector<ld> t((size_t)n * n, 0.0L);
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < n; ++k) {
+            const ld a = A[i * n + k];
+            for (int j = 0; j < n; ++j) t[i * n + j] += a * B[k * n + j];
+        }
+    memcpy(C, t.data(), sizeof(ld) * n * n);
+}
+
+ld maxabs(const ld *A, int n) {
+    ld m = 0;
+    for (int i = 0; i < n; ++i) m = fabsl(A[i]) > m ? fabsl(A[i]) : m;
+    return m;
+}
+
+}  // namespace
+
+void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out) {
+    *out = RgTmDesign();
+    const uint32_t W = (uint32_t)(((uint64_t)rc.sample_rate * 50u) / 1000u);
+    if (L == 0 || W % L != 0) return;
+    RgRateDesign rd;
+    rg_design_rate(rc, &rd);
+    if (!rd.stable) return;
+    out->L = L;
+    out->W = W;
+
+    // state matrix F (column j = one homogeneous step from unit state j) and output row h
+    ld F[12][12], h[12];
+    for (int j = 0; j < 12; ++j) {
+        ld q[12] = {0};
+        q[j] = 1.0L;
+        ld z;
+        tm_step_ld(rc, q, 0.0L, 0.0L, &z);
+        for (int i = 0; i < 12; ++i) F[i][j] = q[i];
+        h[j] = z;
+    }
+    // F = [[Fy 0][Cb Fb]]; find X (2x10) with X Fy - Fb X = -Cb so that t' = t + X s decouples
+    std::vector<ld> M(400, 0.0L), rhs(20, 0.0L);
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 10; ++j) {
+            const int r = i * 10 + j;
+            for (int k = 0; k < 10; ++k) M[r * 20 + i * 10 + k] += F[k][j];
+            for (int k = 0; k < 2; ++k) M[r * 20 + k * 10 + j] -= F[10 + i][10 + k];
+            rhs[r] = -F[10 + i][j];
+        }
+    std::vector<ld> M0 = M, x = rhs;
+    if (!solve_ld(20, M, x)) return;
+    {   // one step of iterative refinement
+        std::vector<ld> res(20);
+        for (int r = 0; r < 20; ++r) {
+            ld s = rhs[r];
+            for (int k = 0; k < 20; ++k) s -= M0[r * 20 + k] * x[k];
+            res[r] = s;
+        }
+        std::vector<ld> M1 = M0;
+        if (solve_ld(20, M1, res))
+            for (int k = 0; k < 20; ++k) x[k] += res[k];
+    }
+    ld X[2][10];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 10; ++j) { X[i][j] = x[i * 10 + j]; out->X[i][j] = (double)X[i][j]; }
+    // residual of the decoupling (diagnostic)
+    ld resid = 0;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 10; ++j) {
+            ld s = F[10 + i][j];
+            for (int k = 0; k < 10; ++k) s += X[i][k] * F[k][j];
+            for (int k = 0; k < 2; ++k) s -= F[10 + i][10 + k] * X[k][j];
+            resid = fabsl(s) > resid ? fabsl(s) : resid;
+        }
+    out->resid = (double)resid;
+
+    // block-diagonal dynamics: Fy (10x10), Fb (2x2); output row h' = h P^-1, P^-1 = [[I 0][-X I]]
+    ld Fy[100], Fb[4], hp[12];
+    for (int i = 0; i < 10; ++i)
+        for (int j = 0; j < 10; ++j) Fy[i * 10 + j] = F[i][j];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) Fb[i * 2 + j] = F[10 + i][10 + j];
+    for (int j = 0; j < 10; ++j) hp[j] = h[j] - (h[10] * X[0][j] + h[11] * X[1][j]);
+    hp[10] = h[10];
+    hp[11] = h[11];
+
+    // T'[n] = h' F'^n  (row vector iteration), prefix Gram matrices alongside
+    out->T.resize((size_t)L * 12);
+    out->Gp.resize((size_t)L * RG_TM_GRAM);
+    std::vector<ld> gram(RG_TM_GRAM, 0.0L);
+    ld row[12];
+    memcpy(row, hp, sizeof row);
+    ld tmax = 0;
+    for (uint32_t n = 0; n < L; ++n) {
+        for (int j = 0; j < 12; ++j) {
+            out->T[(size_t)n * 12 + j] = (double)row[j];
+            if (j < 10 && fabsl(row[j]) > tmax) tmax = fabsl(row[j]);
+        }
+        // the kernel multiplies by the rounded table, so the Gram matrix uses the rounded values too
+        int p = 0;
+        for (int j = 0; j < 12; ++j)
+            for (int k = j; k < 12; ++k, ++p)
+                gram[p] += (ld)out->T[(size_t)n * 12 + j] * (ld)out->T[(size_t)n * 12 + k];
+        for (int q = 0; q < RG_TM_GRAM; ++q) out->Gp[(size_t)n * RG_TM_GRAM + q] = (double)gram[q];
+        ld nr[12];
+        for (int j = 0; j < 10; ++j) {
+            ld s = 0;
+            for (int i = 0; i < 10; ++i) s += row[i] * Fy[i * 10 + j];
+            nr[j] = s;
+        }
+        for (int j = 0; j < 2; ++j) nr[10 + j] = row[10] * Fb[0 * 2 + j] + row[11] * Fb[1 * 2 + j];
+        memcpy(row, nr, sizeof row);
+    }
+    // H10: first multiple of 4 after which every fast response stays below 1e-13 of its maximum
+    uint32_t H10 = 0;
+    for (uint32_t n = L; n-- > 0;) {
+        ld m = 0;
+        for (int j = 0; j < 10; ++j) m = fmaxl(m, fabsl((ld)out->T[(size_t)n * 12 + j]));
+        if (m > 1e-13L * tmax) { H10 = n + 1; break; }
+    }
+    H10 = (H10 + 3u) & ~3u;
+    const uint32_t L4 = L & ~3u;
+    out->H10 = H10 > L4 ? L4 : H10;
+
+    // Phi blocks: F^L by repeated multiplication, then squarings for the doubling rounds
+    ld PY[100], PB[4];
+    for (int i = 0; i < 100; ++i) PY[i] = (i / 10 == i % 10) ? 1.0L : 0.0L;
+    PB[0] = PB[3] = 1.0L; PB[1] = PB[2] = 0.0L;
+    for (uint32_t n = 0; n < L; ++n) { matmul_ld(10, PY, Fy, PY); matmul_ld(2, PB, Fb, PB); }
+    uint32_t rounds = 0, rounds_fast = 0;
+    bool fast_done = false;
+    for (int r = 0; r <= RG_TM_MAX_ROUNDS; ++r) {
+        // entering round r the blocks hold Phi^(2^r): if both are negligible, r rounds suffice
+        const bool y_small = maxabs(PY, 100) < 1e-18L, b_small = maxabs(PB, 4) < 1e-18L;
+        if (y_small && !fast_done) { rounds_fast = r; fast_done = true; }
+        if (y_small && b_small) { rounds = r; out->ok = true; break; }
+        if (r == RG_TM_MAX_ROUNDS) break;
+        for (int i = 0; i < 100; ++i) out->PhiY.push_back((double)PY[i]);
+        for (int i = 0; i < 4; ++i) out->PhiB.push_back((double)PB[i]);
+        matmul_ld(10, PY, PY, PY);
+        matmul_ld(2, PB, PB, PB);
+    }
+    if (!out->ok) return;
+    out->rounds = rounds;  // 0 is legal: sigma_k = E_{k-1} alone
+    out->rounds_fast = fast_done ? rounds_fast : rounds;
+    out->PhiY.resize((size_t)rounds * 100);
+    out->PhiB.resize((size_t)rounds * 4);
+
+    // track-start state: every DF2T state holds the +1e-10 offset once (see rg_tm.h), then t' = t + X s
+    const ld c = 1e-10L;
+    for (int j = 0; j < 12; ++j) out->sigma0[j] = (double)c;
+    for (int i = 0; i < 2; ++i) {
+        ld s = c;
+        for (int j = 0; j < 10; ++j) s += X[i][j] * c;
+        out->sigma0[10 + i] = (double)s;
+    }
+}

@@ -15,3 +15,25 @@ struct RgRateDesign {
 };
 
 void rg_design_rate(const rg_rate_coeffs &rc, RgRateDesign *out);
+
+// ---- variant 2 (transient-moment) tables, see rg_tm.h -------------------------------------------
+#include <vector>
+
+struct RgTmDesign {
+    uint32_t L = 0, W = 0;
+    uint32_t H10 = 0;         // multiple of 4, <= L rounded down to a multiple of 4 (or == that bound)
+    uint32_t rounds = 0;      // doubling rounds for the slow (Butter) block
+    uint32_t rounds_fast = 0; // rounds after which the fast (Yule) block's power is below 1e-18
+    std::vector<double> T;       // [L][12]  responses in block-diagonal coordinates
+    std::vector<double> Gp;      // [L][78]  prefix Gram matrices (upper triangle, row major)
+    std::vector<double> PhiY;    // [rounds][10][10]  (F_y^L)^(2^r)
+    std::vector<double> PhiB;    // [rounds][2][2]    (F_b^L)^(2^r)
+    double X[2][10];             // coordinate change: t' = t + X s
+    double sigma0[12];           // track-start state in block-diagonal coordinates
+    double resid;                // Sylvester residual (diagnostic)
+    bool ok = false;
+};
+
+// L must divide W = rate*50/1000.  Returns ok=false for an unstable row or when no truncation
+// with <= RG_TM_MAX_ROUNDS doubling rounds reaches 1e-18.
+void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out);

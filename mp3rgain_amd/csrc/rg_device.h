@@ -38,6 +38,8 @@ struct RgTrackDev {
     uint32_t item_base;    // exclusive prefix sum of work items over the batch
     uint32_t sample_rate;
     uint32_t file_type;    // rg_file_type, carried through to the result
+    uint32_t track_index;  // row of this track in the histogram / peak / result arrays
+    uint32_t pad_;
 };
 
 // 1.0 - RMS_PERCENTILE evaluated in f64 exactly as the reference does (replaygain.rs:671):

@@ -1,0 +1,357 @@
+// rg_enqueue.hip -- batch set-up and kernel launches for one enqueue (host side of
+// analyze_track_internal's set-up, src/replaygain.rs:848-878, for a whole batch at once).
+//
+// Stream order of one batch:
+//   H2D launch descriptors -> memset(histograms, peaks)
+//   variant 2 groups (one per sample rate x sample format x channel count):
+//        rg_tm_main_kernel -> rg_tm_fix_kernel
+//   variant 1 list (all tracks when forced, otherwise only tracks of the unstable 88.2 kHz row)
+//   per-track percentile/result kernel
+//   [album] merge kernel
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "rg_ctx.h"
+
+extern "C" {
+hipError_t rg_launch_k1_halo(const RgTrackDev *, uint32_t, uint32_t, const RgCoefDev *, uint32_t *,
+                             unsigned long long *, hipStream_t);
+hipError_t rg_launch_track_results(const uint32_t *, const unsigned long long *, const RgTrackDev *,
+                                   rg_track_result *, uint32_t, hipStream_t);
+hipError_t rg_launch_album_merge(const uint32_t *, const unsigned long long *, uint32_t, uint32_t *, double *,
+                                 hipStream_t);
+hipError_t rg_launch_tm_main(int fmt, int nch, const RgTmCoef *, const RgTmGeom *, const RgTmTrack *, uint32_t, uint32_t,
+                             double *, uint32_t, unsigned long long *, hipStream_t);
+hipError_t rg_launch_tm_fix(int nch, const RgTmGeom *, const RgTmFixTables *, const RgTmTrack *, uint32_t, uint32_t,
+                            const double *, uint32_t, uint32_t *, hipStream_t);
+}
+
+namespace {
+
+const uint64_t kDefaultTargetLanes = 120000;  // ~2 waves per SIMD on 256 CUs
+const uint32_t kMinSegment = 96;              // shorter segments need more than RG_TM_MAX_ROUNDS doubling rounds
+
+struct TmGroup {
+    int rate_idx, fmt, nch;
+    std::vector<uint32_t> ids;
+    uint64_t frames = 0;
+};
+
+int validate(rg_ctx *c, const rg_track_desc *tracks, size_t n, size_t pcm_bytes) {
+    for (size_t t = 0; t < n; ++t) {
+        const rg_track_desc &d = tracks[t];
+        if (rg_rate_index(d.sample_rate) < 0)
+            return rg_set_err(c, RG_ERR_UNSUPPORTED_RATE,
+                              "Unsupported sample rate: %u Hz. Supported rates: 96000, 88200, 64000, 48000, 44100, "
+                              "32000, 24000, 22050, 16000, 12000, 11025, 8000",
+                              d.sample_rate);
+        if (d.channels == 0) return rg_set_err(c, RG_ERR_INVALID_ARG, "track %zu: channels == 0", t);
+        if (d.format > RG_FMT_S32_PLANAR) return rg_set_err(c, RG_ERR_INVALID_ARG, "track %zu: unknown format %u", t, d.format);
+        const size_t bps = rg_bytes_per_sample(d.format);
+        if (d.offset_bytes % bps) return rg_set_err(c, RG_ERR_INVALID_ARG, "track %zu: offset not sample-aligned", t);
+        const uint64_t need = d.offset_bytes + (uint64_t)d.channels * d.frames * bps;
+        if (need > pcm_bytes)
+            return rg_set_err(c, RG_ERR_INVALID_ARG, "track %zu: extends past the PCM arena (%llu > %zu)", t,
+                              (unsigned long long)need, pcm_bytes);
+        const uint32_t W = rg_window_samples(d.sample_rate);
+        if ((d.frames + W - 1) / W > 0x7FFFFFFFull) return rg_set_err(c, RG_ERR_INVALID_ARG, "track %zu: too long", t);
+    }
+    return RG_OK;
+}
+
+// descriptor every kernel family shares (also what the result kernel reads sample_rate / file_type from)
+void fill_common(rg_ctx *c, const rg_track_desc &d, const unsigned char *d_base, uint32_t track_index, RgTrackDev &o) {
+    const int ri = rg_rate_index(d.sample_rate);
+    const size_t bps = rg_bytes_per_sample(d.format);
+    memset(&o, 0, sizeof o);
+    o.ch0 = d_base + d.offset_bytes;
+    o.ch1 = d.channels >= 2 ? d_base + d.offset_bytes + d.frames * bps : nullptr;
+    o.frames = d.frames;
+    o.window = rg_window_samples(d.sample_rate);
+    o.n_windows = (uint32_t)((d.frames + o.window - 1) / o.window);
+    o.coef_idx = (uint32_t)ri;
+    o.format = d.format;
+    o.sample_rate = d.sample_rate;
+    o.file_type = RG_FILE_MP3;
+    o.track_index = track_index;
+    (void)c;
+}
+
+// variant 1 work split for a list of tracks already filled by fill_common
+int finish_k1_list(rg_ctx *c, RgTrackDev *list, size_t n, uint32_t *total_items) {
+    uint64_t total_windows = 0;
+    for (size_t t = 0; t < n; ++t) total_windows += list[t].n_windows;
+    uint32_t seg_windows = 1;  // enough work items to fill the chip, long enough to amortise the halo
+    if (total_windows > (1u << 18)) {
+        uint64_t s = total_windows >> 17;
+        seg_windows = (uint32_t)(s > 16 ? 16 : s);
+    }
+    uint64_t items = 0;
+    for (size_t t = 0; t < n; ++t) {
+        RgTrackDev &o = list[t];
+        if (c->design[o.coef_idx].stable) {
+            o.seg_windows = seg_windows;
+            o.halo = c->design[o.coef_idx].halo_frames;
+        } else {  // 88.2 kHz row: the recursion diverges, only the sequential order is defined
+            o.seg_windows = o.n_windows ? o.n_windows : 1;
+            o.halo = 0xFFFFFFFFu;
+        }
+        o.n_segments = (o.n_windows + o.seg_windows - 1) / o.seg_windows;
+        o.item_base = (uint32_t)items;
+        items += o.n_segments;
+        if (items > 0x7FFFFFFFull) return rg_set_err(c, RG_ERR_INVALID_ARG, "batch too large");
+    }
+    *total_items = (uint32_t)items;
+    return RG_OK;
+}
+
+// ---- variant 2 tables --------------------------------------------------------------------------
+int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out) {
+    const uint32_t key = ((uint32_t)rate_idx << 16) | L;
+    auto it = c->tm_tables.find(key);
+    if (it != c->tm_tables.end()) {
+        *out = it->second;
+        return it->second->design.ok ? RG_OK : RG_ERR_INVALID_ARG;
+    }
+    RgTmDeviceTables *tb = new RgTmDeviceTables();
+    rg_tm_design(RG_RATE_TABLE[rate_idx], L, &tb->design);
+    c->tm_tables[key] = tb;
+    *out = tb;
+    const RgTmDesign &D = tb->design;
+    if (!D.ok) return RG_ERR_INVALID_ARG;
+    const size_t nT = D.T.size(), nG = D.Gp.size(), nY = D.PhiY.size(), nB = D.PhiB.size();
+    const size_t total = nT + nG + nY + nB + 20 + 12 + 8;
+    std::vector<double> blob(total, 0.0);
+    size_t o = 0;
+    const size_t oT = o; memcpy(&blob[o], D.T.data(), nT * 8); o += nT;
+    const size_t oG = o; memcpy(&blob[o], D.Gp.data(), nG * 8); o += nG;
+    const size_t oY = o; if (nY) memcpy(&blob[o], D.PhiY.data(), nY * 8); o += nY;
+    const size_t oB = o; if (nB) memcpy(&blob[o], D.PhiB.data(), nB * 8); o += nB;
+    const size_t oX = o; memcpy(&blob[o], &D.X[0][0], 20 * 8); o += 20;
+    const size_t oS = o; memcpy(&blob[o], D.sigma0, 12 * 8); o += 12;
+    RG_HIP(c, hipMalloc((void **)&tb->d_blob, total * 8));
+    RG_HIP(c, hipMemcpy(tb->d_blob, blob.data(), total * 8, hipMemcpyHostToDevice));
+    RgTmGeom &g = tb->geom;
+    g.L = D.L;
+    g.W = D.W;
+    g.k = D.W / D.L;
+    g.H10 = D.H10;
+    g.rounds = D.rounds;
+    g.rounds_fast = D.rounds_fast;
+    g.warm = 1u << D.rounds;
+    g.fix_windows = (RG_TM_BLOCK - g.warm) / g.k;
+    g.T = tb->d_blob + oT;
+    tb->fix.Gp = tb->d_blob + oG;
+    tb->fix.PhiY = tb->d_blob + oY;
+    tb->fix.PhiB = tb->d_blob + oB;
+    tb->fix.X = tb->d_blob + oX;
+    tb->fix.sigma0 = tb->d_blob + oS;
+    if (g.fix_windows == 0) {
+        tb->design.ok = false;
+        return RG_ERR_INVALID_ARG;
+    }
+    return RG_OK;
+}
+
+// segment length for one group: the largest divisor of W that still yields enough lanes to fill the
+// chip; workloads too small for that get the smallest admissible divisor
+int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, RgTmDeviceTables **out) {
+    const uint32_t W = rg_window_samples(RG_RATE_TABLE[g.rate_idx].sample_rate);
+    if (c->tune_tm_segment && W % c->tune_tm_segment == 0 &&
+        get_tm_tables(c, g.rate_idx, c->tune_tm_segment, out) == RG_OK)
+        return RG_OK;
+    std::vector<uint32_t> cand;
+    for (uint32_t d = 1; d <= W; ++d)
+        if (W % d == 0 && (d >= kMinSegment || d == W)) cand.push_back(d);
+    const uint64_t target = c->tune_tm_target_lanes ? c->tune_tm_target_lanes : kDefaultTargetLanes;
+    for (size_t i = cand.size(); i-- > 0;) {
+        uint64_t lanes = 0;
+        for (uint32_t id : g.ids) lanes += (tracks[id].frames + cand[i] - 1) / cand[i];
+        if (lanes >= target && get_tm_tables(c, g.rate_idx, cand[i], out) == RG_OK) return RG_OK;
+    }
+    for (size_t i = 0; i < cand.size(); ++i)
+        if (get_tm_tables(c, g.rate_idx, cand[i], out) == RG_OK) return RG_OK;
+    return rg_set_err(c, RG_ERR_INVALID_ARG, "no admissible segment length for %u Hz",
+                      RG_RATE_TABLE[g.rate_idx].sample_rate);
+}
+
+int timing_begin(rg_ctx *c, hipEvent_t *e1) {
+    *e1 = nullptr;
+    if (!c->timing) return RG_OK;
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t a, b;
+        RG_HIP(c, hipEventCreate(&a));
+        RG_HIP(c, hipEventCreate(&b));
+        c->ev_pool.emplace_back(a, b);
+    }
+    hipEvent_t e0 = c->ev_pool[c->ev_used].first;
+    *e1 = c->ev_pool[c->ev_used].second;
+    c->ev_used += 1;
+    RG_HIP(c, hipEventRecord(e0, c->stream));
+    return RG_OK;
+}
+
+}  // namespace
+
+void rg_tm_tables_release(rg_ctx *c) {
+    for (auto &kv : c->tm_tables) {
+        if (kv.second->d_blob) (void)hipFree(kv.second->d_blob);
+        delete kv.second;
+    }
+    c->tm_tables.clear();
+}
+
+int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *d_pcm_base, size_t pcm_bytes,
+                    int album) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    if (n && (!tracks || !d_pcm_base)) return rg_set_err(c, RG_ERR_INVALID_ARG, "null tracks / pcm_base");
+    if (n > 0x7FFFFFFFull) return rg_set_err(c, RG_ERR_INVALID_ARG, "too many tracks");
+    int rc = rg_bind_device(c);
+    if (rc != RG_OK) return rc;
+    hipStream_t s = c->stream;
+    rc = validate(c, tracks, n, pcm_bytes);
+    if (rc != RG_OK) return rc;
+
+    // the pinned staging buffers may still feed the previous batch's H2D copies
+    if (c->staging_pending) {
+        RG_HIP(c, hipEventSynchronize(c->staging_done));
+        c->staging_pending = false;
+    }
+
+    RG_HIP(c, c->h_tracks.reserve(n));
+    RG_HIP(c, c->d_tracks.reserve(n));
+    RG_HIP(c, c->h_k1_tracks.reserve(n));
+    RG_HIP(c, c->d_k1_tracks.reserve(n));
+    RG_HIP(c, c->h_tm_tracks.reserve(n));
+    RG_HIP(c, c->d_tm_tracks.reserve(n));
+    RG_HIP(c, c->d_hist.reserve(n * (size_t)RG_HISTOGRAM_SIZE));
+    RG_HIP(c, c->d_peak_bits.reserve(n));
+    RG_HIP(c, c->d_results.reserve(n));
+    RG_HIP(c, c->h_results.reserve(n));
+
+    const unsigned char *base = (const unsigned char *)d_pcm_base;
+    const bool use_tm = c->kernel_variant != 1;
+
+    // ---- split the batch --------------------------------------------------------------------------
+    std::vector<TmGroup> groups;
+    size_t n_k1 = 0;
+    for (size_t t = 0; t < n; ++t) {
+        fill_common(c, tracks[t], base, (uint32_t)t, c->h_tracks.p[t]);
+        const int ri = rg_rate_index(tracks[t].sample_rate);
+        if (use_tm && c->design[ri].stable) {
+            const int nch = tracks[t].channels >= 2 ? 2 : 1;
+            TmGroup *g = nullptr;
+            for (auto &q : groups)
+                if (q.rate_idx == ri && q.fmt == (int)tracks[t].format && q.nch == nch) { g = &q; break; }
+            if (!g) {
+                groups.push_back(TmGroup{ri, (int)tracks[t].format, nch, {}, 0});
+                g = &groups.back();
+            }
+            g->ids.push_back((uint32_t)t);
+            g->frames += tracks[t].frames;
+        } else {
+            c->h_k1_tracks.p[n_k1++] = c->h_tracks.p[t];
+        }
+    }
+    uint32_t k1_items = 0;
+    rc = finish_k1_list(c, c->h_k1_tracks.p, n_k1, &k1_items);
+    if (rc != RG_OK) return rc;
+
+    // ---- variant 2 launch lists -----------------------------------------------------------------------
+    struct GroupLaunch {
+        RgTmDeviceTables *tb;
+        RgTmCoef K;
+        size_t list_off, list_n;
+        uint32_t main_grid, fix_grid, total_recs;
+        int fmt, nch;
+    };
+    std::vector<GroupLaunch> launches;
+    size_t tm_off = 0;
+    size_t max_rec_doubles = 0;
+    for (const TmGroup &g : groups) {
+        GroupLaunch gl{};
+        rc = choose_tm_tables(c, g, tracks, &gl.tb);
+        if (rc != RG_OK) return rc;
+        const RgTmGeom &geo = gl.tb->geom;
+        const rg_rate_coeffs &rcf = RG_RATE_TABLE[g.rate_idx];
+        // the power-of-two input scale of the sample format is folded into the feed-forward taps
+        // (exact): F32 x 32768 (src/replaygain.rs:969), S16 x 1 (:990), S32 x 32768/2^31 (:1005)
+        const double scale = g.fmt == RG_FMT_F32_PLANAR ? 32768.0 : (g.fmt == RG_FMT_S16_PLANAR ? 1.0 : 32768.0 / 2147483648.0);
+        for (int i = 0; i < 11; ++i) { gl.K.b[i] = rcf.yule_b[i] * scale; gl.K.a[i] = rcf.yule_a[i]; }
+        for (int i = 0; i < 3; ++i) { gl.K.bb[i] = rcf.butter_b[i]; gl.K.ba[i] = rcf.butter_a[i]; }
+        gl.K.c0 = 1e-10;
+        gl.fmt = g.fmt;
+        gl.nch = g.nch;
+        gl.list_off = tm_off;
+        gl.list_n = g.ids.size();
+        uint64_t recs = 0, mb = 0, fb = 0;
+        const uint32_t NB = geo.fix_windows * geo.k;
+        for (uint32_t id : g.ids) {
+            const RgTrackDev &cd = c->h_tracks.p[id];
+            RgTmTrack &o = c->h_tm_tracks.p[tm_off++];
+            o.ch0 = cd.ch0;
+            o.ch1 = cd.ch1;
+            o.frames = cd.frames;
+            o.nseg = (uint32_t)((cd.frames + geo.L - 1) / geo.L);
+            o.n_windows = cd.n_windows;
+            o.rec_base = (uint32_t)recs;
+            o.main_block_base = (uint32_t)mb;
+            o.fix_block_base = (uint32_t)fb;
+            o.track_index = id;
+            recs += o.nseg;
+            mb += (o.nseg + RG_TM_BLOCK - 1) / RG_TM_BLOCK;
+            fb += (o.nseg + NB - 1) / NB;
+            if (recs > 0x7FFFFFFFull || mb > 0x7FFFFFFFull || fb > 0x7FFFFFFFull)
+                return rg_set_err(c, RG_ERR_INVALID_ARG, "batch too large");
+        }
+        gl.total_recs = (uint32_t)recs;
+        gl.main_grid = (uint32_t)mb;
+        gl.fix_grid = (uint32_t)fb;
+        max_rec_doubles = std::max(max_rec_doubles, (size_t)recs * RG_TM_REC * g.nch);
+        launches.push_back(gl);
+    }
+    RG_HIP(c, c->d_tm_rec.reserve(max_rec_doubles ? max_rec_doubles : 1));
+
+    c->n_enqueued = n;
+    c->album_ready = false;
+    if (n) {
+        RG_HIP(c, hipMemcpyAsync(c->d_tracks.p, c->h_tracks.p, n * sizeof(RgTrackDev), hipMemcpyHostToDevice, s));
+        if (n_k1)
+            RG_HIP(c, hipMemcpyAsync(c->d_k1_tracks.p, c->h_k1_tracks.p, n_k1 * sizeof(RgTrackDev), hipMemcpyHostToDevice, s));
+        if (tm_off)
+            RG_HIP(c, hipMemcpyAsync(c->d_tm_tracks.p, c->h_tm_tracks.p, tm_off * sizeof(RgTmTrack), hipMemcpyHostToDevice, s));
+        RG_HIP(c, hipEventRecord(c->staging_done, s));
+        c->staging_pending = true;
+        RG_HIP(c, hipMemsetAsync(c->d_hist.p, 0, n * (size_t)RG_HISTOGRAM_SIZE * sizeof(uint32_t), s));
+        RG_HIP(c, hipMemsetAsync(c->d_peak_bits.p, 0, n * sizeof(unsigned long long), s));
+
+        for (const GroupLaunch &gl : launches) {
+            hipEvent_t e1;
+            rc = timing_begin(c, &e1);
+            if (rc != RG_OK) return rc;
+            RG_HIP(c, rg_launch_tm_main(gl.fmt, gl.nch, &gl.K, &gl.tb->geom, c->d_tm_tracks.p + gl.list_off,
+                                        (uint32_t)gl.list_n, gl.main_grid, c->d_tm_rec.p, gl.total_recs,
+                                        c->d_peak_bits.p, s));
+            if (e1) RG_HIP(c, hipEventRecord(e1, s));
+            RG_HIP(c, rg_launch_tm_fix(gl.nch, &gl.tb->geom, &gl.tb->fix, c->d_tm_tracks.p + gl.list_off,
+                                       (uint32_t)gl.list_n, gl.fix_grid, c->d_tm_rec.p, gl.total_recs, c->d_hist.p, s));
+        }
+        if (n_k1) {
+            hipEvent_t e1;
+            rc = timing_begin(c, &e1);
+            if (rc != RG_OK) return rc;
+            RG_HIP(c, rg_launch_k1_halo(c->d_k1_tracks.p, (uint32_t)n_k1, k1_items, c->d_coefs.p, c->d_hist.p,
+                                        c->d_peak_bits.p, s));
+            if (e1) RG_HIP(c, hipEventRecord(e1, s));
+        }
+        RG_HIP(c, rg_launch_track_results(c->d_hist.p, c->d_peak_bits.p, c->d_tracks.p, c->d_results.p, (uint32_t)n, s));
+    }
+    if (album) {
+        RG_HIP(c, rg_launch_album_merge(c->d_hist.p, c->d_peak_bits.p, (uint32_t)n, c->d_album_hist.p,
+                                        c->d_album_peak.p, s));
+        c->album_ready = true;
+    }
+    return RG_OK;
+}

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) rg_k1_halo_kernel(const RgTrackDev *__res
 
     double peak = 0.0, lsum = 0.0, rsum = 0.0;
     uint32_t n = 0;
-    uint32_t *const h = hist + (size_t)t * RG_HISTOGRAM_SIZE;
+    uint32_t *const h = hist + (size_t)tr.track_index * RG_HISTOGRAM_SIZE;
     for (uint64_t i = first; i < last; ++i) {
         const double lf = df1_process(fl, c, load_input(tr.ch0, i, fmt, mag));
         if (mag > peak) peak = mag;
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(256) rg_k1_halo_kernel(const RgTrackDev *__res
         const int idx = rg_window_bin(lsum, rsum, n);
         if (idx >= 0) atomicAdd(&h[idx], 1u);
     }
-    atomicMax(&peak_bits[t], (unsigned long long)__double_as_longlong(peak));
+    atomicMax(&peak_bits[tr.track_index], (unsigned long long)__double_as_longlong(peak));
 }
 
 extern "C" hipError_t rg_launch_k1_halo(const RgTrackDev *d_tracks, uint32_t n_tracks, uint32_t total_items,

@@ -1,0 +1,73 @@
+// rg_tm.h -- data layout of variant 2, the transient-moment (TM) formulation.
+//
+// The reference runs one sequential recursion per channel over the whole track
+// (src/replaygain.rs:866-904: the filters and the analyzer live across all packets).  Variant 2
+// cuts every channel into segments of L frames (L divides the 50 ms window W) and gives each
+// segment to one lane.  The cascade (10th-order Yule-Walker -> 2nd-order Butterworth,
+// src/replaygain.rs:586-616, here in transposed direct form II with fused multiply-add) is an
+// affine system with a 12-dimensional state  q = (s1..s10 | t1 t2):
+//       q[n+1] = F q[n] + g x[n] + c,      z[n] = h.q[n] + d x[n]
+// so the true output of a segment that starts in state sigma is
+//       z[n] = zs[n] + sum_j sigma_j T_j[n]
+// with zs the response from the ZERO state (what the lane computes) and T_j the response of the
+// homogeneous system to unit state j.  The window energy then needs only three moments per
+// segment and channel, accumulated in the same pass:
+//       A = sum zs^2,   B_j = sum zs T_j,   G_jk = sum T_j T_k  (input independent, tabulated)
+//       sum z^2 = A + 2 B.sigma + sigma' G sigma
+// and the true start state follows from the zero-state end states E of the preceding segments:
+//       sigma_k = E_{k-1} + Phi sigma_{k-1},   Phi = F^L,  |Phi^m| -> 0 geometrically,
+// evaluated by the fix-up kernel as a truncated doubling scan over 2^R predecessors.
+// Nothing is approximated beyond f64 rounding: the truncation is chosen so that the dropped
+// terms are below 1e-17 relative (rg_design.cpp).
+#pragma once
+
+#include <stdint.h>
+
+#define RG_TM_DIM 12          // state dimension: 10 (Yule) + 2 (Butter)
+#define RG_TM_GRAM 78         // upper triangle of a symmetric 12x12
+#define RG_TM_REC 25          // doubles per (segment, channel): A, B[12], E[12]
+#define RG_TM_BLOCK 256
+#define RG_TM_MAX_ROUNDS 5
+
+// filter constants of one launch group, passed by value (wave-uniform -> SGPRs)
+struct RgTmCoef {
+    double b[11];   // yule b, pre-multiplied by the (power of two) input scale of the sample format
+    double a[11];   // yule a (a[0] unused)
+    double bb[3];   // butter b
+    double ba[3];   // butter a (ba[0] unused)
+    double c0;      // the reference's per-stage +1e-10 (src/replaygain.rs:530), injected at the deepest state
+};
+
+struct RgTmTrack {
+    const void *ch0;
+    const void *ch1;           // nullptr for mono
+    uint64_t frames;
+    uint32_t nseg;             // ceil(frames / L)
+    uint32_t n_windows;        // ceil(frames / W)
+    uint32_t rec_base;         // first segment record of this track
+    uint32_t main_block_base;  // first block of this track in the main kernel's grid
+    uint32_t fix_block_base;   // first block of this track in the fix-up kernel's grid
+    uint32_t track_index;      // row in the histogram / peak arrays
+};
+
+// launch-group geometry (passed by value)
+struct RgTmGeom {
+    uint32_t L;            // segment length in frames
+    uint32_t W;            // window length in frames
+    uint32_t k;            // segments per window (W / L)
+    uint32_t H10;          // frames after which the fast (Yule) part of a transient is negligible
+    uint32_t rounds;       // doubling rounds R; 2^R predecessors are summed
+    uint32_t rounds_fast;  // rounds in which the fast block still contributes
+    uint32_t warm;         // warm-up lanes per fix-up block (2^R)
+    uint32_t fix_windows;  // whole windows per fix-up block
+    const double *T;       // [L][12] homogeneous responses, block-diagonal coordinates
+};
+
+// device tables of the fix-up kernel (passed by value; all wave-uniform reads)
+struct RgTmFixTables {
+    const double *X;       // [2][10]  coordinate change t' = t + X s
+    const double *sigma0;  // [12]     state at the start of a track
+    const double *PhiY;    // [rounds][10][10]  (F_y^L)^(2^r)
+    const double *PhiB;    // [rounds][2][2]    (F_b^L)^(2^r)
+    const double *Gp;      // [L][78]  prefix Gram matrices: Gp[len-1] = sum_{n<len} T T'
+};

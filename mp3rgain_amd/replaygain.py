@@ -202,6 +202,10 @@ class Analyzer:
     def set_kernel(self, variant: int):
         self._check(self._lib.rg_set_kernel(self._ctx, variant))
 
+    def set_tuning(self, key: int, value: int):
+        """key 1: segment length of variant 2 (frames); key 2: lane target; 0 = default."""
+        self._check(self._lib.rg_set_tuning(self._ctx, key, value))
+
     # -- synchronous, host PCM ----------------------------------------------------------------
     def analyze_tracks(self, tracks: Sequence[PcmTrack], return_histograms: bool = False):
         """`-r` mode: analyze_track for each track (src/replaygain.rs:929-941)."""

@@ -33,11 +33,34 @@ def capi():
 
 
 @pytest.fixture(scope="session")
-def analyzer(capi):
+def _ctx(capi):
     """GPU context; only gpu-marked tests may request it.  No fallback: failing to get a
     device is a hard error on the GPU box."""
+    import torch  # noqa: F401  (torch first: one HIP runtime per process, see mp3rgain_amd/_capi.py)
+
     import mp3rgain_amd as rg
 
     an = rg.Analyzer(0)
     yield an
     an.close()
+
+
+# every GPU parity test runs against both kernel variants and several segment lengths of variant 2:
+#   (1, 0)    order-faithful halo kernel
+#   (2, 0)    transient-moment kernels, segment length chosen by the library
+#   (2, -1)   transient-moment kernels, smallest admissible segment (many segments per window)
+#   (2, -2)   transient-moment kernels, one segment per window
+@pytest.fixture(params=[(1, 0), (2, 0), (2, -1), (2, -2)], ids=["halo", "tm-auto", "tm-short", "tm-window"])
+def analyzer(_ctx, request):
+    variant, seg = request.param
+    _ctx.set_kernel(variant)
+    _ctx.set_tuning(1, 0)
+    _ctx.set_tuning(2, 0)
+    if seg == -1:
+        _ctx.set_tuning(2, 1 << 40)  # unreachable lane target -> smallest admissible segment
+    elif seg == -2:
+        _ctx.set_tuning(2, 1)        # any lane count is enough -> largest segment (= the window)
+    yield _ctx
+    _ctx.set_kernel(0)
+    _ctx.set_tuning(1, 0)
+    _ctx.set_tuning(2, 0)
