@@ -54,6 +54,7 @@ def main() -> int:
     ap.add_argument("--kernel", type=int, default=0, help="kernel variant (0 = library default)")
     ap.add_argument("--tracks-per-rank", type=int, default=1)
     ap.add_argument("--minutes", type=float, default=10.0, help="track length (default: BASELINE's 10 min)")
+    ap.add_argument("--tm-segment", type=int, default=0, help="force variant 2 segment length (tuning)")
     ap.add_argument("--cpu-reps", type=int, default=8, help="oracle repetitions for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -85,6 +86,8 @@ def main() -> int:
     an = rg.Analyzer(local_rank)
     if args.kernel:
         an.set_kernel(args.kernel)
+    if args.tm_segment:
+        an.set_tuning(1, args.tm_segment)
     stream = torch.cuda.current_stream()
     an.set_stream(stream.cuda_stream)
 

@@ -9,7 +9,10 @@ import ctypes as C
 from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "libmp3rgain_amd.so"
+import os
+
+# MP3RGAIN_AMD_LIB selects another build of the same library (kernel experiments); never a fallback
+LIB_PATH = Path(os.environ.get("MP3RGAIN_AMD_LIB", PKG_DIR / "libmp3rgain_amd.so"))
 
 HISTOGRAM_SIZE = 12000
 HISTOGRAM_OFFSET = 2000

@@ -11,6 +11,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <math.h>
+
 #include <algorithm>
 
 #include "rg_ctx.h"
@@ -23,14 +25,13 @@ hipError_t rg_launch_track_results(const uint32_t *, const unsigned long long *,
 hipError_t rg_launch_album_merge(const uint32_t *, const unsigned long long *, uint32_t, uint32_t *, double *,
                                  hipStream_t);
 hipError_t rg_launch_tm_main(int fmt, int nch, const RgTmCoef *, const RgTmGeom *, const RgTmTrack *, uint32_t, uint32_t,
-                             double *, uint32_t, unsigned long long *, hipStream_t);
+                             double *, uint32_t, hipStream_t);
 hipError_t rg_launch_tm_fix(int nch, const RgTmGeom *, const RgTmFixTables *, const RgTmTrack *, uint32_t, uint32_t,
-                            const double *, uint32_t, uint32_t *, hipStream_t);
+                            const double *, uint32_t, uint32_t *, unsigned long long *, hipStream_t);
 }
 
 namespace {
 
-const uint64_t kDefaultTargetLanes = 120000;  // ~2 waves per SIMD on 256 CUs
 const uint32_t kMinSegment = 96;              // shorter segments need more than RG_TM_MAX_ROUNDS doubling rounds
 
 struct TmGroup {
@@ -122,7 +123,8 @@ int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out) {
     const RgTmDesign &D = tb->design;
     if (!D.ok) return RG_ERR_INVALID_ARG;
     const size_t nT = D.T.size(), nG = D.Gp.size(), nY = D.PhiY.size(), nB = D.PhiB.size();
-    const size_t total = nT + nG + nY + nB + 20 + 12 + 8;
+    const size_t nL = (size_t)D.H10 * 12 + (size_t)(D.L - D.H10) * 2;
+    const size_t total = nT + nG + nY + nB + 20 + 12 + 8 + nL + 2;
     std::vector<double> blob(total, 0.0);
     size_t o = 0;
     const size_t oT = o; memcpy(&blob[o], D.T.data(), nT * 8); o += nT;
@@ -131,6 +133,11 @@ int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out) {
     const size_t oB = o; if (nB) memcpy(&blob[o], D.PhiB.data(), nB * 8); o += nB;
     const size_t oX = o; memcpy(&blob[o], &D.X[0][0], 20 * 8); o += 20;
     const size_t oS = o; memcpy(&blob[o], D.sigma0, 12 * 8); o += 12;
+    o = (o + 1) & ~(size_t)1;  // 16-byte alignment of the LDS image
+    const size_t oL = o;
+    for (uint32_t n = 0; n < D.H10; ++n)
+        for (int j = 0; j < 12; ++j) blob[o++] = D.T[(size_t)n * 12 + j];
+    for (uint32_t n = D.H10; n < D.L; ++n) { blob[o++] = D.T[(size_t)n * 12 + 10]; blob[o++] = D.T[(size_t)n * 12 + 11]; }
     RG_HIP(c, hipMalloc((void **)&tb->d_blob, total * 8));
     RG_HIP(c, hipMemcpy(tb->d_blob, blob.data(), total * 8, hipMemcpyHostToDevice));
     RgTmGeom &g = tb->geom;
@@ -143,6 +150,7 @@ int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out) {
     g.warm = 1u << D.rounds;
     g.fix_windows = (RG_TM_BLOCK - g.warm) / g.k;
     g.T = tb->d_blob + oT;
+    g.Tlds = tb->d_blob + oL;
     tb->fix.Gp = tb->d_blob + oG;
     tb->fix.PhiY = tb->d_blob + oY;
     tb->fix.PhiB = tb->d_blob + oB;
@@ -155,8 +163,14 @@ int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out) {
     return RG_OK;
 }
 
-// segment length for one group: the largest divisor of W that still yields enough lanes to fill the
-// chip; workloads too small for that get the smallest admissible divisor
+// Segment length for one group.  Every divisor L of the window W (>= kMinSegment) is a legal
+// segment; the choice trades arithmetic (all 12 transient moments are live for the first H10 frames
+// of a segment, 2 afterwards, so short segments cost up to 40 instead of 30 FP64 ops per sample)
+// against how evenly the resulting waves fill 256 CUs x 4 SIMDs x 4 resident waves.
+//   cost(L)  = L*30 + min(L, H10)*10 + fixed          [VALU slots per lane]
+//   waves(L) = sum over tracks and channels of ceil(nseg / 256) * 4
+//   time(L)  ~ ceil(waves / 1024) * cost   when everything is resident at once (waves <= 4096),
+//              (waves / 1024 + 1) * cost   otherwise (many rounds, one extra for the ragged tail)
 int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, RgTmDeviceTables **out) {
     const uint32_t W = rg_window_samples(RG_RATE_TABLE[g.rate_idx].sample_rate);
     if (c->tune_tm_segment && W % c->tune_tm_segment == 0 &&
@@ -165,14 +179,41 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
     std::vector<uint32_t> cand;
     for (uint32_t d = 1; d <= W; ++d)
         if (W % d == 0 && (d >= kMinSegment || d == W)) cand.push_back(d);
-    const uint64_t target = c->tune_tm_target_lanes ? c->tune_tm_target_lanes : kDefaultTargetLanes;
-    for (size_t i = cand.size(); i-- > 0;) {
-        uint64_t lanes = 0;
-        for (uint32_t id : g.ids) lanes += (tracks[id].frames + cand[i] - 1) / cand[i];
-        if (lanes >= target && get_tm_tables(c, g.rate_idx, cand[i], out) == RG_OK) return RG_OK;
+    if (c->tune_tm_target_lanes) {  // explicit lane target: largest L reaching it, else the smallest L
+        for (size_t i = cand.size(); i-- > 0;) {
+            uint64_t lanes = 0;
+            for (uint32_t id : g.ids) lanes += (tracks[id].frames + cand[i] - 1) / cand[i];
+            if (lanes >= c->tune_tm_target_lanes && get_tm_tables(c, g.rate_idx, cand[i], out) == RG_OK) return RG_OK;
+        }
+        for (size_t i = 0; i < cand.size(); ++i)
+            if (get_tm_tables(c, g.rate_idx, cand[i], out) == RG_OK) return RG_OK;
+        return rg_set_err(c, RG_ERR_INVALID_ARG, "no admissible segment length for %u Hz",
+                          RG_RATE_TABLE[g.rate_idx].sample_rate);
     }
-    for (size_t i = 0; i < cand.size(); ++i)
-        if (get_tm_tables(c, g.rate_idx, cand[i], out) == RG_OK) return RG_OK;
+    // H10 of this rate from the one-window design (the decay length does not depend on L)
+    RgTmDeviceTables *full = nullptr;
+    uint32_t H10 = W;
+    if (get_tm_tables(c, g.rate_idx, W, &full) == RG_OK) H10 = full->design.H10;
+    double best = 1e300;
+    uint32_t bestL = 0;
+    for (uint32_t L : cand) {
+        double waves = 0;
+        for (uint32_t id : g.ids) {
+            const uint64_t nseg = (tracks[id].frames + L - 1) / L;
+            waves += (double)((nseg + RG_TM_BLOCK - 1) / RG_TM_BLOCK) * (RG_TM_BLOCK / 64) * g.nch;
+        }
+        const double cost = (double)L * 30.0 + (double)std::min(L, H10) * 10.0 + 1500.0;
+        const double rounds = waves <= 4096.0 ? ceil(waves / 1024.0) : waves / 1024.0 + 1.0;
+        const double tm = rounds * cost;
+        if (tm < best) { best = tm; bestL = L; }
+    }
+    // walk outwards from the best candidate until one designs (tiny L can need too many scan rounds)
+    std::sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) {
+        const uint32_t da = a > bestL ? a - bestL : bestL - a, db = b > bestL ? b - bestL : bestL - b;
+        return da < db;
+    });
+    for (uint32_t L : cand)
+        if (get_tm_tables(c, g.rate_idx, L, out) == RG_OK) return RG_OK;
     return rg_set_err(c, RG_ERR_INVALID_ARG, "no admissible segment length for %u Hz",
                       RG_RATE_TABLE[g.rate_idx].sample_rate);
 }
@@ -332,11 +373,11 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
             rc = timing_begin(c, &e1);
             if (rc != RG_OK) return rc;
             RG_HIP(c, rg_launch_tm_main(gl.fmt, gl.nch, &gl.K, &gl.tb->geom, c->d_tm_tracks.p + gl.list_off,
-                                        (uint32_t)gl.list_n, gl.main_grid, c->d_tm_rec.p, gl.total_recs,
-                                        c->d_peak_bits.p, s));
+                                        (uint32_t)gl.list_n, gl.main_grid, c->d_tm_rec.p, gl.total_recs, s));
             if (e1) RG_HIP(c, hipEventRecord(e1, s));
             RG_HIP(c, rg_launch_tm_fix(gl.nch, &gl.tb->geom, &gl.tb->fix, c->d_tm_tracks.p + gl.list_off,
-                                       (uint32_t)gl.list_n, gl.fix_grid, c->d_tm_rec.p, gl.total_recs, c->d_hist.p, s));
+                                       (uint32_t)gl.list_n, gl.fix_grid, c->d_tm_rec.p, gl.total_recs, c->d_hist.p,
+                                       c->d_peak_bits.p, s));
         }
         if (n_k1) {
             hipEvent_t e1;

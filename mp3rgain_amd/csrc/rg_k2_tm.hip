@@ -42,9 +42,14 @@ struct TmLane {
     double B[NCH][RG_TM_DIM];
 };
 
+// The T table is read through the constant address space: its rows are wave-uniform, and only a
+// constant-address-space load is guaranteed to become a scalar s_load (the asm memory clobbers around
+// the LDS staging would otherwise demote these loads to per-lane vector loads).
+typedef __attribute__((address_space(4))) const double rg_cdouble;
+
 // NX = number of transient moments still alive: 12 (all) or 2 (Butterworth pair only)
 template <int NCH, int NX>
-__device__ __forceinline__ void tm_sample(TmLane<NCH> &st, const double (&x)[NCH], const double *__restrict__ Trow,
+__device__ __forceinline__ void tm_sample(TmLane<NCH> &st, const double (&x)[NCH], rg_cdouble *__restrict__ Trow,
                                           const RgTmCoef &K) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -54,8 +59,6 @@ __device__ __forceinline__ void tm_sample(TmLane<NCH> &st, const double (&x)[NCH
         for (int j = RG_TM_DIM - NX; j < RG_TM_DIM; ++j) st.B[c][j] = fma(z, Trow[j], st.B[c][j]);
     }
 }
-
-struct __attribute__((packed, aligned(4))) F32x4 { float v[4]; };
 
 // ---- per-format sample access: raw value as double (the power-of-two scale is folded into K.b) and
 // ---- the peak accumulator in the format's own domain
@@ -102,16 +105,162 @@ __device__ __forceinline__ uint32_t find_track(const RgTmTrack *__restrict__ tra
 }  // namespace
 
 // =================================================================================================
-template <int FMT, int NCH>
+// Main kernel.  One lane = one (channel, segment); blockIdx.y is the channel.
+//
+// F32 fast path, everything the inner loop touches lives in LDS:
+//  * PCM.  One wave owns 64 consecutive segments (rows) of one channel: 64 strided runs, L frames
+//    apart.  Per tile of RG_TM_TILE = 16 frames every lane issues 4 global_load_dwordx4: instruction
+//    q, lane j fetches one 16-byte piece of row 16q + (j >> 2), so an instruction reads 16 contiguous
+//    64-byte runs (each 128-byte line of the stream is fetched once or twice in total, instead of
+//    eight times by per-lane strided loads).  The pieces go through registers into the wave's private
+//    4 KiB tile (ds_write_b128, row-major) one tile ahead of their use; the piece a lane fetches is
+//    XOR-swizzled with (row >> 2) & 3 so that the consumer's row-per-lane ds_read_b128 is bank
+//    conflict free (the 16 lanes of a read group hit 16 distinct 16-byte slots of the 256-byte bank
+//    row).  The tile is wave-private: no block barrier in the loop.
+//  * The transient-response table.  T rows are wave-uniform, but as scalar loads they cost one
+//    exposed s_waitcnt lgkmcnt(0) per row (SMEM returns out of order), which left a lone wave at a
+//    ninth of the FP64 issue rate.  The block copies the rows it needs into LDS once (12 doubles per
+//    frame for n < H10, then only the Butterworth pair) and reads them as broadcast ds_read_b128,
+//    which the compiler can keep in flight with counted lgkmcnt waits.
+#define RG_TM_TILE 16
+#define RG_TM_WAVE_TILE_BYTES 4096  // 64 rows x 16 frames x 4 B
+
+typedef float __attribute__((ext_vector_type(4), aligned(4))) rg_f32x4u;  // 16-byte load, 4-byte aligned
+
+// moments of one piece of 4 frames; MASK: frames at or past `len` do not count (tail of a track)
+template <int NX, bool MASK>
+__device__ __forceinline__ void tm_piece_lds(TmLane<1> &st, const float4 v, float &pk, const double *__restrict__ Trow,
+                                             const RgTmCoef &K, const uint32_t n, const uint32_t len) {
+    const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        pk = fmaxf(pk, fabsf(f[u]));  // frames past the end were staged as zeros
+        double z = tm_step(st.s[0], st.t[0], (double)f[u], K);
+        if (MASK) z = n + u < len ? z : 0.0;
+        st.A[0] = fma(z, z, st.A[0]);
+        if (NX == 12) {
+#pragma unroll
+            for (int j = 0; j < 12; ++j) st.B[0][j] = fma(z, Trow[u * 12 + j], st.B[0][j]);
+        } else {
+            st.B[0][10] = fma(z, Trow[u * 2 + 0], st.B[0][10]);
+            st.B[0][11] = fma(z, Trow[u * 2 + 1], st.B[0][11]);
+        }
+    }
+}
+
+// The F32 fast path of one wave.  TAIL = some row of this wave is shorter than L (the end of the
+// track): short rows are staged zero-filled, element by element where a 16-byte piece would cross the
+// end of the channel, and their moments are masked.
+template <bool TAIL>
+__device__ __forceinline__ void tm_fast_path(TmLane<1> &st, float &pk, const RgTmCoef &K, const uint32_t L,
+                                             const uint32_t H, const __attribute__((address_space(1))) float *chp,
+                                             const uint64_t frames, const uint32_t wave_seg0, const uint32_t len,
+                                             const double *__restrict__ T12, const double *__restrict__ T2,
+                                             char *const wtile) {
+    typedef const __attribute__((address_space(1))) float gfloat;
+    const int lane = threadIdx.x & 63;
+    // loader role: instruction q covers rows 16q .. 16q+15; this lane fetches for row 16q + (lane >> 2)
+    const int lrow = lane >> 2, lslot = lane & 3;
+    uint64_t lfirst[4];  // first frame (within the channel) of the piece this lane fetches, tile 0
+    uint32_t llen[4];    // valid frames of that row
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = 16 * q + lrow;
+        const int piece = lslot ^ ((row >> 2) & 3);
+        const uint64_t row0 = (uint64_t)(wave_seg0 + row) * L;
+        lfirst[q] = row0 + 4u * piece;
+        llen[q] = L;
+        if (TAIL) llen[q] = row0 >= frames ? 0u : (frames - row0 < L ? (uint32_t)(frames - row0) : L);
+    }
+    // consumer role: row == lane
+    const char *const rrow = wtile + lane * 64;
+    const int rswz = (lane >> 2) & 3;
+    const uint32_t ntiles = (L + RG_TM_TILE - 1) / RG_TM_TILE;
+
+    rg_f32x4u stage[4];
+    auto load_tile = [&](uint32_t tile) {
+        const uint32_t n0 = tile * RG_TM_TILE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = 16 * q + lrow;
+            const int piece = lslot ^ ((row >> 2) & 3);
+            const uint32_t pn = n0 + 4u * piece;  // frame index of the piece within its row
+            if (!TAIL) {
+                if (pn < L) stage[q] = *(const __attribute__((address_space(1))) rg_f32x4u *)(chp + lfirst[q] + n0);
+            } else {
+                gfloat *src = chp + lfirst[q] + n0;
+                if (pn + 4u <= llen[q]) {
+                    stage[q] = *(const __attribute__((address_space(1))) rg_f32x4u *)src;
+                } else {
+                    stage[q].x = pn + 0u < llen[q] ? src[0] : 0.0f;
+                    stage[q].y = pn + 1u < llen[q] ? src[1] : 0.0f;
+                    stage[q].z = pn + 2u < llen[q] ? src[2] : 0.0f;
+                    stage[q].w = pn + 3u < llen[q] ? src[3] : 0.0f;
+                }
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4 *>(wtile + q * 1024 + lane * 16) =
+                make_float4(stage[q].x, stage[q].y, stage[q].z, stage[q].w);
+    };
+
+    load_tile(0);
+    for (uint32_t tile = 0; tile < ntiles; ++tile) {
+        __builtin_amdgcn_wave_barrier();
+        store_tile();  // tile `tile` -> LDS (all reads of the previous tile are behind us)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (tile + 1 < ntiles) load_tile(tile + 1);  // in flight during this tile's arithmetic
+        const uint32_t n0 = tile * RG_TM_TILE;
+#pragma unroll 1
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t n = n0 + 4u * p;
+            if (n + 4u > L) break;
+            const float4 v = *reinterpret_cast<const float4 *>(rrow + 16 * (p ^ rswz));
+            if (n < H) tm_piece_lds<12, TAIL>(st, v, pk, T12 + (size_t)n * 12, K, n, len);
+            else tm_piece_lds<2, TAIL>(st, v, pk, T2 + (size_t)(n - H) * 2, K, n, len);
+        }
+        if (tile + 1 == ntiles) {
+            // L mod 4 trailing frames, still in this tile
+            for (uint32_t n = L & ~3u; n < L; ++n) {
+                const uint32_t o = n - n0;
+                const float f = *reinterpret_cast<const float *>(rrow + 16 * ((o >> 2) ^ rswz) + 4 * (o & 3));
+                pk = fmaxf(pk, fabsf(f));
+                double z = tm_step(st.s[0], st.t[0], (double)f, K);
+                if (TAIL) z = n < len ? z : 0.0;
+                st.A[0] = fma(z, z, st.A[0]);
+                if (n < H) {
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) st.B[0][j] = fma(z, T12[(size_t)n * 12 + j], st.B[0][j]);
+                } else {
+                    st.B[0][10] = fma(z, T2[(size_t)(n - H) * 2 + 0], st.B[0][10]);
+                    st.B[0][11] = fma(z, T2[(size_t)(n - H) * 2 + 1], st.B[0][11]);
+                }
+            }
+        }
+    }
+}
+
+template <int FMT>
 __global__ void __launch_bounds__(RG_TM_BLOCK)
 rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restrict__ tracks, uint32_t n_tracks,
-                  double *__restrict__ rec, uint32_t total_recs, unsigned long long *__restrict__ peak_bits) {
+                  double *__restrict__ rec, uint32_t total_recs, uint32_t lds_tables,
+                  unsigned long long *__restrict__ dbg /* nullptr, or 4 words per wave: start, end, hw id, path */) {
     typedef Fmt<FMT> F;
+    const unsigned long long dbg_t0 = dbg ? wall_clock64() : 0ull;
     typedef typename F::elem elem;
+    typedef __attribute__((address_space(1))) const elem gelem;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
     const uint32_t t = find_track(tracks, n_tracks, blockIdx.x, &RgTmTrack::main_block_base);
     const RgTmTrack tr = tracks[t];
+    const int chan = blockIdx.y;
     const uint32_t seg = (blockIdx.x - tr.main_block_base) * RG_TM_BLOCK + threadIdx.x;
     const uint32_t L = G.L;
+    const uint32_t H = G.H10;
     const bool active = seg < tr.nseg;
     const uint64_t start = (uint64_t)seg * L;
     uint32_t len = 0;
@@ -119,133 +268,99 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
         const uint64_t rem = tr.frames - start;
         len = rem < L ? (uint32_t)rem : L;
     }
-    const elem *__restrict__ p[2] = {(const elem *)tr.ch0 + start, (const elem *)tr.ch1 + start};
-    const double *__restrict__ T = G.T;
+    gelem *const chp = (gelem *)(chan == 0 ? tr.ch0 : tr.ch1);
+    rg_cdouble *__restrict__ T = (rg_cdouble *)G.T;
 
-    TmLane<NCH> st;
+    TmLane<1> st;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
+    for (int i = 0; i < 10; ++i) st.s[0][i] = 0.0;
+    st.t[0][0] = st.t[0][1] = 0.0;
+    st.A[0] = 0.0;
 #pragma unroll
-        for (int i = 0; i < 10; ++i) st.s[c][i] = 0.0;
-        st.t[c][0] = st.t[c][1] = 0.0;
-        st.A[c] = 0.0;
-#pragma unroll
-        for (int j = 0; j < RG_TM_DIM; ++j) st.B[c][j] = 0.0;
-    }
+    for (int j = 0; j < RG_TM_DIM; ++j) st.B[0][j] = 0.0;
     typename F::peak_t pk = 0;
 
-    if (__all(len == L)) {
-        // ---- fast path: every lane of the wave owns a full segment ------------------------------
-        const uint32_t L4 = L & ~3u;
-        const uint32_t H = G.H10;  // multiple of 4, <= L4
-        uint32_t n = 0;
-        if constexpr (FMT == RG_FMT_F32_PLANAR) {
-            F32x4 cur[NCH], nxt[NCH];
+    bool done = false;
+    if constexpr (FMT == RG_FMT_F32_PLANAR) {
+        if (lds_tables) {
+            done = true;
+            // ---- block-shared tables, one packed image: T12[n][12] for n < H, then T2[n - H][2] -------------
+            const uint32_t tbl_doubles = H * 12 + (L - H) * 2;  // even
+            {
+                const double2 *__restrict__ src = reinterpret_cast<const double2 *>(G.Tlds);
+                double2 *dst = reinterpret_cast<double2 *>(smem);
+                const uint32_t n16 = tbl_doubles / 2;
+                for (uint32_t i = threadIdx.x; i < n16; i += 4 * RG_TM_BLOCK) {
+                    double2 v[4];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) cur[c] = *reinterpret_cast<const F32x4 *>(p[c]);
-            for (; n < H; n += 4) {
-                const uint32_t nn = n + 4 < L4 ? n + 4 : n;  // prefetch the next chunk (clamped)
+                    for (int u = 0; u < 4; ++u)
+                        if (i + u * RG_TM_BLOCK < n16) v[u] = src[i + u * RG_TM_BLOCK];
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) nxt[c] = *reinterpret_cast<const F32x4 *>(p[c] + nn);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    double x[NCH];
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) x[c] = F::cvt(cur[c].v[u], pk);
-                    tm_sample<NCH, 12>(st, x, T + (size_t)(n + u) * RG_TM_DIM, K);
+                    for (int u = 0; u < 4; ++u)
+                        if (i + u * RG_TM_BLOCK < n16) dst[i + u * RG_TM_BLOCK] = v[u];
                 }
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) cur[c] = nxt[c];
+                __syncthreads();
             }
-            for (; n < L4; n += 4) {
-                const uint32_t nn = n + 4 < L4 ? n + 4 : n;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) nxt[c] = *reinterpret_cast<const F32x4 *>(p[c] + nn);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    double x[NCH];
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) x[c] = F::cvt(cur[c].v[u], pk);
-                    tm_sample<NCH, 2>(st, x, T + (size_t)(n + u) * RG_TM_DIM, K);
-                }
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) cur[c] = nxt[c];
-            }
-        } else {
-            for (; n < H; ++n) {
-                double x[NCH];
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) x[c] = F::cvt(p[c][n], pk);
-                tm_sample<NCH, 12>(st, x, T + (size_t)n * RG_TM_DIM, K);
-            }
-            for (; n < L4; ++n) {
-                double x[NCH];
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) x[c] = F::cvt(p[c][n], pk);
-                tm_sample<NCH, 2>(st, x, T + (size_t)n * RG_TM_DIM, K);
-            }
+            const double *const T12 = reinterpret_cast<const double *>(smem);
+            const double *const T2 = T12 + (size_t)H * 12;
+            char *const wtile = smem + (size_t)tbl_doubles * sizeof(double) + (threadIdx.x >> 6) * RG_TM_WAVE_TILE_BYTES;
+            const uint32_t wave_seg0 = seg - (threadIdx.x & 63);
+            // a 16-byte piece may reach up to 3 frames past its row: full rows that end exactly at the end
+            // of the channel go through the element-wise staging of the TAIL variant too
+            const bool plain = len == L && start + ((L + 3u) & ~3u) <= tr.frames;
+            if (__all(plain))
+                tm_fast_path<false>(st, pk, K, L, H, chp, tr.frames, wave_seg0, len, T12, T2, wtile);
+            else if (__any(len != 0))
+                tm_fast_path<true>(st, pk, K, L, H, chp, tr.frames, wave_seg0, len, T12, T2, wtile);
         }
-        for (; n < L; ++n) {  // L mod 4 trailing frames
-            double x[NCH];
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) x[c] = F::cvt(p[c][n], pk);
-            tm_sample<NCH, 12>(st, x, T + (size_t)n * RG_TM_DIM, K);
-        }
-    } else {
-        // ---- tail path: some lane of this wave has a short (or no) segment ------------------------
-        // frames past `len` are fed as zeros and their output is excluded from the moments; the end
-        // state of such a lane is never used (the track ends inside it).
+    }
+    if (!done) {
+        // ---- generic path: other sample formats, tables too large for LDS, and waves holding the tail
+        // of a track.  Frames past `len` are fed as zeros and their output is excluded from the moments;
+        // the end state of such a lane is never used (the track ends inside it).
+        gelem *const p0 = chp + start;
         for (uint32_t n = 0; n < L; ++n) {
             const bool valid = n < len;
-            double x[NCH];
+            double x = 0.0;
+            if (valid) x = F::cvt(p0[n], pk);
+            rg_cdouble *__restrict__ Trow = T + (size_t)n * RG_TM_DIM;
+            double z = tm_step(st.s[0], st.t[0], x, K);
+            z = valid ? z : 0.0;
+            st.A[0] = fma(z, z, st.A[0]);
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                x[c] = 0.0;
-                if (valid) x[c] = F::cvt(p[c][n], pk);
-            }
-            const double *__restrict__ Trow = T + (size_t)n * RG_TM_DIM;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                double z = tm_step(st.s[c], st.t[c], x[c], K);
-                z = valid ? z : 0.0;
-                st.A[c] = fma(z, z, st.A[c]);
-#pragma unroll
-                for (int j = 0; j < RG_TM_DIM; ++j) st.B[c][j] = fma(z, Trow[j], st.B[c][j]);
-            }
+            for (int j = 0; j < RG_TM_DIM; ++j) st.B[0][j] = fma(z, Trow[j], st.B[0][j]);
         }
     }
 
-    // ---- segment records, structure-of-arrays: field f of channel c at ((c*25 + f) * total_recs + idx)
+    if (dbg && (threadIdx.x & 63) == 0) {
+        const size_t w = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (RG_TM_BLOCK / 64) + (threadIdx.x >> 6)) * 4;
+        dbg[w + 0] = dbg_t0;
+        dbg[w + 1] = wall_clock64();
+        dbg[w + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |  // XCC_ID
+                     __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));                                  // HW_ID
+        dbg[w + 3] = done ? 1ull : 0ull;
+    }
+
+    // ---- segment record, structure-of-arrays: field f of channel c at ((c*RG_TM_REC + f) * total_recs + idx)
     if (active) {
-        const size_t idx = (size_t)tr.rec_base + seg;
+        double *__restrict__ r = rec + (size_t)chan * RG_TM_REC * total_recs + ((size_t)tr.rec_base + seg);
+        r[0] = st.A[0];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            double *__restrict__ r = rec + (size_t)c * RG_TM_REC * total_recs + idx;
-            r[0] = st.A[c];
+        for (int j = 0; j < RG_TM_DIM; ++j) r[(size_t)(1 + j) * total_recs] = st.B[0][j];
 #pragma unroll
-            for (int j = 0; j < RG_TM_DIM; ++j) r[(size_t)(1 + j) * total_recs] = st.B[c][j];
-#pragma unroll
-            for (int j = 0; j < 10; ++j) r[(size_t)(13 + j) * total_recs] = st.s[c][j];
-            r[(size_t)23 * total_recs] = st.t[c][0];
-            r[(size_t)24 * total_recs] = st.t[c][1];
-        }
+        for (int j = 0; j < 10; ++j) r[(size_t)(13 + j) * total_recs] = st.s[0][j];
+        r[(size_t)23 * total_recs] = st.t[0][0];
+        r[(size_t)24 * total_recs] = st.t[0][1];
+        r[(size_t)25 * total_recs] = F::peak_norm(pk);  // max |x| of this segment, normalised (replaygain.rs:967)
     }
-
-    // ---- peak: wave max, one atomic per wave (f64 bit pattern of a non-negative value is ordered) ----
-    unsigned long long pb = (unsigned long long)__double_as_longlong(F::peak_norm(pk));
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(pb, off, 64);
-        pb = o > pb ? o : pb;
-    }
-    if ((threadIdx.x & 63) == 0 && pb != 0) atomicMax(&peak_bits[tr.track_index], pb);
 }
 
 // =================================================================================================
 template <int NCH>
 __global__ void __launch_bounds__(RG_TM_BLOCK)
 rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__restrict__ tracks, uint32_t n_tracks,
-                 const double *__restrict__ rec, uint32_t total_recs, uint32_t *__restrict__ hist) {
+                 const double *__restrict__ rec, uint32_t total_recs, uint32_t *__restrict__ hist,
+                 unsigned long long *__restrict__ peak_bits) {
     __shared__ double wx[RG_TM_DIM][RG_TM_BLOCK];
     __shared__ double pieces[RG_TM_BLOCK];
     __shared__ int bins[RG_TM_BLOCK];
@@ -263,9 +378,11 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     const size_t idx = (size_t)tr.rec_base + (size_t)(seg_valid ? seg : 0);
 
     double S = 0.0;
+    double pk = 0.0;
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
         const double *__restrict__ r = rec + (size_t)c * RG_TM_REC * total_recs + idx;
+        if (owner) pk = fmax(pk, r[(size_t)25 * total_recs]);
         // zero-state end state of this segment in block-diagonal coordinates: t' = t + X s
         double w[RG_TM_DIM];
         if (seg_valid) {
@@ -339,6 +456,17 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     }
     if (NCH == 1) S *= 2.0;  // add_mono_sample feeds both sums (src/replaygain.rs:731-740)
     pieces[i] = owner ? S : 0.0;
+    // peak of the block's segments: wave max, then one atomic per wave (the bit pattern of a
+    // non-negative double is ordered like the value)
+    {
+        unsigned long long pb = (unsigned long long)__double_as_longlong(pk);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(pb, off, 64);
+            pb = o > pb ? o : pb;
+        }
+        if ((i & 63) == 0 && pb != 0) atomicMax(&peak_bits[tr.track_index], pb);
+    }
     __syncthreads();
 
     // ---- 50 ms windows: k consecutive segments each (finish_window, src/replaygain.rs:743-765) ----
@@ -369,39 +497,48 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
 }
 
 // =================================================================================================
+// diagnostic timeline buffer (tools/ubench/timeline.py); nullptr in normal operation
+static unsigned long long *g_tm_debug = nullptr;
+extern "C" void rg_tm_set_debug_buffer(unsigned long long *d_buf) { g_tm_debug = d_buf; }
+
 template <int FMT>
 static hipError_t launch_main_fmt(int nch, const RgTmCoef &K, const RgTmGeom &G, const RgTmTrack *d_tracks,
-                                  uint32_t n_tracks, uint32_t grid, double *d_rec, uint32_t total_recs,
-                                  unsigned long long *d_peak_bits, hipStream_t s) {
-    if (nch == 1)
-        hipLaunchKernelGGL((rg_tm_main_kernel<FMT, 1>), dim3(grid), dim3(RG_TM_BLOCK), 0, s, K, G, d_tracks, n_tracks,
-                           d_rec, total_recs, d_peak_bits);
-    else
-        hipLaunchKernelGGL((rg_tm_main_kernel<FMT, 2>), dim3(grid), dim3(RG_TM_BLOCK), 0, s, K, G, d_tracks, n_tracks,
-                           d_rec, total_recs, d_peak_bits);
+                                  uint32_t n_tracks, uint32_t grid, double *d_rec, uint32_t total_recs, hipStream_t s) {
+    // LDS: T12 (H10 x 12 doubles) + T2 ((L - H10) x 2 doubles) + one 4 KiB PCM tile per wave
+    size_t lds = ((size_t)G.H10 * 12 + (size_t)(G.L - G.H10) * 2) * sizeof(double) +
+                 (size_t)(RG_TM_BLOCK / 64) * RG_TM_WAVE_TILE_BYTES;
+    uint32_t lds_tables = FMT == RG_FMT_F32_PLANAR && lds <= 80 * 1024 ? 1u : 0u;
+    if (!lds_tables) lds = 0;
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute((const void *)rg_tm_main_kernel<FMT>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((rg_tm_main_kernel<FMT>), dim3(grid, nch), dim3(RG_TM_BLOCK), lds, s, K, G, d_tracks, n_tracks,
+                       d_rec, total_recs, lds_tables, g_tm_debug);
     return hipGetLastError();
 }
 
 extern "C" hipError_t rg_launch_tm_main(int fmt, int nch, const RgTmCoef *K, const RgTmGeom *G,
                                         const RgTmTrack *d_tracks, uint32_t n_tracks, uint32_t grid, double *d_rec,
-                                        uint32_t total_recs, unsigned long long *d_peak_bits, hipStream_t s) {
+                                        uint32_t total_recs, hipStream_t s) {
     if (grid == 0) return hipSuccess;
     switch (fmt) {
-        case RG_FMT_F32_PLANAR: return launch_main_fmt<RG_FMT_F32_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_peak_bits, s);
-        case RG_FMT_S16_PLANAR: return launch_main_fmt<RG_FMT_S16_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_peak_bits, s);
-        default: return launch_main_fmt<RG_FMT_S32_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_peak_bits, s);
+        case RG_FMT_F32_PLANAR: return launch_main_fmt<RG_FMT_F32_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, s);
+        case RG_FMT_S16_PLANAR: return launch_main_fmt<RG_FMT_S16_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, s);
+        default: return launch_main_fmt<RG_FMT_S32_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, s);
     }
 }
 
 extern "C" hipError_t rg_launch_tm_fix(int nch, const RgTmGeom *G, const RgTmFixTables *FT, const RgTmTrack *d_tracks,
                                        uint32_t n_tracks, uint32_t grid, const double *d_rec, uint32_t total_recs,
-                                       uint32_t *d_hist, hipStream_t s) {
+                                       uint32_t *d_hist, unsigned long long *d_peak_bits, hipStream_t s) {
     if (grid == 0) return hipSuccess;
     if (nch == 1)
         hipLaunchKernelGGL((rg_tm_fix_kernel<1>), dim3(grid), dim3(RG_TM_BLOCK), 0, s, *G, *FT, d_tracks, n_tracks, d_rec,
-                           total_recs, d_hist);
+                           total_recs, d_hist, d_peak_bits);
     else
         hipLaunchKernelGGL((rg_tm_fix_kernel<2>), dim3(grid), dim3(RG_TM_BLOCK), 0, s, *G, *FT, d_tracks, n_tracks, d_rec,
-                           total_recs, d_hist);
+                           total_recs, d_hist, d_peak_bits);
     return hipGetLastError();
 }

@@ -25,7 +25,7 @@
 
 #define RG_TM_DIM 12          // state dimension: 10 (Yule) + 2 (Butter)
 #define RG_TM_GRAM 78         // upper triangle of a symmetric 12x12
-#define RG_TM_REC 25          // doubles per (segment, channel): A, B[12], E[12]
+#define RG_TM_REC 26          // doubles per (segment, channel): A, B[12], E[12], peak
 #define RG_TM_BLOCK 256
 #define RG_TM_MAX_ROUNDS 5
 
@@ -61,6 +61,7 @@ struct RgTmGeom {
     uint32_t warm;         // warm-up lanes per fix-up block (2^R)
     uint32_t fix_windows;  // whole windows per fix-up block
     const double *T;       // [L][12] homogeneous responses, block-diagonal coordinates
+    const double *Tlds;    // the same packed for LDS: [H10][12] then [L - H10][2] (only the slow pair)
 };
 
 // device tables of the fix-up kernel (passed by value; all wave-uniform reads)

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Per-wave timeline of rg_tm_main_kernel (diagnostic): when each wave started/ended and on which
+XCD/SE/CU/SIMD it ran.  Usage on the GPU box: python tools/ubench/timeline.py [L]"""
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+import mp3rgain_amd as rg  # noqa: E402
+from mp3rgain_amd import _capi  # noqa: E402
+
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+rate, frames = 44100, 44100 * 600
+an = rg.Analyzer(0)
+if L:
+    an.set_tuning(1, L)
+pcm = torch.empty((1, 2, frames), dtype=torch.float32, device="cuda")
+for c in range(2):
+    an.synth_fill_device(pcm[0, c].data_ptr(), 0x5EED0000, c, rate, 0, frames)
+d = (_capi.TrackDesc * 1)()
+d[0].offset_bytes, d[0].frames, d[0].sample_rate, d[0].channels, d[0].format = 0, frames, rate, 2, 0
+raw = C.CDLL(str(_capi.LIB_PATH))
+raw.rg_tm_set_debug_buffer.argtypes = [C.c_void_p]
+nw = 1 << 16
+dbg = torch.zeros(nw * 4, dtype=torch.int64, device="cuda")
+for _ in range(3):
+    an.enqueue_device(d, 1, pcm.data_ptr(), pcm.numel() * 4)
+an.collect(1)
+raw.rg_tm_set_debug_buffer(dbg.data_ptr())
+an.enqueue_device(d, 1, pcm.data_ptr(), pcm.numel() * 4)
+an.collect(1)
+raw.rg_tm_set_debug_buffer(None)
+a = dbg.cpu().numpy().reshape(-1, 4)
+a = a[a[:, 0] != 0]
+t0 = a[:, 0].min()
+st, en = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0  # wall_clock64 ticks at 100 MHz -> us
+hw = a[:, 2] & 0xFFFFFFFF
+xcc = (a[:, 2] >> 32) & 0xF
+cu = (hw >> 8) & 0xF
+sh = (hw >> 12) & 0x1
+se = (hw >> 13) & 0x7
+simd = (hw >> 4) & 0x3
+print(f"waves {len(a)}  fast-path {int(a[:,3].sum())}  kernel span {en.max():.1f} us")
+print(f"start: min {st.min():.1f} med {np.median(st):.1f} max {st.max():.1f} us; duration: min {(en-st).min():.1f} med {np.median(en-st):.1f} max {(en-st).max():.1f} us")
+key = xcc * 1000 + se * 100 + sh * 50 + cu
+uk, cnt = np.unique(key, return_counts=True)
+print(f"distinct (xcc,se,sh,cu) = {len(uk)}; waves per CU: min {cnt.min()} med {int(np.median(cnt))} max {cnt.max()}")
+for q in (0.1, 0.25, 0.5, 0.75, 0.9, 1.0):
+    print(f"  {int(q*100):3d}% of waves finished by {np.quantile(en, q):8.1f} us")
+print("per-XCD wave counts:", np.bincount(xcc.astype(int), minlength=8))
