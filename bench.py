@@ -55,6 +55,7 @@ def main() -> int:
     ap.add_argument("--tracks-per-rank", type=int, default=1)
     ap.add_argument("--minutes", type=float, default=10.0, help="track length (default: BASELINE's 10 min)")
     ap.add_argument("--tm-segment", type=int, default=0, help="force variant 2 segment length (tuning)")
+    ap.add_argument("--slots", type=int, default=0, help="pipeline slots of the library (0 = default)")
     ap.add_argument("--cpu-reps", type=int, default=8, help="oracle repetitions for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -88,6 +89,8 @@ def main() -> int:
         an.set_kernel(args.kernel)
     if args.tm_segment:
         an.set_tuning(1, args.tm_segment)
+    if args.slots:
+        an.set_tuning(3, args.slots)
     stream = torch.cuda.current_stream()
     an.set_stream(stream.cuda_stream)
 
@@ -107,17 +110,17 @@ def main() -> int:
     torch.cuda.synchronize()
 
     album = world > 1
-    view = None
-    hist_t = peak_t = None
+    views = {}  # the library rotates through pipeline slots: one pair of tensor views per slot
 
     def step():
-        nonlocal view, hist_t, peak_t
         an.enqueue_device(descs, ntr, pcm.data_ptr(), pcm_bytes, album=album)
         if album:
-            if view is None:
-                view = an.device_view()
-                hist_t = torch.as_tensor(_DevArray(view.d_album_hist, (_capi.HISTOGRAM_SIZE,), "<i4"), device="cuda")
-                peak_t = torch.as_tensor(_DevArray(view.d_album_peak, (1,), "<f8"), device="cuda")
+            view = an.device_view()
+            if view.d_album_hist not in views:
+                views[view.d_album_hist] = (
+                    torch.as_tensor(_DevArray(view.d_album_hist, (_capi.HISTOGRAM_SIZE,), "<i4"), device="cuda"),
+                    torch.as_tensor(_DevArray(view.d_album_peak, (1,), "<f8"), device="cuda"))
+            hist_t, peak_t = views[view.d_album_hist]
             # LoudnessHistogram::accumulate / album_peak.max across ranks (replaygain.rs:1056-1059);
             # int32 two's-complement sum == the reference's u32 bins
             dist.all_reduce(hist_t, op=dist.ReduceOp.SUM)

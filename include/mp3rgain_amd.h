@@ -138,7 +138,9 @@ int rg_set_stream(rg_ctx *ctx, void *hip_stream);
 int rg_set_kernel(rg_ctx *ctx, int variant);
 
 /* tuning knobs (0 restores the default): key 1 = segment length of variant 2 in frames (must divide
- * the 50 ms window), key 2 = number of segments (lanes) variant 2 aims for when it picks one */
+ * the 50 ms window), key 2 = number of segments (lanes) variant 2 aims for when it picks one,
+ * key 3 = number of pipeline slots (1..8, default 4): consecutive enqueues run on separate HIP streams and
+ * overlap on the GPU; rg_collect / rg_album_finish always refer to the most recent enqueue */
 int rg_set_tuning(rg_ctx *ctx, int key, int64_t value);
 /* diagnostic (host only): variant 2's design for one rate and segment length.  T_out: [L][12],
  * gram_last_out: [78]; either may be NULL.  RG_ERR_INVALID_ARG when no design exists. */

@@ -69,13 +69,23 @@ int32_t round_to_i32(double v) {  // Rust: f64::round() as i32
 
 // flush finished timing events into the running sum (requires the stream to be idle)
 int drain_timing(rg_ctx *c) {
-    for (size_t i = 0; i < c->ev_used; ++i) {
-        float ms = 0.f;
-        RG_HIP(c, hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second));
-        c->timing_sum_ms += ms;
-        c->timing_count += 1;
+    for (int k = 0; k < RG_MAX_SLOTS; ++k) {
+        RgSlot &S = c->slots[k];
+        for (size_t i = 0; i < S.ev_used; ++i) {
+            float ms = 0.f;
+            RG_HIP(c, hipEventElapsedTime(&ms, S.ev_pool[i].first, S.ev_pool[i].second));
+            c->timing_sum_ms += ms;
+            c->timing_count += 1;
+        }
+        S.ev_used = 0;
     }
-    c->ev_used = 0;
+    return RG_OK;
+}
+
+int sync_all(rg_ctx *c) {
+    for (int k = 0; k < RG_MAX_SLOTS; ++k)
+        if (c->slots[k].stream) RG_HIP(c, hipStreamSynchronize(c->slots[k].stream));
+    if (c->user_stream) RG_HIP(c, hipStreamSynchronize(c->user_stream));
     return RG_OK;
 }
 
@@ -156,14 +166,23 @@ extern "C" rg_ctx *rg_create(int device) {
     }
     rg_ctx *c = new rg_ctx();
     c->device = device;
-    if ((e = hipSetDevice(device)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->staging_done, hipEventDisableTiming)) != hipSuccess) {
-        rg_set_err(nullptr, RG_ERR_DEVICE, "stream creation: %s", hipGetErrorString(e));
-        delete c;
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->user_ev, hipEventDisableTiming);
+    for (int k = 0; k < RG_MAX_SLOTS && e == hipSuccess; ++k) {
+        RgSlot &S = c->slots[k];
+        e = hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&S.staging_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&S.batch_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = S.d_album_hist.reserve(RG_HISTOGRAM_SIZE);
+        if (e == hipSuccess) e = S.d_album_peak.reserve(1);
+        if (e == hipSuccess) e = S.d_album_result.reserve(1);
+        if (e == hipSuccess) e = S.h_album_result.reserve(1);
+    }
+    if (e != hipSuccess) {
+        rg_set_err(nullptr, RG_ERR_DEVICE, "stream / buffer creation: %s", hipGetErrorString(e));
+        rg_destroy(c);
         return nullptr;
     }
-    c->stream = c->own_stream;
 
     std::vector<RgCoefDev> coefs(RG_NUM_RATES);
     for (int i = 0; i < RG_NUM_RATES; ++i) {
@@ -175,10 +194,7 @@ extern "C" rg_ctx *rg_create(int device) {
     }
     if ((e = c->d_coefs.reserve(RG_NUM_RATES)) != hipSuccess ||
         (e = hipMemcpy(c->d_coefs.p, coefs.data(), sizeof(RgCoefDev) * RG_NUM_RATES, hipMemcpyHostToDevice)) !=
-            hipSuccess ||
-        (e = c->d_album_hist.reserve(RG_HISTOGRAM_SIZE)) != hipSuccess ||
-        (e = c->d_album_peak.reserve(1)) != hipSuccess || (e = c->d_album_result.reserve(1)) != hipSuccess ||
-        (e = c->h_album_result.reserve(1)) != hipSuccess) {
+            hipSuccess) {
         rg_set_err(nullptr, RG_ERR_DEVICE, "context allocation: %s", hipGetErrorString(e));
         rg_destroy(c);
         return nullptr;
@@ -189,39 +205,41 @@ extern "C" rg_ctx *rg_create(int device) {
 extern "C" void rg_destroy(rg_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto &p : c->ev_pool) {
-        (void)hipEventDestroy(p.first);
-        (void)hipEventDestroy(p.second);
+    (void)sync_all(c);
+    for (int k = 0; k < RG_MAX_SLOTS; ++k) {
+        RgSlot &S = c->slots[k];
+        for (auto &p : S.ev_pool) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+        S.d_desc.release();
+        S.h_desc.release();
+        S.d_tm_rec.release();
+        S.d_hist.release();
+        S.d_results.release();
+        S.h_results.release();
+        S.d_album_hist.release();
+        S.d_album_peak.release();
+        S.d_album_result.release();
+        S.h_album_result.release();
+        if (S.staging_done) (void)hipEventDestroy(S.staging_done);
+        if (S.batch_done) (void)hipEventDestroy(S.batch_done);
+        if (S.stream) (void)hipStreamDestroy(S.stream);
     }
+    if (c->user_ev) (void)hipEventDestroy(c->user_ev);
     c->d_coefs.release();
-    c->d_tracks.release();
-    c->h_tracks.release();
-    c->d_k1_tracks.release();
-    c->h_k1_tracks.release();
-    c->d_tm_tracks.release();
-    c->h_tm_tracks.release();
-    c->d_tm_rec.release();
-    rg_tm_tables_release(c);
-    if (c->staging_done) (void)hipEventDestroy(c->staging_done);
-    c->d_hist.release();
     c->d_peak_bits.release();
-    c->d_results.release();
-    c->h_results.release();
-    c->d_album_hist.release();
-    c->d_album_peak.release();
-    c->d_album_result.release();
-    c->h_album_result.release();
     c->d_arena.release();
-    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    rg_tm_tables_release(c);
     delete c;
 }
 
 extern "C" int rg_set_stream(rg_ctx *c, void *s) {
     if (!c) return RG_ERR_INVALID_ARG;
     if (rg_bind_device(c) != RG_OK) return RG_ERR_DEVICE;
-    RG_HIP(c, hipStreamSynchronize(c->stream));
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    int rc = sync_all(c);
+    if (rc != RG_OK) return rc;
+    c->user_stream = (hipStream_t)s;
     return RG_OK;
 }
 
@@ -238,6 +256,12 @@ extern "C" int rg_set_tuning(rg_ctx *c, int key, int64_t value) {
     switch (key) {
         case RG_TUNE_TM_SEGMENT: c->tune_tm_segment = (uint32_t)value; return RG_OK;
         case RG_TUNE_TM_TARGET_LANES: c->tune_tm_target_lanes = (uint64_t)value; return RG_OK;
+        case RG_TUNE_PIPELINE_SLOTS: {
+            if (sync_all(c) != RG_OK) return RG_ERR_DEVICE;
+            c->n_slots = value == 0 ? 4 : (value > RG_MAX_SLOTS ? RG_MAX_SLOTS : (int)value);
+            c->cur = 0;
+            return RG_OK;
+        }
         default: return rg_set_err(c, RG_ERR_INVALID_ARG, "unknown tuning key %d", key);
     }
 }
@@ -267,8 +291,9 @@ extern "C" int rg_timing_enable(rg_ctx *c, int on) {
 extern "C" int rg_timing_read(rg_ctx *c, double *sum_ms, uint64_t *launches, int reset) {
     if (!c) return RG_ERR_INVALID_ARG;
     if (rg_bind_device(c) != RG_OK) return RG_ERR_DEVICE;
-    RG_HIP(c, hipStreamSynchronize(c->stream));
-    int rc = drain_timing(c);
+    int rc = sync_all(c);
+    if (rc != RG_OK) return rc;
+    rc = drain_timing(c);
     if (rc != RG_OK) return rc;
     if (sum_ms) *sum_ms = c->timing_sum_ms;
     if (launches) *launches = c->timing_count;
@@ -289,9 +314,10 @@ int stage_pcm(rg_ctx *c, const void *pcm_base, size_t pcm_bytes, int on_device, 
     }
     int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
-    RG_HIP(c, hipStreamSynchronize(c->stream));  // the arena may still be read by a previous batch
+    rc = sync_all(c);  // the arena may still be read by a previous batch
+    if (rc != RG_OK) return rc;
     RG_HIP(c, c->d_arena.reserve(pcm_bytes ? pcm_bytes : 1));
-    if (pcm_bytes) RG_HIP(c, hipMemcpyAsync(c->d_arena.p, pcm_base, pcm_bytes, hipMemcpyHostToDevice, c->stream));
+    if (pcm_bytes) RG_HIP(c, hipMemcpy(c->d_arena.p, pcm_base, pcm_bytes, hipMemcpyHostToDevice));
     *d_base = c->d_arena.p;
     return RG_OK;
 }
@@ -305,11 +331,11 @@ extern "C" int rg_enqueue_pcm_batch(rg_ctx *c, const rg_track_desc *tracks, size
 
 extern "C" int rg_device_view_get(rg_ctx *c, rg_device_view *v) {
     if (!c || !v) return RG_ERR_INVALID_ARG;
-    v->d_track_hist = c->d_hist.p;
-    v->d_track_result = c->d_results.p;
-    v->d_album_hist = c->d_album_hist.p;
-    v->d_album_peak = c->d_album_peak.p;
-    v->n_tracks = c->n_enqueued;
+    v->d_track_hist = c->slot().d_hist.p;
+    v->d_track_result = c->slot().d_results.p;
+    v->d_album_hist = c->slot().d_album_hist.p;
+    v->d_album_peak = c->slot().d_album_peak.p;
+    v->n_tracks = c->slot().n_enqueued;
     return RG_OK;
 }
 
@@ -317,40 +343,40 @@ extern "C" int rg_collect(rg_ctx *c, rg_track_result *out, uint32_t *hist_out) {
     if (!c) return RG_ERR_INVALID_ARG;
     int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
-    const size_t n = c->n_enqueued;
+    const size_t n = c->slot().n_enqueued;
     if (n && out)
-        RG_HIP(c, hipMemcpyAsync(c->h_results.p, c->d_results.p, n * sizeof(rg_track_result), hipMemcpyDeviceToHost,
-                                 c->stream));
+        RG_HIP(c, hipMemcpyAsync(c->slot().h_results.p, c->slot().d_results.p, n * sizeof(rg_track_result), hipMemcpyDeviceToHost,
+                                 c->slot().stream));
     if (n && hist_out)
-        RG_HIP(c, hipMemcpyAsync(hist_out, c->d_hist.p, n * (size_t)RG_HISTOGRAM_SIZE * sizeof(uint32_t),
-                                 hipMemcpyDeviceToHost, c->stream));
-    RG_HIP(c, hipStreamSynchronize(c->stream));
-    if (n && out) memcpy(out, c->h_results.p, n * sizeof(rg_track_result));
+        RG_HIP(c, hipMemcpyAsync(hist_out, c->slot().d_hist.p, n * (size_t)RG_HISTOGRAM_SIZE * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, c->slot().stream));
+    RG_HIP(c, hipStreamSynchronize(c->slot().stream));
+    if (n && out) memcpy(out, c->slot().h_results.p, n * sizeof(rg_track_result));
     return RG_OK;
 }
 
 extern "C" int rg_album_result_enqueue(rg_ctx *c) {
     if (!c) return RG_ERR_INVALID_ARG;
-    if (!c->album_ready) return rg_set_err(c, RG_ERR_STATE, "rg_album_result_enqueue without an album enqueue");
+    if (!c->slot().album_ready) return rg_set_err(c, RG_ERR_STATE, "rg_album_result_enqueue without an album enqueue");
     int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
-    RG_HIP(c, rg_launch_album_result(c->d_album_hist.p, c->d_album_peak.p, c->d_album_result.p, c->stream));
+    RG_HIP(c, rg_launch_album_result(c->slot().d_album_hist.p, c->slot().d_album_peak.p, c->slot().d_album_result.p, c->album_stream()));
     return RG_OK;
 }
 
 extern "C" int rg_album_finish(rg_ctx *c, rg_album_result *album_out, uint32_t *album_hist_out) {
     if (!c) return RG_ERR_INVALID_ARG;
-    if (!c->album_ready) return rg_set_err(c, RG_ERR_STATE, "rg_album_finish without an album enqueue");
+    if (!c->slot().album_ready) return rg_set_err(c, RG_ERR_STATE, "rg_album_finish without an album enqueue");
     int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
-    RG_HIP(c, rg_launch_album_result(c->d_album_hist.p, c->d_album_peak.p, c->d_album_result.p, c->stream));
-    RG_HIP(c, hipMemcpyAsync(c->h_album_result.p, c->d_album_result.p, sizeof(rg_album_result), hipMemcpyDeviceToHost,
-                             c->stream));
+    RG_HIP(c, rg_launch_album_result(c->slot().d_album_hist.p, c->slot().d_album_peak.p, c->slot().d_album_result.p, c->album_stream()));
+    RG_HIP(c, hipMemcpyAsync(c->slot().h_album_result.p, c->slot().d_album_result.p, sizeof(rg_album_result), hipMemcpyDeviceToHost,
+                             c->album_stream()));
     if (album_hist_out)
-        RG_HIP(c, hipMemcpyAsync(album_hist_out, c->d_album_hist.p, RG_HISTOGRAM_SIZE * sizeof(uint32_t),
-                                 hipMemcpyDeviceToHost, c->stream));
-    RG_HIP(c, hipStreamSynchronize(c->stream));
-    if (album_out) *album_out = *c->h_album_result.p;
+        RG_HIP(c, hipMemcpyAsync(album_hist_out, c->slot().d_album_hist.p, RG_HISTOGRAM_SIZE * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, c->album_stream()));
+    RG_HIP(c, hipStreamSynchronize(c->album_stream()));
+    if (album_out) *album_out = *c->slot().h_album_result.p;
     return RG_OK;
 }
 
@@ -373,7 +399,7 @@ void *resolve(const char *name) {
 
 extern "C" int rg_album_allreduce(rg_ctx *c, void *comm) {
     if (!c) return RG_ERR_INVALID_ARG;
-    if (!c->album_ready) return rg_set_err(c, RG_ERR_STATE, "rg_album_allreduce without an album enqueue");
+    if (!c->slot().album_ready) return rg_set_err(c, RG_ERR_STATE, "rg_album_allreduce without an album enqueue");
     if (!comm) return RG_OK;  // single GPU: nothing to exchange
     nccl_allreduce_fn ar = (nccl_allreduce_fn)resolve("ncclAllReduce");
     nccl_group_fn gs = (nccl_group_fn)resolve("ncclGroupStart");
@@ -382,8 +408,8 @@ extern "C" int rg_album_allreduce(rg_ctx *c, void *comm) {
     int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
     int r = gs();
-    if (r == 0) r = ar(c->d_album_hist.p, c->d_album_hist.p, RG_HISTOGRAM_SIZE, kNcclUint32, kNcclSum, comm, c->stream);
-    if (r == 0) r = ar(c->d_album_peak.p, c->d_album_peak.p, 1, kNcclFloat64, kNcclMax, comm, c->stream);
+    if (r == 0) r = ar(c->slot().d_album_hist.p, c->slot().d_album_hist.p, RG_HISTOGRAM_SIZE, kNcclUint32, kNcclSum, comm, c->album_stream());
+    if (r == 0) r = ar(c->slot().d_album_peak.p, c->slot().d_album_peak.p, 1, kNcclFloat64, kNcclMax, comm, c->album_stream());
     int r2 = ge();
     if (r != 0 || r2 != 0) return rg_set_err(c, RG_ERR_COLLECTIVE, "ncclAllReduce failed (%d/%d)", r, r2);
     return RG_OK;
@@ -428,12 +454,12 @@ extern "C" int rg_find_peak_pcm(rg_ctx *c, const rg_track_desc *track, const voi
     int rc = stage_pcm(c, pcm_base, pcm_bytes, on_device, &d_base);
     if (rc != RG_OK) return rc;
     RG_HIP(c, c->d_peak_bits.reserve(1));
-    RG_HIP(c, hipMemsetAsync(c->d_peak_bits.p, 0, sizeof(unsigned long long), c->stream));
+    RG_HIP(c, hipMemsetAsync(c->d_peak_bits.p, 0, sizeof(unsigned long long), (c->user_stream ? c->user_stream : c->slot().stream)));
     RG_HIP(c, rg_launch_peak_all((const unsigned char *)d_base + track->offset_bytes, total, track->format,
-                                 c->d_peak_bits.p, c->stream));
+                                 c->d_peak_bits.p, (c->user_stream ? c->user_stream : c->slot().stream)));
     unsigned long long bits = 0;
-    RG_HIP(c, hipMemcpyAsync(&bits, c->d_peak_bits.p, sizeof bits, hipMemcpyDeviceToHost, c->stream));
-    RG_HIP(c, hipStreamSynchronize(c->stream));
+    RG_HIP(c, hipMemcpyAsync(&bits, c->d_peak_bits.p, sizeof bits, hipMemcpyDeviceToHost, (c->user_stream ? c->user_stream : c->slot().stream)));
+    RG_HIP(c, hipStreamSynchronize((c->user_stream ? c->user_stream : c->slot().stream)));
     double pk;
     memcpy(&pk, &bits, sizeof pk);
     out->peak = pk;
@@ -448,6 +474,6 @@ extern "C" int rg_synth_fill_device(rg_ctx *c, void *d_dst, uint64_t seed, uint3
     if (!c || (!d_dst && frames)) return RG_ERR_INVALID_ARG;
     int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
-    RG_HIP(c, rg_launch_synth_fill((float *)d_dst, seed, channel, sample_rate, first_frame, frames, c->stream));
+    RG_HIP(c, rg_launch_synth_fill((float *)d_dst, seed, channel, sample_rate, first_frame, frames, (c->user_stream ? c->user_stream : c->slot().stream)));
     return RG_OK;
 }

@@ -4,6 +4,7 @@
 
 #include "../../include/rg_synth.h"
 #include "rg_device.h"
+#include "rg_device_inl.h"
 
 // ---------------------------------------------------------------------------------------------
 // LoudnessHistogram::get_loudness (src/replaygain.rs:665-682) for one histogram per workgroup,
@@ -16,89 +17,24 @@
 // and finishes inside the crossing chunk, so the scan order and the result are exactly the
 // sequential ones.
 // ---------------------------------------------------------------------------------------------
-#define RG_PCT_THREADS 256
-#define RG_PCT_CHUNK 47  // 256 * 47 = 12032 >= 12000
-
-struct RgLoudness {
-    double loudness_db;
-    uint64_t total;
-};
-
-static __device__ RgLoudness rg_block_loudness(const uint32_t *__restrict__ h, uint64_t *chunk_sum /* LDS[256] */) {
-    const int t = threadIdx.x;
-    const int b0 = t * RG_PCT_CHUNK;
-    uint64_t s = 0;
-    for (int i = 0; i < RG_PCT_CHUNK; ++i) {
-        const int b = b0 + i;
-        if (b < RG_HISTOGRAM_SIZE) s += h[b];
-    }
-    chunk_sum[t] = s;
-    __syncthreads();
-    __shared__ RgLoudness res;
-    if (t == 0) {
-        uint64_t total = 0;
-        for (int i = 0; i < RG_PCT_THREADS; ++i) total += chunk_sum[i];
-        double loud = -20.0;
-        if (total != 0) {
-            const uint64_t threshold = (uint64_t)ceil((double)total * RG_ONE_MINUS_PERCENTILE);
-            uint64_t count = 0;
-            int c = RG_PCT_THREADS - 1;
-            for (; c >= 0; --c) {
-                if (count + chunk_sum[c] >= threshold) break;
-                count += chunk_sum[c];
-            }
-            if (c >= 0) {
-                int hi = c * RG_PCT_CHUNK + RG_PCT_CHUNK - 1;
-                if (hi > RG_HISTOGRAM_SIZE - 1) hi = RG_HISTOGRAM_SIZE - 1;
-                for (int i = hi; i >= c * RG_PCT_CHUNK; --i) {
-                    count += h[i];
-                    if (count >= threshold) {
-                        loud = (double)(i - RG_HISTOGRAM_OFFSET) / 100.0;
-                        break;
-                    }
-                }
-            }
-        }
-        res.loudness_db = loud;
-        res.total = total;
-    }
-    __syncthreads();
-    return res;
-}
-
-static __device__ __forceinline__ int32_t rg_round_steps(double gain_db) {
-    const double r = round(gain_db / RG_GAIN_STEP_DB);  // Rust f64::round: half away from zero
-    if (r != r) return 0;
-    if (r >= 2147483647.0) return 2147483647;
-    if (r <= -2147483648.0) return (int32_t)0x80000000;
-    return (int32_t)r;
-}
-
 __global__ void __launch_bounds__(RG_PCT_THREADS)
 rg_track_result_kernel(const uint32_t *__restrict__ hist, const unsigned long long *__restrict__ peak_bits,
-                       const RgTrackDev *__restrict__ tracks,
+                       const RgTrackDev *__restrict__ list /* the tracks to finish, any subset */,
                        rg_track_result *__restrict__ out) {
-    __shared__ uint64_t chunk_sum[RG_PCT_THREADS];
-    const uint32_t t = blockIdx.x;
-    const RgLoudness l = rg_block_loudness(hist + (size_t)t * RG_HISTOGRAM_SIZE, chunk_sum);
-    if (threadIdx.x == 0) {
-        rg_track_result r;
-        r.loudness_db = l.loudness_db;
-        r.gain_db = RG_PINK_REF - l.loudness_db;
-        r.peak = __longlong_as_double((long long)peak_bits[t]);
-        r.sample_rate = tracks[t].sample_rate;
-        r.gain_steps = rg_round_steps(r.gain_db);
-        r.windows = (uint32_t)l.total;
-        r.file_type = tracks[t].file_type;
-        out[t] = r;
-    }
+    __shared__ uint64_t scan[RG_PCT_THREADS];
+    __shared__ uint32_t bins[RG_PCT_THREADS * RG_PCT_CHUNK];
+    const RgTrackDev tr = list[blockIdx.x];
+    const uint32_t t = tr.track_index;
+    const RgLoudness l = rg_block_loudness(hist + (size_t)t * RG_HISTOGRAM_SIZE, bins, scan);
+    if (threadIdx.x == 0) rg_store_track_result(out + t, l, __longlong_as_double((long long)peak_bits[t]), tr.sample_rate, tr.file_type);
 }
 
 __global__ void __launch_bounds__(RG_PCT_THREADS)
 rg_album_result_kernel(const uint32_t *__restrict__ album_hist, const double *__restrict__ album_peak,
                        rg_album_result *__restrict__ out) {
-    __shared__ uint64_t chunk_sum[RG_PCT_THREADS];
-    const RgLoudness l = rg_block_loudness(album_hist, chunk_sum);
+    __shared__ uint64_t scan[RG_PCT_THREADS];
+    __shared__ uint32_t bins[RG_PCT_THREADS * RG_PCT_CHUNK];
+    const RgLoudness l = rg_block_loudness(album_hist, bins, scan);
     if (threadIdx.x == 0) {
         rg_album_result r;
         r.album_loudness_db = l.loudness_db;

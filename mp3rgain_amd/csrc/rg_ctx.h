@@ -62,48 +62,67 @@ struct RgTmDeviceTables {
     RgTmFixTables fix{};
 };
 
-enum { RG_TUNE_TM_SEGMENT = 1, RG_TUNE_TM_TARGET_LANES = 2 };
+enum { RG_TUNE_TM_SEGMENT = 1, RG_TUNE_TM_TARGET_LANES = 2, RG_TUNE_PIPELINE_SLOTS = 3 };
 
-struct rg_ctx {
-    int device = -1;
-    hipStream_t own_stream = nullptr;
+#define RG_MAX_SLOTS 8
+
+// Everything one enqueued batch owns.  A context rotates through several slots, each with its own
+// HIP stream, so that consecutive batches overlap on the GPU: the latency-bound fix-up / percentile
+// kernels of batch i run under the main kernel of batch i+1, and two main kernels of small batches
+// share the chip (one 10-minute track alone leaves it at under two waves per SIMD).
+struct RgSlot {
     hipStream_t stream = nullptr;
-    std::string err;
-    int kernel_variant = 0;      // 0 auto (= 2), 1 halo/reference-order kernel, 2 transient-moment kernels
-    uint32_t tune_tm_segment = 0;          // 0 = choose from the workload
-    uint64_t tune_tm_target_lanes = 0;     // 0 = default
-
-    RgRateDesign design[RG_NUM_RATES];
-    DevBuf<RgCoefDev> d_coefs;
-
-    DevBuf<RgTrackDev> d_tracks;       // all tracks of the batch, index == track index
-    PinnedBuf<RgTrackDev> h_tracks;
-    DevBuf<RgTrackDev> d_k1_tracks;    // the tracks variant 1 processes (a subset under variant 2)
-    PinnedBuf<RgTrackDev> h_k1_tracks;
-    DevBuf<RgTmTrack> d_tm_tracks;     // variant 2 launch lists, all groups back to back
-    PinnedBuf<RgTmTrack> h_tm_tracks;
-    DevBuf<double> d_tm_rec;           // segment records (rg_tm.h)
-    std::map<uint32_t, RgTmDeviceTables *> tm_tables;  // key = rate_idx << 16 | L
-    hipEvent_t staging_done = nullptr; // H2D copies out of the pinned staging buffers have finished
+    hipEvent_t staging_done = nullptr;  // H2D copy out of the pinned staging buffer has finished
+    hipEvent_t batch_done = nullptr;    // everything enqueued for the batch has finished
     bool staging_pending = false;
-
-    DevBuf<uint32_t> d_hist;
-    DevBuf<unsigned long long> d_peak_bits;
+    // all launch descriptors of a batch travel as one blob: [RgTrackDev x n | RgTrackDev x n_k1 | RgTmTrack x m];
+    // an unchanged blob (the same batch enqueued again) is not copied again
+    DevBuf<unsigned char> d_desc;
+    PinnedBuf<unsigned char> h_desc;
+    std::vector<unsigned char> desc_shadow;  // what d_desc currently holds
+    DevBuf<double> d_tm_rec;                 // segment records (rg_tm.h)
+    DevBuf<uint32_t> d_hist;                 // [hist n*12000 | peak n*2 | done n] words
+    unsigned long long *peak_ptr = nullptr;
     DevBuf<rg_track_result> d_results;
     PinnedBuf<rg_track_result> h_results;
     DevBuf<uint32_t> d_album_hist;
     DevBuf<double> d_album_peak;
     DevBuf<rg_album_result> d_album_result;
     PinnedBuf<rg_album_result> h_album_result;
-    DevBuf<unsigned char> d_arena;  // staging for host PCM
-
     size_t n_enqueued = 0;
     bool album_ready = false;
-
-    // timing of the dominant kernel
-    bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // timing of the dominant kernel
     size_t ev_used = 0;
+};
+
+struct rg_ctx {
+    int device = -1;
+    std::string err;
+    int kernel_variant = 0;      // 0 auto (= 2), 1 halo/reference-order kernel, 2 transient-moment kernels
+    uint32_t tune_tm_segment = 0;          // 0 = choose from the workload
+    uint64_t tune_tm_target_lanes = 0;     // 0 = cost model
+    int n_slots = 4;
+
+    RgSlot slots[RG_MAX_SLOTS];
+    int cur = 0;                        // slot of the most recent enqueue
+    hipStream_t user_stream = nullptr;  // rg_set_stream: inputs are ordered after it, album collectives run on it
+    hipEvent_t user_ev = nullptr;
+    RgSlot &slot() { return slots[cur]; }
+    // stream on which the album tail (all-reduce, album percentile, its D2H) runs
+    hipStream_t album_stream() { return user_stream ? user_stream : slots[cur].stream; }
+
+    RgRateDesign design[RG_NUM_RATES];
+    DevBuf<RgCoefDev> d_coefs;
+    std::map<uint32_t, RgTmDeviceTables *> tm_tables;  // key = rate_idx << 16 | L, shared by all slots (read only)
+
+    // host scratch for building one batch's descriptors
+    std::vector<RgTrackDev> h_tracks, h_k1_tracks;
+    std::vector<RgTmTrack> h_tm_tracks;
+
+    DevBuf<unsigned long long> d_peak_bits;  // rg_find_peak_pcm
+    DevBuf<unsigned char> d_arena;           // staging for host PCM (synchronous API)
+
+    bool timing = false;
     double timing_sum_ms = 0.0;
     uint64_t timing_count = 0;
 };

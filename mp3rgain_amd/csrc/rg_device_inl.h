@@ -21,3 +21,103 @@ static __device__ __forceinline__ int rg_window_bin(double lsum, double rsum, ui
     const int idx = (int)((unsigned)iv + (unsigned)RG_HISTOGRAM_OFFSET);
     return (idx >= 0 && idx < RG_HISTOGRAM_SIZE) ? idx : -1;
 }
+
+// ---------------------------------------------------------------------------------------------
+// LoudnessHistogram::get_loudness (src/replaygain.rs:665-682) for one histogram per workgroup of 256
+// threads, followed by the tail of analyze_track_internal (src/replaygain.rs:910-918): gain =
+// PINK_REF - loudness, gain_steps = round(gain / 1.5).
+//   total     = sum of bins (u64)
+//   threshold = ceil(total as f64 * (1.0 - 0.95)) as u64
+//   scan i = 11999 .. 0 accumulating; first i with count >= threshold -> (i - 2000) / 100.0
+// ---------------------------------------------------------------------------------------------
+#define RG_PCT_THREADS 256
+#define RG_PCT_CHUNK 47  // 256 * 47 = 12032 >= 12000
+
+struct RgLoudness {
+    double loudness_db;
+    uint64_t total;
+};
+
+// All 256 threads cooperate: the histogram is staged in LDS with coalesced loads, thread t owns bins
+// [47t, 47t+47), a block-wide suffix scan of the 256 chunk sums finds the one chunk in which the
+// running count (from the top bin down) first reaches the threshold, and that thread alone walks its
+// 47 bins from the top.  The result is exactly the sequential scan's.
+static __device__ __forceinline__ RgLoudness rg_block_loudness(const uint32_t *__restrict__ h, uint32_t *bins /* LDS[12032] */,
+                                               uint64_t *scan /* LDS[256] */) {
+    const int t = threadIdx.x;
+    {   // 12000 bins = 3000 16-byte vectors, 12 per thread, all loads in flight before the first store
+        const uint4 *__restrict__ h4 = reinterpret_cast<const uint4 *>(h);  // rows are 48000 B apart: 16-byte aligned
+        uint4 *b4 = reinterpret_cast<uint4 *>(bins);
+        uint4 v[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int i = t + u * RG_PCT_THREADS;
+            v[u] = i < RG_HISTOGRAM_SIZE / 4 ? h4[i] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int i = t + u * RG_PCT_THREADS;
+            if (i < RG_PCT_THREADS * RG_PCT_CHUNK / 4) b4[i] = v[u];
+        }
+    }
+    __syncthreads();
+    const uint32_t *mine = bins + t * RG_PCT_CHUNK;
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < RG_PCT_CHUNK; ++i) s += mine[i];
+    // inclusive suffix sum over threads: suffix[t] = sum_{u >= t} chunk[u]
+    scan[t] = s;
+    __syncthreads();
+    for (int d = 1; d < RG_PCT_THREADS; d <<= 1) {
+        const uint64_t add = t + d < RG_PCT_THREADS ? scan[t + d] : 0;
+        __syncthreads();
+        scan[t] += add;
+        __syncthreads();
+    }
+    const uint64_t total = scan[0];
+    const uint64_t suffix = scan[t];
+    const uint64_t above = t + 1 < RG_PCT_THREADS ? scan[t + 1] : 0;  // count of all bins above this chunk
+    __shared__ RgLoudness res;  // one instance per kernel: the helper is called once per block
+    if (t == 0) {
+        res.loudness_db = -20.0;  // empty histogram, or the fall-through of src/replaygain.rs:681
+        res.total = total;
+    }
+    __syncthreads();
+    if (total != 0) {
+        const uint64_t threshold = (uint64_t)ceil((double)total * RG_ONE_MINUS_PERCENTILE);
+        if (suffix >= threshold && above < threshold) {  // exactly one thread
+            uint64_t count = above;
+            for (int i = RG_PCT_CHUNK - 1; i >= 0; --i) {
+                count += mine[i];
+                if (count >= threshold) {
+                    res.loudness_db = (double)(t * RG_PCT_CHUNK + i - RG_HISTOGRAM_OFFSET) / 100.0;
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    return res;
+}
+
+static __device__ __forceinline__ int32_t rg_round_steps(double gain_db) {
+    const double r = round(gain_db / RG_GAIN_STEP_DB);  // Rust f64::round: half away from zero
+    if (r != r) return 0;
+    if (r >= 2147483647.0) return 2147483647;
+    if (r <= -2147483648.0) return (int32_t)0x80000000;
+    return (int32_t)r;
+}
+
+
+static __device__ __forceinline__ void rg_store_track_result(rg_track_result *out, const RgLoudness &l, double peak,
+                                                             uint32_t sample_rate, uint32_t file_type) {
+    rg_track_result r;
+    r.loudness_db = l.loudness_db;
+    r.gain_db = RG_PINK_REF - l.loudness_db;
+    r.peak = peak;
+    r.sample_rate = sample_rate;
+    r.gain_steps = rg_round_steps(r.gain_db);
+    r.windows = (uint32_t)l.total;
+    r.file_type = file_type;
+    *out = r;
+}

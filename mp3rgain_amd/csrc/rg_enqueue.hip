@@ -25,9 +25,10 @@ hipError_t rg_launch_track_results(const uint32_t *, const unsigned long long *,
 hipError_t rg_launch_album_merge(const uint32_t *, const unsigned long long *, uint32_t, uint32_t *, double *,
                                  hipStream_t);
 hipError_t rg_launch_tm_main(int fmt, int nch, const RgTmCoef *, const RgTmGeom *, const RgTmTrack *, uint32_t, uint32_t,
-                             double *, uint32_t, hipStream_t);
+                             double *, uint32_t, uint32_t *, uint64_t, hipStream_t);
 hipError_t rg_launch_tm_fix(int nch, const RgTmGeom *, const RgTmFixTables *, const RgTmTrack *, uint32_t, uint32_t,
-                            const double *, uint32_t, uint32_t *, unsigned long long *, hipStream_t);
+                            const double *, uint32_t, uint32_t *, unsigned long long *, uint32_t *, rg_track_result *,
+                            hipStream_t);
 }
 
 namespace {
@@ -169,8 +170,9 @@ int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out) {
 // against how evenly the resulting waves fill 256 CUs x 4 SIMDs x 4 resident waves.
 //   cost(L)  = L*30 + min(L, H10)*10 + fixed          [VALU slots per lane]
 //   waves(L) = sum over tracks and channels of ceil(nseg / 256) * 4
-//   time(L)  ~ ceil(waves / 1024) * cost   when everything is resident at once (waves <= 4096),
+//   time(L)  ~ ceil(waves / 1024) * cost   when everything is resident at once (waves <= 3072),
 //              (waves / 1024 + 1) * cost   otherwise (many rounds, one extra for the ragged tail)
+// Consecutive batches overlap across the context's pipeline slots, so `waves` counts n_slots batches.
 int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, RgTmDeviceTables **out) {
     const uint32_t W = rg_window_samples(RG_RATE_TABLE[g.rate_idx].sample_rate);
     if (c->tune_tm_segment && W % c->tune_tm_segment == 0 &&
@@ -202,9 +204,18 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
             const uint64_t nseg = (tracks[id].frames + L - 1) / L;
             waves += (double)((nseg + RG_TM_BLOCK - 1) / RG_TM_BLOCK) * (RG_TM_BLOCK / 64) * g.nch;
         }
+        waves *= c->n_slots;
         const double cost = (double)L * 30.0 + (double)std::min(L, H10) * 10.0 + 1500.0;
-        const double rounds = waves <= 4096.0 ? ceil(waves / 1024.0) : waves / 1024.0 + 1.0;
-        const double tm = rounds * cost;
+        // residency: the LDS image of the response tables + one 4 KiB tile per wave bound the blocks per CU
+        const uint32_t Hl = std::min(H10, L & ~3u);
+        const double lds = ((double)Hl * 12 + (double)(L - Hl) * 2) * 8.0 + 4.0 * 4096.0;
+        const double blocks_cu = std::max(1.0, std::min(3.0, floor(160.0 * 1024.0 / lds)));
+        const double cap = 1024.0 * blocks_cu;
+        const double rounds = waves <= cap ? ceil(waves / 1024.0) : waves / 1024.0 + 1.0;
+        // FP64 issue efficiency by waves per SIMD (tools/ubench/frame.hip: 188 / 160 / 147 cycles per frame)
+        const double wps = std::min(blocks_cu, std::max(1.0, waves / 1024.0));
+        const double eff = wps >= 3.0 ? 1.0 : (wps >= 2.0 ? 1.09 + (3.0 - wps) * 0.0 : 1.28 - (wps - 1.0) * 0.19);
+        const double tm = rounds * cost * eff;
         if (tm < best) { best = tm; bestL = L; }
     }
     // walk outwards from the best candidate until one designs (tiny L can need too many scan rounds)
@@ -221,16 +232,17 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
 int timing_begin(rg_ctx *c, hipEvent_t *e1) {
     *e1 = nullptr;
     if (!c->timing) return RG_OK;
-    if (c->ev_used == c->ev_pool.size()) {
+    RgSlot &S = c->slot();
+    if (S.ev_used == S.ev_pool.size()) {
         hipEvent_t a, b;
         RG_HIP(c, hipEventCreate(&a));
         RG_HIP(c, hipEventCreate(&b));
-        c->ev_pool.emplace_back(a, b);
+        S.ev_pool.emplace_back(a, b);
     }
-    hipEvent_t e0 = c->ev_pool[c->ev_used].first;
-    *e1 = c->ev_pool[c->ev_used].second;
-    c->ev_used += 1;
-    RG_HIP(c, hipEventRecord(e0, c->stream));
+    hipEvent_t e0 = S.ev_pool[S.ev_used].first;
+    *e1 = S.ev_pool[S.ev_used].second;
+    S.ev_used += 1;
+    RG_HIP(c, hipEventRecord(e0, S.stream));
     return RG_OK;
 }
 
@@ -251,26 +263,34 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
     if (n > 0x7FFFFFFFull) return rg_set_err(c, RG_ERR_INVALID_ARG, "too many tracks");
     int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
-    hipStream_t s = c->stream;
     rc = validate(c, tracks, n, pcm_bytes);
     if (rc != RG_OK) return rc;
-
-    // the pinned staging buffers may still feed the previous batch's H2D copies
-    if (c->staging_pending) {
-        RG_HIP(c, hipEventSynchronize(c->staging_done));
-        c->staging_pending = false;
+    // next pipeline slot: its stream orders this batch behind the batch that used the slot before
+    c->cur = (c->cur + 1) % c->n_slots;
+    RgSlot &S = c->slot();
+    hipStream_t s = S.stream;
+    if (c->user_stream) {  // inputs produced on the caller's stream must be complete first
+        RG_HIP(c, hipEventRecord(c->user_ev, c->user_stream));
+        RG_HIP(c, hipStreamWaitEvent(s, c->user_ev, 0));
     }
 
-    RG_HIP(c, c->h_tracks.reserve(n));
-    RG_HIP(c, c->d_tracks.reserve(n));
-    RG_HIP(c, c->h_k1_tracks.reserve(n));
-    RG_HIP(c, c->d_k1_tracks.reserve(n));
-    RG_HIP(c, c->h_tm_tracks.reserve(n));
-    RG_HIP(c, c->d_tm_tracks.reserve(n));
-    RG_HIP(c, c->d_hist.reserve(n * (size_t)RG_HISTOGRAM_SIZE));
-    RG_HIP(c, c->d_peak_bits.reserve(n));
-    RG_HIP(c, c->d_results.reserve(n));
-    RG_HIP(c, c->h_results.reserve(n));
+    // the pinned staging buffers may still feed the previous batch's H2D copies
+    if (S.staging_pending) {
+        RG_HIP(c, hipEventSynchronize(S.staging_done));
+        S.staging_pending = false;
+    }
+
+    c->h_tracks.resize(n ? n : 1);
+    c->h_k1_tracks.resize(n ? n : 1);
+    c->h_tm_tracks.resize(n ? n : 1);
+    // histograms, peaks and per-track arrival counters share one allocation: [hist n*12000 | peak n*2 | done n]
+    // words, cleared together (by the first main kernel of the batch, or by one memset)
+    const size_t acc_words = n * (size_t)(RG_HISTOGRAM_SIZE + 3);
+    RG_HIP(c, S.d_hist.reserve(acc_words));
+    S.peak_ptr = reinterpret_cast<unsigned long long *>(S.d_hist.p + n * (size_t)RG_HISTOGRAM_SIZE);
+    uint32_t *const done_ptr = S.d_hist.p + n * (size_t)(RG_HISTOGRAM_SIZE + 2);
+    RG_HIP(c, S.d_results.reserve(n));
+    RG_HIP(c, S.h_results.reserve(n));
 
     const unsigned char *base = (const unsigned char *)d_pcm_base;
     const bool use_tm = c->kernel_variant != 1;
@@ -279,7 +299,7 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
     std::vector<TmGroup> groups;
     size_t n_k1 = 0;
     for (size_t t = 0; t < n; ++t) {
-        fill_common(c, tracks[t], base, (uint32_t)t, c->h_tracks.p[t]);
+        fill_common(c, tracks[t], base, (uint32_t)t, c->h_tracks[t]);
         const int ri = rg_rate_index(tracks[t].sample_rate);
         if (use_tm && c->design[ri].stable) {
             const int nch = tracks[t].channels >= 2 ? 2 : 1;
@@ -293,11 +313,11 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
             g->ids.push_back((uint32_t)t);
             g->frames += tracks[t].frames;
         } else {
-            c->h_k1_tracks.p[n_k1++] = c->h_tracks.p[t];
+            c->h_k1_tracks[n_k1++] = c->h_tracks[t];
         }
     }
     uint32_t k1_items = 0;
-    rc = finish_k1_list(c, c->h_k1_tracks.p, n_k1, &k1_items);
+    rc = finish_k1_list(c, c->h_k1_tracks.data(), n_k1, &k1_items);
     if (rc != RG_OK) return rc;
 
     // ---- variant 2 launch lists -----------------------------------------------------------------------
@@ -330,8 +350,8 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
         uint64_t recs = 0, mb = 0, fb = 0;
         const uint32_t NB = geo.fix_windows * geo.k;
         for (uint32_t id : g.ids) {
-            const RgTrackDev &cd = c->h_tracks.p[id];
-            RgTmTrack &o = c->h_tm_tracks.p[tm_off++];
+            const RgTrackDev &cd = c->h_tracks[id];
+            RgTmTrack &o = c->h_tm_tracks[tm_off++];
             o.ch0 = cd.ch0;
             o.ch1 = cd.ch1;
             o.frames = cd.frames;
@@ -341,6 +361,16 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
             o.main_block_base = (uint32_t)mb;
             o.fix_block_base = (uint32_t)fb;
             o.track_index = id;
+            o.fix_blocks = (o.nseg + NB - 1) / NB;
+            o.sample_rate = cd.sample_rate;
+            o.file_type = cd.file_type;
+            o.pad_ = 0;
+            if (o.fix_blocks == 0) {  // empty track: no block will finish it, the result kernel does
+                c->h_k1_tracks[n_k1] = cd;
+                c->h_k1_tracks[n_k1].n_segments = 0;
+                c->h_k1_tracks[n_k1].item_base = k1_items;
+                ++n_k1;
+            }
             recs += o.nseg;
             mb += (o.nseg + RG_TM_BLOCK - 1) / RG_TM_BLOCK;
             fb += (o.nseg + NB - 1) / NB;
@@ -353,46 +383,77 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
         max_rec_doubles = std::max(max_rec_doubles, (size_t)recs * RG_TM_REC * g.nch);
         launches.push_back(gl);
     }
-    RG_HIP(c, c->d_tm_rec.reserve(max_rec_doubles ? max_rec_doubles : 1));
+    RG_HIP(c, S.d_tm_rec.reserve(max_rec_doubles ? max_rec_doubles : 1));
 
-    c->n_enqueued = n;
-    c->album_ready = false;
+    S.n_enqueued = n;
+    S.album_ready = false;
+    const RgTrackDev *d_tracks = nullptr, *d_k1_tracks = nullptr;
+    const RgTmTrack *d_tm_tracks = nullptr;
     if (n) {
-        RG_HIP(c, hipMemcpyAsync(c->d_tracks.p, c->h_tracks.p, n * sizeof(RgTrackDev), hipMemcpyHostToDevice, s));
-        if (n_k1)
-            RG_HIP(c, hipMemcpyAsync(c->d_k1_tracks.p, c->h_k1_tracks.p, n_k1 * sizeof(RgTrackDev), hipMemcpyHostToDevice, s));
-        if (tm_off)
-            RG_HIP(c, hipMemcpyAsync(c->d_tm_tracks.p, c->h_tm_tracks.p, tm_off * sizeof(RgTmTrack), hipMemcpyHostToDevice, s));
-        RG_HIP(c, hipEventRecord(c->staging_done, s));
-        c->staging_pending = true;
-        RG_HIP(c, hipMemsetAsync(c->d_hist.p, 0, n * (size_t)RG_HISTOGRAM_SIZE * sizeof(uint32_t), s));
-        RG_HIP(c, hipMemsetAsync(c->d_peak_bits.p, 0, n * sizeof(unsigned long long), s));
+        // ---- one descriptor blob, one H2D copy (skipped when the blob is what the device already holds) ----
+        const size_t o_all = 0;
+        const size_t o_k1 = (o_all + n * sizeof(RgTrackDev) + 15) & ~(size_t)15;
+        const size_t o_tm = (o_k1 + n_k1 * sizeof(RgTrackDev) + 15) & ~(size_t)15;
+        const size_t blob_bytes = o_tm + tm_off * sizeof(RgTmTrack);
+        const unsigned char *old_dev = S.d_desc.p;
+        RG_HIP(c, S.d_desc.reserve(blob_bytes));
+        RG_HIP(c, S.h_desc.reserve(blob_bytes));
+        if (S.d_desc.p != old_dev) S.desc_shadow.clear();
+        std::vector<unsigned char> blob(blob_bytes, 0);
+        memcpy(&blob[o_all], c->h_tracks.data(), n * sizeof(RgTrackDev));
+        if (n_k1) memcpy(&blob[o_k1], c->h_k1_tracks.data(), n_k1 * sizeof(RgTrackDev));
+        if (tm_off) memcpy(&blob[o_tm], c->h_tm_tracks.data(), tm_off * sizeof(RgTmTrack));
+        if (blob != S.desc_shadow) {
+            memcpy(S.h_desc.p, blob.data(), blob_bytes);
+            RG_HIP(c, hipMemcpyAsync(S.d_desc.p, S.h_desc.p, blob_bytes, hipMemcpyHostToDevice, s));
+            RG_HIP(c, hipEventRecord(S.staging_done, s));
+            S.staging_pending = true;
+            S.desc_shadow.swap(blob);
+        }
+        d_tracks = reinterpret_cast<const RgTrackDev *>(S.d_desc.p + o_all);
+        (void)d_tracks;
+        d_k1_tracks = reinterpret_cast<const RgTrackDev *>(S.d_desc.p + o_k1);
+        d_tm_tracks = reinterpret_cast<const RgTmTrack *>(S.d_desc.p + o_tm);
+        bool cleared = false;
+        bool any_main = false;
+        for (const GroupLaunch &gl : launches) any_main = any_main || gl.main_grid != 0;
+        if (!any_main) {
+            RG_HIP(c, hipMemsetAsync(S.d_hist.p, 0, acc_words * sizeof(uint32_t), s));
+            cleared = true;
+        }
 
         for (const GroupLaunch &gl : launches) {
             hipEvent_t e1;
             rc = timing_begin(c, &e1);
             if (rc != RG_OK) return rc;
-            RG_HIP(c, rg_launch_tm_main(gl.fmt, gl.nch, &gl.K, &gl.tb->geom, c->d_tm_tracks.p + gl.list_off,
-                                        (uint32_t)gl.list_n, gl.main_grid, c->d_tm_rec.p, gl.total_recs, s));
+            RG_HIP(c, rg_launch_tm_main(gl.fmt, gl.nch, &gl.K, &gl.tb->geom, d_tm_tracks + gl.list_off,
+                                        (uint32_t)gl.list_n, gl.main_grid, S.d_tm_rec.p, gl.total_recs,
+                                        cleared ? nullptr : S.d_hist.p, (uint64_t)acc_words, s));
+            if (gl.main_grid != 0) cleared = true;
             if (e1) RG_HIP(c, hipEventRecord(e1, s));
-            RG_HIP(c, rg_launch_tm_fix(gl.nch, &gl.tb->geom, &gl.tb->fix, c->d_tm_tracks.p + gl.list_off,
-                                       (uint32_t)gl.list_n, gl.fix_grid, c->d_tm_rec.p, gl.total_recs, c->d_hist.p,
-                                       c->d_peak_bits.p, s));
+            RG_HIP(c, rg_launch_tm_fix(gl.nch, &gl.tb->geom, &gl.tb->fix, d_tm_tracks + gl.list_off,
+                                       (uint32_t)gl.list_n, gl.fix_grid, S.d_tm_rec.p, gl.total_recs, S.d_hist.p,
+                                       S.peak_ptr, done_ptr, S.d_results.p, s));
         }
         if (n_k1) {
             hipEvent_t e1;
             rc = timing_begin(c, &e1);
             if (rc != RG_OK) return rc;
-            RG_HIP(c, rg_launch_k1_halo(c->d_k1_tracks.p, (uint32_t)n_k1, k1_items, c->d_coefs.p, c->d_hist.p,
-                                        c->d_peak_bits.p, s));
+            RG_HIP(c, rg_launch_k1_halo(d_k1_tracks, (uint32_t)n_k1, k1_items, c->d_coefs.p, S.d_hist.p,
+                                        S.peak_ptr, s));
             if (e1) RG_HIP(c, hipEventRecord(e1, s));
         }
-        RG_HIP(c, rg_launch_track_results(c->d_hist.p, c->d_peak_bits.p, c->d_tracks.p, c->d_results.p, (uint32_t)n, s));
+        // tracks the fix-up kernel did not finish: variant 1's, and empty ones
+        RG_HIP(c, rg_launch_track_results(S.d_hist.p, S.peak_ptr, d_k1_tracks, S.d_results.p, (uint32_t)n_k1, s));
     }
     if (album) {
-        RG_HIP(c, rg_launch_album_merge(c->d_hist.p, c->d_peak_bits.p, (uint32_t)n, c->d_album_hist.p,
-                                        c->d_album_peak.p, s));
-        c->album_ready = true;
+        RG_HIP(c, rg_launch_album_merge(S.d_hist.p, S.peak_ptr, (uint32_t)n, S.d_album_hist.p,
+                                        S.d_album_peak.p, s));
+        S.album_ready = true;
+        if (c->user_stream) {  // the caller's collective (on its own stream) follows the merge
+            RG_HIP(c, hipEventRecord(S.batch_done, s));
+            RG_HIP(c, hipStreamWaitEvent(c->user_stream, S.batch_done, 0));
+        }
     }
     return RG_OK;
 }

@@ -127,36 +127,75 @@ __device__ __forceinline__ uint32_t find_track(const RgTmTrack *__restrict__ tra
 
 typedef float __attribute__((ext_vector_type(4), aligned(4))) rg_f32x4u;  // 16-byte load, 4-byte aligned
 
-// moments of one piece of 4 frames; MASK: frames at or past `len` do not count (tail of a track)
+// One frame of one lane: cascade step + moments.  NX = live transient moments (12, or only the slow
+// pair); MASK: frames at or past `len` do not count (tail of a track).
+//
+// The FP64 FMA pipe takes a new wave instruction every 4 cycles but a dependent one only after ~8, and
+// a lone wave (short batches leave a SIMD one or two waves) has nothing else to issue.  The frame is
+// therefore written as four groups inside which every instruction is independent, fenced with
+// sched_barrier so that hipcc keeps them apart (left alone it pairs each u_i with the s_i that
+// consumes it, which is a dependent chain of 2 x 10 instructions):
+//   G1  y,  u_i = b_{i+1} x + s_{i+1}                      (10 + 1, need x and the old state)
+//   G2  z,  w_1 = bb_1 y + t_1,  w_2 = bb_2 y + c          (need y, issued 10 slots earlier)
+//   G3  s_i = u_i - a_{i+1} y                              (10, need y and u_i)
+//   G4  t_0, t_1, A, B_j                                   (need z, issued 10 slots earlier)
 template <int NX, bool MASK>
-__device__ __forceinline__ void tm_piece_lds(TmLane<1> &st, const float4 v, float &pk, const double *__restrict__ Trow,
-                                             const RgTmCoef &K, const uint32_t n, const uint32_t len) {
-    const float f[4] = {v.x, v.y, v.z, v.w};
+__device__ __forceinline__ void tm_frame(TmLane<1> &st, const float f, float &pk, const double (&tr)[NX],
+                                         const RgTmCoef &K, const uint32_t n, const uint32_t len) {
+    double (&s)[10] = st.s[0];
+    double (&t)[2] = st.t[0];
+    pk = fmaxf(pk, fabsf(f));  // frames past the end were staged as zeros
+    const double x = (double)f;
+    const double y = fma(K.b[0], x, s[0]);
+    double u[10];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        pk = fmaxf(pk, fabsf(f[u]));  // frames past the end were staged as zeros
-        double z = tm_step(st.s[0], st.t[0], (double)f[u], K);
-        if (MASK) z = n + u < len ? z : 0.0;
-        st.A[0] = fma(z, z, st.A[0]);
-        if (NX == 12) {
+    for (int i = 0; i < 9; ++i) u[i] = fma(K.b[i + 1], x, s[i + 1]);
+    u[9] = fma(K.b[10], x, K.c0);
+    __builtin_amdgcn_sched_barrier(0);
+    double z = fma(K.bb[0], y, t[0]);
+    const double w1 = fma(K.bb[1], y, t[1]);
+    const double w2 = fma(K.bb[2], y, K.c0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 12; ++j) st.B[0][j] = fma(z, Trow[u * 12 + j], st.B[0][j]);
-        } else {
-            st.B[0][10] = fma(z, Trow[u * 2 + 0], st.B[0][10]);
-            st.B[0][11] = fma(z, Trow[u * 2 + 1], st.B[0][11]);
-        }
+    for (int i = 0; i < 10; ++i) s[i] = fma(-K.a[i + 1], y, u[i]);
+    __builtin_amdgcn_sched_barrier(0);
+    t[0] = fma(-K.ba[1], z, w1);
+    t[1] = fma(-K.ba[2], z, w2);
+    if (MASK) z = n < len ? z : 0.0;
+    st.A[0] = fma(z, z, st.A[0]);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) st.B[0][RG_TM_DIM - NX + j] = fma(z, tr[j], st.B[0][RG_TM_DIM - NX + j]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NX>
+__device__ __forceinline__ void tm_load_row(double (&dst)[NX], const double *__restrict__ src) {
+#if defined(RG_EXP) && RG_EXP >= 3
+#pragma unroll
+    for (int j = 0; j < NX; ++j) dst[j] = 1e-3 * j + (double)(size_t)src * 1e-30;
+    return;
+#endif
+#pragma unroll
+    for (int j = 0; j < NX; j += 2) {
+        const double2 v = *reinterpret_cast<const double2 *>(src + j);  // 16-byte aligned broadcast read
+        dst[j] = v.x;
+        dst[j + 1] = v.y;
     }
 }
 
 // The F32 fast path of one wave.  TAIL = some row of this wave is shorter than L (the end of the
 // track): short rows are staged zero-filled, element by element where a 16-byte piece would cross the
 // end of the channel, and their moments are masked.
+//
+// Per wave, no block barrier: the global loads of tile t+1 are issued when tile t has just been
+// written to the wave's LDS tile and stay in flight during tile t's arithmetic; inside a tile the
+// next 4-frame piece is read from LDS while the current one computes.
 template <bool TAIL>
 __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, float &pk, const RgTmCoef &K, const uint32_t L,
                                              const uint32_t H, const __attribute__((address_space(1))) float *chp,
                                              const uint64_t frames, const uint32_t wave_seg0, const uint32_t len,
                                              const double *__restrict__ T12, const double *__restrict__ T2,
-                                             char *const wtile) {
+                                             char *const wtile /* RG_TM_WAVE_TILE_BYTES */) {
     typedef const __attribute__((address_space(1))) float gfloat;
     const int lane = threadIdx.x & 63;
     // loader role: instruction q covers rows 16q .. 16q+15; this lane fetches for row 16q + (lane >> 2)
@@ -186,7 +225,9 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, float &pk, const RgT
             const int piece = lslot ^ ((row >> 2) & 3);
             const uint32_t pn = n0 + 4u * piece;  // frame index of the piece within its row
             if (!TAIL) {
-                if (pn < L) stage[q] = *(const __attribute__((address_space(1))) rg_f32x4u *)(chp + lfirst[q] + n0);
+                // pieces starting past the row's end are never read; only the last tile can have such pieces
+                if (n0 + RG_TM_TILE <= L || pn < L)
+                    stage[q] = *(const __attribute__((address_space(1))) rg_f32x4u *)(chp + lfirst[q] + n0);
             } else {
                 gfloat *src = chp + lfirst[q] + n0;
                 if (pn + 4u <= llen[q]) {
@@ -201,43 +242,59 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, float &pk, const RgT
         }
     };
     auto store_tile = [&]() {
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4 *>(wtile + q * 1024 + lane * 16) =
-                make_float4(stage[q].x, stage[q].y, stage[q].z, stage[q].w);
+            *reinterpret_cast<float4 *>(wtile + q * 1024 + lane * 16) = make_float4(stage[q].x, stage[q].y, stage[q].z, stage[q].w);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     };
+    auto read_piece = [&](int p) -> float4 { return *reinterpret_cast<const float4 *>(rrow + 16 * (p ^ rswz)); };
 
     load_tile(0);
     for (uint32_t tile = 0; tile < ntiles; ++tile) {
-        __builtin_amdgcn_wave_barrier();
-        store_tile();  // tile `tile` -> LDS (all reads of the previous tile are behind us)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        store_tile();                                // tile `tile` -> LDS (every read of the previous tile is behind us)
         if (tile + 1 < ntiles) load_tile(tile + 1);  // in flight during this tile's arithmetic
         const uint32_t n0 = tile * RG_TM_TILE;
+        const int np = L - n0 >= RG_TM_TILE ? 4 : (int)((L - n0) >> 2);  // full 4-frame pieces in this tile
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (np) v = read_piece(0);
 #pragma unroll 1
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < np; ++p) {
+            const float4 vn = p + 1 < np ? read_piece(p + 1) : v;
+            const float f[4] = {v.x, v.y, v.z, v.w};
             const uint32_t n = n0 + 4u * p;
-            if (n + 4u > L) break;
-            const float4 v = *reinterpret_cast<const float4 *>(rrow + 16 * (p ^ rswz));
-            if (n < H) tm_piece_lds<12, TAIL>(st, v, pk, T12 + (size_t)n * 12, K, n, len);
-            else tm_piece_lds<2, TAIL>(st, v, pk, T2 + (size_t)(n - H) * 2, K, n, len);
+            if (n < H) {  // all 12 transient moments live (H is a multiple of 4)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    double row[12];
+                    tm_load_row<12>(row, T12 + (size_t)(n + u) * 12);
+                    tm_frame<12, TAIL>(st, f[u], pk, row, K, n + u, len);
+                }
+            } else {  // only the slow (Butterworth) pair
+                double rows[8];
+                tm_load_row<4>(reinterpret_cast<double (&)[4]>(rows[0]), T2 + (size_t)(n - H) * 2);
+                tm_load_row<4>(reinterpret_cast<double (&)[4]>(rows[4]), T2 + (size_t)(n - H) * 2 + 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double tr[2] = {rows[2 * u], rows[2 * u + 1]};
+                    tm_frame<2, TAIL>(st, f[u], pk, tr, K, n + u, len);
+                }
+            }
+            v = vn;
         }
         if (tile + 1 == ntiles) {
-            // L mod 4 trailing frames, still in this tile
+            // L & 3 trailing frames, in this (the last) tile
             for (uint32_t n = L & ~3u; n < L; ++n) {
                 const uint32_t o = n - n0;
-                const float f = *reinterpret_cast<const float *>(rrow + 16 * ((o >> 2) ^ rswz) + 4 * (o & 3));
-                pk = fmaxf(pk, fabsf(f));
-                double z = tm_step(st.s[0], st.t[0], (double)f, K);
-                if (TAIL) z = n < len ? z : 0.0;
-                st.A[0] = fma(z, z, st.A[0]);
+                const float f = *reinterpret_cast<const float *>(rrow + 16 * ((int)(o >> 2) ^ rswz) + 4 * (o & 3));
                 if (n < H) {
-#pragma unroll
-                    for (int j = 0; j < 12; ++j) st.B[0][j] = fma(z, T12[(size_t)n * 12 + j], st.B[0][j]);
+                    double row[12];
+                    tm_load_row<12>(row, T12 + (size_t)n * 12);
+                    tm_frame<12, TAIL>(st, f, pk, row, K, n, len);
                 } else {
-                    st.B[0][10] = fma(z, T2[(size_t)(n - H) * 2 + 0], st.B[0][10]);
-                    st.B[0][11] = fma(z, T2[(size_t)(n - H) * 2 + 1], st.B[0][11]);
+                    const double tr[2] = {T2[(size_t)(n - H) * 2], T2[(size_t)(n - H) * 2 + 1]};
+                    tm_frame<2, TAIL>(st, f, pk, tr, K, n, len);
                 }
             }
         }
@@ -248,6 +305,7 @@ template <int FMT>
 __global__ void __launch_bounds__(RG_TM_BLOCK)
 rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restrict__ tracks, uint32_t n_tracks,
                   double *__restrict__ rec, uint32_t total_recs, uint32_t lds_tables,
+                  uint32_t *__restrict__ zero_words, uint64_t zero_count /* batch accumulators to clear, or nullptr */,
                   unsigned long long *__restrict__ dbg /* nullptr, or 4 words per wave: start, end, hw id, path */) {
     typedef Fmt<FMT> F;
     const unsigned long long dbg_t0 = dbg ? wall_clock64() : 0ull;
@@ -255,6 +313,13 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
     typedef __attribute__((address_space(1))) const elem gelem;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    // the batch's histograms, peaks and arrival counters are cleared here instead of by a memset of
+    // their own: nothing in this kernel reads them, and everything that does is behind it in the stream
+    if (zero_words) {
+        const uint64_t stride = (uint64_t)gridDim.x * gridDim.y * RG_TM_BLOCK;
+        for (uint64_t w = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * RG_TM_BLOCK + threadIdx.x; w < zero_count; w += stride)
+            zero_words[w] = 0u;
+    }
     const uint32_t t = find_track(tracks, n_tracks, blockIdx.x, &RgTmTrack::main_block_base);
     const RgTmTrack tr = tracks[t];
     const int chan = blockIdx.y;
@@ -290,15 +355,15 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
                 const double2 *__restrict__ src = reinterpret_cast<const double2 *>(G.Tlds);
                 double2 *dst = reinterpret_cast<double2 *>(smem);
                 const uint32_t n16 = tbl_doubles / 2;
-                for (uint32_t i = threadIdx.x; i < n16; i += 4 * RG_TM_BLOCK) {
-                    double2 v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (i + u * RG_TM_BLOCK < n16) v[u] = src[i + u * RG_TM_BLOCK];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (i + u * RG_TM_BLOCK < n16) dst[i + u * RG_TM_BLOCK] = v[u];
+                uint32_t i = threadIdx.x;
+                for (; i + 3 * RG_TM_BLOCK < n16; i += 4 * RG_TM_BLOCK) {  // four loads in flight per thread
+                    const double2 a = src[i], b = src[i + RG_TM_BLOCK], c = src[i + 2 * RG_TM_BLOCK], d = src[i + 3 * RG_TM_BLOCK];
+                    dst[i] = a;
+                    dst[i + RG_TM_BLOCK] = b;
+                    dst[i + 2 * RG_TM_BLOCK] = c;
+                    dst[i + 3 * RG_TM_BLOCK] = d;
                 }
+                for (; i < n16; i += RG_TM_BLOCK) dst[i] = src[i];
                 __syncthreads();
             }
             const double *const T12 = reinterpret_cast<const double *>(smem);
@@ -356,14 +421,38 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
 }
 
 // =================================================================================================
+// Fix-up kernel.  One lane = one segment (all channels).  Lanes [0, warm) of a block repeat the last
+// `warm` segments of the previous block so that every owner lane finds its 2^R predecessors in LDS.
+
+// sigma' G sigma for the packed upper triangle G (row major), evaluated as sum_j s_j (G_jj s_j / 2 + sum_{q>j} G_jq s_q) * 2
+template <typename GP>
+__device__ __forceinline__ double tm_quad_half(GP Gm, const double (&sg)[RG_TM_DIM]) {
+    double quad = 0.0;
+    int p = 0;
+#pragma unroll
+    for (int j = 0; j < RG_TM_DIM; ++j) {
+        double row = 0.5 * Gm[p] * sg[j];
+        ++p;
+#pragma unroll
+        for (int q = j + 1; q < RG_TM_DIM; ++q, ++p) row = fma(Gm[p], sg[q], row);
+        quad = fma(row, sg[j], quad);
+    }
+    return quad;
+}
+
 template <int NCH>
 __global__ void __launch_bounds__(RG_TM_BLOCK)
 rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__restrict__ tracks, uint32_t n_tracks,
                  const double *__restrict__ rec, uint32_t total_recs, uint32_t *__restrict__ hist,
-                 unsigned long long *__restrict__ peak_bits) {
-    __shared__ double wx[RG_TM_DIM][RG_TM_BLOCK];
+                 unsigned long long *__restrict__ peak_bits, uint32_t *__restrict__ done_count,
+                 rg_track_result *__restrict__ results) {
+    // LDS: the scan exchange buffer is reused as the histogram staging area of the percentile epilogue
+    __shared__ __attribute__((aligned(16))) char lds_raw[2 * RG_TM_DIM * RG_TM_BLOCK * sizeof(double)];  // 48 KiB >= 12032 * 4
+    __shared__ uint64_t pct_scan[RG_PCT_THREADS];
     __shared__ double pieces[RG_TM_BLOCK];
     __shared__ int bins[RG_TM_BLOCK];
+    __shared__ int is_last;
+    double (*wx)[RG_TM_DIM][RG_TM_BLOCK] = reinterpret_cast<double (*)[RG_TM_DIM][RG_TM_BLOCK]>(lds_raw);
 
     const uint32_t t = find_track(tracks, n_tracks, blockIdx.x, &RgTmTrack::fix_block_base);
     const RgTmTrack tr = tracks[t];
@@ -376,82 +465,97 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     const bool seg_valid = in_block && seg >= 0 && seg < (long long)tr.nseg;
     const bool owner = seg_valid && i >= warm;
     const size_t idx = (size_t)tr.rec_base + (size_t)(seg_valid ? seg : 0);
+    rg_cdouble *const X = (rg_cdouble *)FT.X;
+    rg_cdouble *const S0 = (rg_cdouble *)FT.sigma0;
 
-    double S = 0.0;
-    double pk = 0.0;
-#pragma unroll 1
+    // ---- everything this lane needs from the segment records, issued up front ------------------------
+    double w[NCH][RG_TM_DIM], Bm[NCH][RG_TM_DIM], Am[NCH], pk = 0.0;
+#pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const double *__restrict__ r = rec + (size_t)c * RG_TM_REC * total_recs + idx;
+#pragma unroll
+        for (int j = 0; j < RG_TM_DIM; ++j) w[c][j] = seg_valid ? r[(size_t)(13 + j) * total_recs] : 0.0;
+#pragma unroll
+        for (int j = 0; j < RG_TM_DIM; ++j) Bm[c][j] = owner ? r[(size_t)(1 + j) * total_recs] : 0.0;
+        Am[c] = owner ? r[0] : 0.0;
         if (owner) pk = fmax(pk, r[(size_t)25 * total_recs]);
-        // zero-state end state of this segment in block-diagonal coordinates: t' = t + X s
-        double w[RG_TM_DIM];
-        if (seg_valid) {
+    }
+    // zero-state end state in block-diagonal coordinates: t' = t + X s; virtual segment -1 carries the
+    // track-start state
+    const bool vstart = in_block && seg == -1;
 #pragma unroll
-            for (int j = 0; j < RG_TM_DIM; ++j) w[j] = r[(size_t)(13 + j) * total_recs];
+    for (int c = 0; c < NCH; ++c) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                double acc = w[10 + q];
+        for (int q = 0; q < 2; ++q) {
+            double acc = w[c][10 + q];
 #pragma unroll
-                for (int j = 0; j < 10; ++j) acc = fma(FT.X[q * 10 + j], w[j], acc);
-                w[10 + q] = acc;
-            }
-        } else {
-            const bool start = in_block && seg == -1;  // virtual segment -1 carries the track-start state
-#pragma unroll
-            for (int j = 0; j < RG_TM_DIM; ++j) w[j] = start ? FT.sigma0[j] : 0.0;
+            for (int j = 0; j < 10; ++j) acc = fma(X[q * 10 + j], w[c][j], acc);
+            w[c][10 + q] = acc;
         }
-        // doubling scan: after round r, w_k = sum_{q < 2^(r+1)} Phi^q e_{k-q}
-        for (uint32_t rd = 0; rd < G.rounds; ++rd) {
-            const int d = 1 << rd;
+        if (vstart) {
 #pragma unroll
-            for (int j = 0; j < RG_TM_DIM; ++j) wx[j][i] = w[j];
-            __syncthreads();
-            double wn[RG_TM_DIM];
+            for (int j = 0; j < RG_TM_DIM; ++j) w[c][j] = S0[j];
+        }
+    }
+    // ---- doubling scan: after round r, w_k = sum_{q < 2^(r+1)} Phi^q e_{k-q} ------------------------------
+    for (uint32_t rd = 0; rd < G.rounds; ++rd) {
+        const int d = 1 << rd;
 #pragma unroll
-            for (int j = 0; j < RG_TM_DIM; ++j) wn[j] = i >= d ? wx[j][i - d] : 0.0;
-            __syncthreads();
-            if (rd < G.rounds_fast) {
-                const double *__restrict__ PY = FT.PhiY + (size_t)rd * 100;
+        for (int c = 0; c < NCH; ++c)
 #pragma unroll
-                for (int a = 0; a < 10; ++a) {
-                    double acc = w[a];
+            for (int j = 0; j < RG_TM_DIM; ++j) wx[c][j][i] = w[c][j];
+        __syncthreads();
+        double wn[NCH][RG_TM_DIM];
 #pragma unroll
-                    for (int q = 0; q < 10; ++q) acc = fma(PY[a * 10 + q], wn[q], acc);
-                    w[a] = acc;
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int j = 0; j < RG_TM_DIM; ++j) wn[c][j] = i >= d ? wx[c][j][i - d] : 0.0;
+        __syncthreads();
+        if (rd < G.rounds_fast) {
+            rg_cdouble *__restrict__ PY = (rg_cdouble *)FT.PhiY + (size_t)rd * 100;
+#pragma unroll
+            for (int a = 0; a < 10; ++a) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    double acc = w[c][a];
+#pragma unroll
+                    for (int q = 0; q < 10; ++q) acc = fma(PY[a * 10 + q], wn[c][q], acc);
+                    w[c][a] = acc;
                 }
             }
-            const double *__restrict__ PB = FT.PhiB + (size_t)rd * 4;
-            w[10] = fma(PB[0], wn[10], fma(PB[1], wn[11], w[10]));
-            w[11] = fma(PB[2], wn[10], fma(PB[3], wn[11], w[11]));
         }
-        // the true start state of segment k is the scanned end state of segment k-1
+        rg_cdouble *__restrict__ PB = (rg_cdouble *)FT.PhiB + (size_t)rd * 4;
 #pragma unroll
-        for (int j = 0; j < RG_TM_DIM; ++j) wx[j][i] = w[j];
-        __syncthreads();
-        double sg[RG_TM_DIM];
+        for (int c = 0; c < NCH; ++c) {
+            w[c][10] = fma(PB[0], wn[c][10], fma(PB[1], wn[c][11], w[c][10]));
+            w[c][11] = fma(PB[2], wn[c][10], fma(PB[3], wn[c][11], w[c][11]));
+        }
+    }
+    // the true start state of segment k is the scanned end state of segment k-1
 #pragma unroll
-        for (int j = 0; j < RG_TM_DIM; ++j) sg[j] = i >= 1 ? wx[j][i - 1] : 0.0;
-        __syncthreads();
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < RG_TM_DIM; ++j) wx[c][j][i] = w[c][j];
+    __syncthreads();
 
-        if (owner) {
-            const uint64_t start = (uint64_t)seg * G.L;
-            const uint64_t rem = tr.frames - start;
-            const uint32_t len = rem < G.L ? (uint32_t)rem : G.L;
-            const double *__restrict__ Gm = FT.Gp + (size_t)(len - 1) * RG_TM_GRAM;
+    double S = 0.0;
+    if (owner) {
+        const uint64_t start = (uint64_t)seg * G.L;
+        const uint64_t rem = tr.frames - start;
+        const uint32_t len = rem < G.L ? (uint32_t)rem : G.L;
+        const bool full = len == G.L;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            double sg[RG_TM_DIM];
+#pragma unroll
+            for (int j = 0; j < RG_TM_DIM; ++j) sg[j] = wx[c][j][i - 1];  // owner => i >= warm >= 1
             double lin = 0.0;
 #pragma unroll
-            for (int j = 0; j < RG_TM_DIM; ++j) lin = fma(r[(size_t)(1 + j) * total_recs], sg[j], lin);
-            double quad = 0.0;
-            int p = 0;
-#pragma unroll
-            for (int j = 0; j < RG_TM_DIM; ++j) {
-                double row = 0.5 * Gm[p] * sg[j];
-                ++p;
-#pragma unroll
-                for (int q = j + 1; q < RG_TM_DIM; ++q, ++p) row = fma(Gm[p], sg[q], row);
-                quad = fma(row, sg[j], quad);
-            }
-            S += r[0] + 2.0 * (lin + quad);
+            for (int j = 0; j < RG_TM_DIM; ++j) lin = fma(Bm[c][j], sg[j], lin);
+            double quad;
+            if (full) quad = tm_quad_half((rg_cdouble *)FT.Gp + (size_t)(G.L - 1) * RG_TM_GRAM, sg);  // wave-uniform table
+            else quad = tm_quad_half(FT.Gp + (size_t)(len - 1) * RG_TM_GRAM, sg);
+            S += Am[c] + 2.0 * (lin + quad);
         }
     }
     if (NCH == 1) S *= 2.0;  // add_mono_sample feeds both sums (src/replaygain.rs:731-740)
@@ -494,6 +598,24 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
             atomicAdd(&hist[(size_t)tr.track_index * RG_HISTOGRAM_SIZE + bin], count);
         }
     }
+
+    // ---- the last block of a track to get here finishes the track: percentile, gain, peak -> result
+    // (tail of analyze_track_internal, src/replaygain.rs:910-918).  Release: every thread's atomics are
+    // device-visible before the arrival counter moves; acquire: the finisher drops stale lines first.
+    __threadfence();
+    __syncthreads();
+    if (i == 0) is_last = atomicAdd(&done_count[tr.track_index], 1u) + 1u == tr.fix_blocks ? 1 : 0;
+    __syncthreads();
+    if (is_last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const RgLoudness l = rg_block_loudness(hist + (size_t)tr.track_index * RG_HISTOGRAM_SIZE,
+                                               reinterpret_cast<uint32_t *>(lds_raw), pct_scan);
+        if (i == 0) {
+            const unsigned long long pb = atomicMax(&peak_bits[tr.track_index], 0ull);  // coherent read
+            rg_store_track_result(results + tr.track_index, l, __longlong_as_double((long long)pb), tr.sample_rate,
+                                  tr.file_type);
+        }
+    }
 }
 
 // =================================================================================================
@@ -503,42 +625,44 @@ extern "C" void rg_tm_set_debug_buffer(unsigned long long *d_buf) { g_tm_debug =
 
 template <int FMT>
 static hipError_t launch_main_fmt(int nch, const RgTmCoef &K, const RgTmGeom &G, const RgTmTrack *d_tracks,
-                                  uint32_t n_tracks, uint32_t grid, double *d_rec, uint32_t total_recs, hipStream_t s) {
+                                  uint32_t n_tracks, uint32_t grid, double *d_rec, uint32_t total_recs,
+                                  uint32_t *d_zero, uint64_t zero_count, hipStream_t s) {
     // LDS: T12 (H10 x 12 doubles) + T2 ((L - H10) x 2 doubles) + one 4 KiB PCM tile per wave
     size_t lds = ((size_t)G.H10 * 12 + (size_t)(G.L - G.H10) * 2) * sizeof(double) +
                  (size_t)(RG_TM_BLOCK / 64) * RG_TM_WAVE_TILE_BYTES;
-    uint32_t lds_tables = FMT == RG_FMT_F32_PLANAR && lds <= 80 * 1024 ? 1u : 0u;
+    uint32_t lds_tables = FMT == RG_FMT_F32_PLANAR && lds <= 96 * 1024 ? 1u : 0u;
     if (!lds_tables) lds = 0;
     static bool attr_set = false;
     if (lds > 48 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void *)rg_tm_main_kernel<FMT>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void *)rg_tm_main_kernel<FMT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_set = true;
     }
     hipLaunchKernelGGL((rg_tm_main_kernel<FMT>), dim3(grid, nch), dim3(RG_TM_BLOCK), lds, s, K, G, d_tracks, n_tracks,
-                       d_rec, total_recs, lds_tables, g_tm_debug);
+                       d_rec, total_recs, lds_tables, d_zero, zero_count, g_tm_debug);
     return hipGetLastError();
 }
 
 extern "C" hipError_t rg_launch_tm_main(int fmt, int nch, const RgTmCoef *K, const RgTmGeom *G,
                                         const RgTmTrack *d_tracks, uint32_t n_tracks, uint32_t grid, double *d_rec,
-                                        uint32_t total_recs, hipStream_t s) {
+                                        uint32_t total_recs, uint32_t *d_zero, uint64_t zero_count, hipStream_t s) {
     if (grid == 0) return hipSuccess;
     switch (fmt) {
-        case RG_FMT_F32_PLANAR: return launch_main_fmt<RG_FMT_F32_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, s);
-        case RG_FMT_S16_PLANAR: return launch_main_fmt<RG_FMT_S16_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, s);
-        default: return launch_main_fmt<RG_FMT_S32_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, s);
+        case RG_FMT_F32_PLANAR: return launch_main_fmt<RG_FMT_F32_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_zero, zero_count, s);
+        case RG_FMT_S16_PLANAR: return launch_main_fmt<RG_FMT_S16_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_zero, zero_count, s);
+        default: return launch_main_fmt<RG_FMT_S32_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_zero, zero_count, s);
     }
 }
 
 extern "C" hipError_t rg_launch_tm_fix(int nch, const RgTmGeom *G, const RgTmFixTables *FT, const RgTmTrack *d_tracks,
                                        uint32_t n_tracks, uint32_t grid, const double *d_rec, uint32_t total_recs,
-                                       uint32_t *d_hist, unsigned long long *d_peak_bits, hipStream_t s) {
+                                       uint32_t *d_hist, unsigned long long *d_peak_bits, uint32_t *d_done,
+                                       rg_track_result *d_results, hipStream_t s) {
     if (grid == 0) return hipSuccess;
     if (nch == 1)
         hipLaunchKernelGGL((rg_tm_fix_kernel<1>), dim3(grid), dim3(RG_TM_BLOCK), 0, s, *G, *FT, d_tracks, n_tracks, d_rec,
-                           total_recs, d_hist, d_peak_bits);
+                           total_recs, d_hist, d_peak_bits, d_done, d_results);
     else
         hipLaunchKernelGGL((rg_tm_fix_kernel<2>), dim3(grid), dim3(RG_TM_BLOCK), 0, s, *G, *FT, d_tracks, n_tracks, d_rec,
-                           total_recs, d_hist, d_peak_bits);
+                           total_recs, d_hist, d_peak_bits, d_done, d_results);
     return hipGetLastError();
 }

@@ -48,6 +48,10 @@ struct RgTmTrack {
     uint32_t main_block_base;  // first block of this track in the main kernel's grid
     uint32_t fix_block_base;   // first block of this track in the fix-up kernel's grid
     uint32_t track_index;      // row in the histogram / peak arrays
+    uint32_t fix_blocks;       // number of fix-up blocks of this track (the last one to finish writes the result)
+    uint32_t sample_rate;
+    uint32_t file_type;
+    uint32_t pad_;
 };
 
 // launch-group geometry (passed by value)
