@@ -56,7 +56,7 @@ def main() -> int:
     ap.add_argument("--minutes", type=float, default=10.0, help="track length (default: BASELINE's 10 min)")
     ap.add_argument("--tm-segment", type=int, default=0, help="force variant 2 segment length (tuning)")
     ap.add_argument("--slots", type=int, default=0, help="pipeline slots of the library (0 = default)")
-    ap.add_argument("--cpu-reps", type=int, default=8, help="oracle repetitions for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-reps", type=int, default=16, help="oracle repetitions for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
     import numpy as np
@@ -64,6 +64,7 @@ def main() -> int:
 
     import mp3rgain_amd as rg
     from mp3rgain_amd import _capi
+    from mp3rgain_amd import album as album_mod
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -121,10 +122,8 @@ def main() -> int:
                     torch.as_tensor(_DevArray(view.d_album_hist, (_capi.HISTOGRAM_SIZE,), "<i4"), device="cuda"),
                     torch.as_tensor(_DevArray(view.d_album_peak, (1,), "<f8"), device="cuda"))
             hist_t, peak_t = views[view.d_album_hist]
-            # LoudnessHistogram::accumulate / album_peak.max across ranks (replaygain.rs:1056-1059);
-            # int32 two's-complement sum == the reference's u32 bins
-            dist.all_reduce(hist_t, op=dist.ReduceOp.SUM)
-            dist.all_reduce(peak_t, op=dist.ReduceOp.MAX)
+            # LoudnessHistogram::accumulate / album_peak.max across ranks (replaygain.rs:1056-1059)
+            album_mod.allreduce_album(hist_t, peak_t)
             an.album_result_enqueue()
 
     def fence():
@@ -142,7 +141,7 @@ def main() -> int:
         step()
     fence()
     dt = time.perf_counter() - t0
-    k1_ms_sum, k1_launches = an.timing_read(reset=True)
+    k1_ms_sum, k1_launches, k1_span_ms = an.timing_read(reset=True)
     an.timing_enable(False)
 
     if dist is not None:
@@ -156,8 +155,23 @@ def main() -> int:
 
     total_frames = frames * ntr * world * args.steps
     value = total_frames / dt
+    # Dominant kernel (rg_tm_main_kernel), HIP events on the streams it is launched on.  Consecutive
+    # batches run in separate pipeline slots, so several launches are in flight at once:
+    #   kernel_ms    average duration of one launch (what rocprofv3 --stats reports as the average)
+    #   concurrency  sum of the launch durations / span from the first start to the last end
+    #   achieved     algorithmic bytes per launch / (kernel_ms / concurrency), i.e. the bytes all launches
+    #                consumed divided by the time during which the kernel was running
     k1_ms = k1_ms_sum / max(1, k1_launches)
-    achieved = ALGO_BYTES_PER_FRAME * frames * ntr / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+    concurrency = k1_ms_sum / k1_span_ms if k1_span_ms > 0 else 1.0
+    algo_bytes = ALGO_BYTES_PER_FRAME * frames * ntr
+    achieved = algo_bytes * k1_launches / (k1_span_ms * 1e-3) / 1e9 if k1_span_ms > 0 else 0.0
+    traffic = None
+    try:  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), same workload only
+        pm = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+        if pm.get("frames_per_launch") == frames * ntr:
+            traffic = pm["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
 
     out = None
     if rank == 0:
@@ -202,9 +216,12 @@ def main() -> int:
                 "mode": "album (-a), RCCL all-reduce of the 12000-bin histogram + peak" if album else "track (-r)",
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel_ms": k1_ms, "kernel_launches": int(k1_launches),
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * frames * ntr},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "rg_tm_main_kernel", "kernel_ms": k1_ms, "kernel_launches": int(k1_launches),
+                         "kernel_concurrency": concurrency, "kernel_span_ms": k1_span_ms,
+                         "achieved_one_launch_alone": algo_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "fp64_fma_tflops": 2.0 * 62.0 * frames * ntr * k1_launches / (k1_span_ms * 1e-3) / 1e12 if k1_span_ms > 0 else 0.0},
             "cpu_baseline": cpu,
             "parity": parity,
             "result": {"loudness_db": res[0].loudness_db, "gain_db": res[0].gain_db, "peak": res[0].peak,

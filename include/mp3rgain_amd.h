@@ -132,8 +132,16 @@ int rg_rate_design_info(uint32_t sample_rate, int *stable, uint32_t *halo_frames
 rg_ctx *rg_create(int device);
 void rg_destroy(rg_ctx *ctx);
 const char *rg_last_error(const rg_ctx *ctx);
-/* run on a caller-owned HIP stream (hipStream_t as void*); NULL restores the ctx's own stream */
+/* Attach a caller-owned HIP stream (hipStream_t as void*; NULL detaches).  The analysis kernels keep
+ * running on the context's own pipeline streams; the caller's stream is used for (a) input ordering:
+ * the first enqueue after rg_set_stream / rg_wait_user_stream / rg_synth_fill_device waits for
+ * everything submitted to it so far, and (b) the album tail: after an album enqueue the caller's
+ * stream waits for the batch, and rg_album_allreduce / rg_album_result_enqueue / rg_album_finish run
+ * on it, so that a collective the caller issues on that stream (RCCL through torch.distributed, say)
+ * sits between them in stream order. */
 int rg_set_stream(rg_ctx *ctx, void *hip_stream);
+/* order the next enqueue behind everything submitted to the caller's stream so far (PCM produced there) */
+int rg_wait_user_stream(rg_ctx *ctx);
 /* kernel variant: 0 = auto, 1 = halo-tiled reference kernel, 2 = transient-moment kernel */
 int rg_set_kernel(rg_ctx *ctx, int variant);
 
@@ -184,8 +192,10 @@ int rg_album_result_enqueue(rg_ctx *ctx);
 /* When enabled, every enqueue brackets the dominant kernel (IIR+RMS+histogram) with HIP events
  * on the stream it is launched on. */
 int rg_timing_enable(rg_ctx *ctx, int on);
-/* sum of bracketed kernel durations and their count since the last reset; synchronises */
-int rg_timing_read(rg_ctx *ctx, double *sum_ms, uint64_t *launches, int reset);
+/* Since the last reset: sum of the bracketed kernel durations, their count, and the span from the
+ * first bracketed start to the last bracketed end (launches of consecutive batches overlap across
+ * pipeline slots, so span < sum when the pipeline is deeper than one).  Synchronises. */
+int rg_timing_read(rg_ctx *ctx, double *sum_ms, uint64_t *launches, double *span_ms, int reset);
 
 /* ---- synthetic PCM directly in HBM (bench / tests; include/rg_synth.h) --------------------- */
 int rg_synth_fill_device(rg_ctx *ctx, void *d_dst_f32, uint64_t seed, uint32_t channel,

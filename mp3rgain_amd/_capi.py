@@ -98,6 +98,7 @@ SYMBOLS = [
     ("rg_destroy", None, [_vp]),
     ("rg_last_error", C.c_char_p, [_vp]),
     ("rg_set_stream", _int, [_vp, _vp]),
+    ("rg_wait_user_stream", _int, [_vp]),
     ("rg_set_kernel", _int, [_vp, _int]),
     ("rg_set_tuning", _int, [_vp, _int, C.c_int64]),
     ("rg_tm_design_info", _int, [_u32, _u32, _P(_u32), _P(_u32), _P(_u32), _P(_dbl), _vp, _vp]),
@@ -111,7 +112,7 @@ SYMBOLS = [
     ("rg_album_finish", _int, [_vp, _P(AlbumResult), _vp]),
     ("rg_album_result_enqueue", _int, [_vp]),
     ("rg_timing_enable", _int, [_vp, _int]),
-    ("rg_timing_read", _int, [_vp, _P(_dbl), _P(_u64), _int]),
+    ("rg_timing_read", _int, [_vp, _P(_dbl), _P(_u64), _P(_dbl), _int]),
     ("rg_synth_fill_device", _int, [_vp, _vp, _u64, _u32, _u32, _u64, _u64]),
 ]
 

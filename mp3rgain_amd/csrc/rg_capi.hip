@@ -76,6 +76,11 @@ int drain_timing(rg_ctx *c) {
             RG_HIP(c, hipEventElapsedTime(&ms, S.ev_pool[i].first, S.ev_pool[i].second));
             c->timing_sum_ms += ms;
             c->timing_count += 1;
+            if (c->timing_first) {
+                float sp = 0.f;
+                RG_HIP(c, hipEventElapsedTime(&sp, c->timing_first, S.ev_pool[i].second));
+                if (sp > c->timing_span_ms) c->timing_span_ms = sp;
+            }
         }
         S.ev_used = 0;
     }
@@ -173,6 +178,7 @@ extern "C" rg_ctx *rg_create(int device) {
         e = hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&S.staging_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&S.batch_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&S.album_done, hipEventDisableTiming);
         if (e == hipSuccess) e = S.d_album_hist.reserve(RG_HISTOGRAM_SIZE);
         if (e == hipSuccess) e = S.d_album_peak.reserve(1);
         if (e == hipSuccess) e = S.d_album_result.reserve(1);
@@ -224,6 +230,7 @@ extern "C" void rg_destroy(rg_ctx *c) {
         S.h_album_result.release();
         if (S.staging_done) (void)hipEventDestroy(S.staging_done);
         if (S.batch_done) (void)hipEventDestroy(S.batch_done);
+        if (S.album_done) (void)hipEventDestroy(S.album_done);
         if (S.stream) (void)hipStreamDestroy(S.stream);
     }
     if (c->user_ev) (void)hipEventDestroy(c->user_ev);
@@ -240,6 +247,13 @@ extern "C" int rg_set_stream(rg_ctx *c, void *s) {
     int rc = sync_all(c);
     if (rc != RG_OK) return rc;
     c->user_stream = (hipStream_t)s;
+    c->user_dirty = s != nullptr;
+    return RG_OK;
+}
+
+extern "C" int rg_wait_user_stream(rg_ctx *c) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    c->user_dirty = c->user_stream != nullptr;
     return RG_OK;
 }
 
@@ -288,7 +302,7 @@ extern "C" int rg_timing_enable(rg_ctx *c, int on) {
     return RG_OK;
 }
 
-extern "C" int rg_timing_read(rg_ctx *c, double *sum_ms, uint64_t *launches, int reset) {
+extern "C" int rg_timing_read(rg_ctx *c, double *sum_ms, uint64_t *launches, double *span_ms, int reset) {
     if (!c) return RG_ERR_INVALID_ARG;
     if (rg_bind_device(c) != RG_OK) return RG_ERR_DEVICE;
     int rc = sync_all(c);
@@ -297,9 +311,12 @@ extern "C" int rg_timing_read(rg_ctx *c, double *sum_ms, uint64_t *launches, int
     if (rc != RG_OK) return rc;
     if (sum_ms) *sum_ms = c->timing_sum_ms;
     if (launches) *launches = c->timing_count;
+    if (span_ms) *span_ms = c->timing_span_ms;
     if (reset) {
         c->timing_sum_ms = 0.0;
         c->timing_count = 0;
+        c->timing_span_ms = 0.0;
+        c->timing_first = nullptr;
     }
     return RG_OK;
 }
@@ -361,6 +378,10 @@ extern "C" int rg_album_result_enqueue(rg_ctx *c) {
     int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
     RG_HIP(c, rg_launch_album_result(c->slot().d_album_hist.p, c->slot().d_album_peak.p, c->slot().d_album_result.p, c->album_stream()));
+    if (c->user_stream) {
+        RG_HIP(c, hipEventRecord(c->slot().album_done, c->user_stream));
+        c->slot().album_pending = true;
+    }
     return RG_OK;
 }
 
@@ -412,6 +433,10 @@ extern "C" int rg_album_allreduce(rg_ctx *c, void *comm) {
     if (r == 0) r = ar(c->slot().d_album_peak.p, c->slot().d_album_peak.p, 1, kNcclFloat64, kNcclMax, comm, c->album_stream());
     int r2 = ge();
     if (r != 0 || r2 != 0) return rg_set_err(c, RG_ERR_COLLECTIVE, "ncclAllReduce failed (%d/%d)", r, r2);
+    if (c->user_stream) {
+        RG_HIP(c, hipEventRecord(c->slot().album_done, c->user_stream));
+        c->slot().album_pending = true;
+    }
     return RG_OK;
 }
 
@@ -474,6 +499,10 @@ extern "C" int rg_synth_fill_device(rg_ctx *c, void *d_dst, uint64_t seed, uint3
     if (!c || (!d_dst && frames)) return RG_ERR_INVALID_ARG;
     int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
-    RG_HIP(c, rg_launch_synth_fill((float *)d_dst, seed, channel, sample_rate, first_frame, frames, (c->user_stream ? c->user_stream : c->slot().stream)));
+    hipStream_t fs = c->user_stream ? c->user_stream : c->slot().stream;
+    RG_HIP(c, rg_launch_synth_fill((float *)d_dst, seed, channel, sample_rate, first_frame, frames, fs));
+    // every pipeline stream must see the generated PCM: the next enqueue waits for this point
+    if (!c->user_stream) RG_HIP(c, hipEventRecord(c->user_ev, fs));
+    c->user_dirty = true;
     return RG_OK;
 }

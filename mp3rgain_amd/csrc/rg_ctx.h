@@ -74,6 +74,8 @@ struct RgSlot {
     hipStream_t stream = nullptr;
     hipEvent_t staging_done = nullptr;  // H2D copy out of the pinned staging buffer has finished
     hipEvent_t batch_done = nullptr;    // everything enqueued for the batch has finished
+    hipEvent_t album_done = nullptr;    // the album tail on the caller's stream is done with this slot's buffers
+    bool album_pending = false;
     bool staging_pending = false;
     // all launch descriptors of a batch travel as one blob: [RgTrackDev x n | RgTrackDev x n_k1 | RgTmTrack x m];
     // an unchanged blob (the same batch enqueued again) is not copied again
@@ -105,8 +107,9 @@ struct rg_ctx {
 
     RgSlot slots[RG_MAX_SLOTS];
     int cur = 0;                        // slot of the most recent enqueue
-    hipStream_t user_stream = nullptr;  // rg_set_stream: inputs are ordered after it, album collectives run on it
+    hipStream_t user_stream = nullptr;  // rg_set_stream: the album tail (collectives, album percentile) runs on it
     hipEvent_t user_ev = nullptr;
+    bool user_dirty = false;            // the next enqueue must first wait for what was submitted to user_stream
     RgSlot &slot() { return slots[cur]; }
     // stream on which the album tail (all-reduce, album percentile, its D2H) runs
     hipStream_t album_stream() { return user_stream ? user_stream : slots[cur].stream; }
@@ -125,6 +128,8 @@ struct rg_ctx {
     bool timing = false;
     double timing_sum_ms = 0.0;
     uint64_t timing_count = 0;
+    hipEvent_t timing_first = nullptr;  // start event of the first bracketed launch since the last reset
+    double timing_span_ms = 0.0;        // first start -> last end over all bracketed launches
 };
 
 int rg_set_err(rg_ctx *c, int code, const char *fmt, ...) __attribute__((format(printf, 3, 4)));

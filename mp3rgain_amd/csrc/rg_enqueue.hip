@@ -243,6 +243,7 @@ int timing_begin(rg_ctx *c, hipEvent_t *e1) {
     *e1 = S.ev_pool[S.ev_used].second;
     S.ev_used += 1;
     RG_HIP(c, hipEventRecord(e0, S.stream));
+    if (!c->timing_first) c->timing_first = e0;
     return RG_OK;
 }
 
@@ -269,9 +270,14 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
     c->cur = (c->cur + 1) % c->n_slots;
     RgSlot &S = c->slot();
     hipStream_t s = S.stream;
-    if (c->user_stream) {  // inputs produced on the caller's stream must be complete first
-        RG_HIP(c, hipEventRecord(c->user_ev, c->user_stream));
-        RG_HIP(c, hipStreamWaitEvent(s, c->user_ev, 0));
+    if (c->user_dirty) {  // inputs produced on the caller's stream (or by rg_synth_fill_device) must be complete first
+        if (c->user_stream) RG_HIP(c, hipEventRecord(c->user_ev, c->user_stream));
+        for (int k = 0; k < RG_MAX_SLOTS; ++k) RG_HIP(c, hipStreamWaitEvent(c->slots[k].stream, c->user_ev, 0));
+        c->user_dirty = false;
+    }
+    if (S.album_pending) {  // the previous album tail that used this slot's buffers ran on another stream
+        RG_HIP(c, hipStreamWaitEvent(s, S.album_done, 0));
+        S.album_pending = false;
     }
 
     // the pinned staging buffers may still feed the previous batch's H2D copies

@@ -199,6 +199,10 @@ class Analyzer:
     def set_stream(self, hip_stream: Optional[int]):
         self._check(self._lib.rg_set_stream(self._ctx, hip_stream))
 
+    def wait_user_stream(self):
+        """Order the next enqueue behind what the attached stream has been given so far."""
+        self._check(self._lib.rg_wait_user_stream(self._ctx))
+
     def set_kernel(self, variant: int):
         self._check(self._lib.rg_set_kernel(self._ctx, variant))
 
@@ -278,9 +282,10 @@ class Analyzer:
         self._check(self._lib.rg_timing_enable(self._ctx, int(on)))
 
     def timing_read(self, reset: bool = True):
-        s, k = C.c_double(), C.c_uint64()
-        self._check(self._lib.rg_timing_read(self._ctx, C.byref(s), C.byref(k), int(reset)))
-        return s.value, k.value
+        """-> (sum of kernel durations [ms], launches, first-start-to-last-end span [ms])"""
+        s, k, sp = C.c_double(), C.c_uint64(), C.c_double()
+        self._check(self._lib.rg_timing_read(self._ctx, C.byref(s), C.byref(k), C.byref(sp), int(reset)))
+        return s.value, k.value, sp.value
 
 
 def _to_result(r: _capi.TrackResult, file_type: AudioFileType) -> ReplayGainResult:
