@@ -22,10 +22,9 @@ rg_track_result_kernel(const uint32_t *__restrict__ hist, const unsigned long lo
                        const RgTrackDev *__restrict__ list /* the tracks to finish, any subset */,
                        rg_track_result *__restrict__ out) {
     __shared__ uint64_t scan[RG_PCT_THREADS];
-    __shared__ uint32_t bins[RG_PCT_THREADS * RG_PCT_CHUNK];
     const RgTrackDev tr = list[blockIdx.x];
     const uint32_t t = tr.track_index;
-    const RgLoudness l = rg_block_loudness(hist + (size_t)t * RG_HISTOGRAM_SIZE, bins, scan);
+    const RgLoudness l = rg_block_loudness(hist + (size_t)t * RG_HISTOGRAM_SIZE, scan);
     if (threadIdx.x == 0) rg_store_track_result(out + t, l, __longlong_as_double((long long)peak_bits[t]), tr.sample_rate, tr.file_type);
 }
 
@@ -33,8 +32,7 @@ __global__ void __launch_bounds__(RG_PCT_THREADS)
 rg_album_result_kernel(const uint32_t *__restrict__ album_hist, const double *__restrict__ album_peak,
                        rg_album_result *__restrict__ out) {
     __shared__ uint64_t scan[RG_PCT_THREADS];
-    __shared__ uint32_t bins[RG_PCT_THREADS * RG_PCT_CHUNK];
-    const RgLoudness l = rg_block_loudness(album_hist, bins, scan);
+    const RgLoudness l = rg_block_loudness(album_hist, scan);
     if (threadIdx.x == 0) {
         rg_album_result r;
         r.album_loudness_db = l.loudness_db;

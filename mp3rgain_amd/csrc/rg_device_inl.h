@@ -38,30 +38,18 @@ struct RgLoudness {
     uint64_t total;
 };
 
-// All 256 threads cooperate: the histogram is staged in LDS with coalesced loads, thread t owns bins
-// [47t, 47t+47), a block-wide suffix scan of the 256 chunk sums finds the one chunk in which the
-// running count (from the top bin down) first reaches the threshold, and that thread alone walks its
-// 47 bins from the top.  The result is exactly the sequential scan's.
-static __device__ __forceinline__ RgLoudness rg_block_loudness(const uint32_t *__restrict__ h, uint32_t *bins /* LDS[12032] */,
-                                               uint64_t *scan /* LDS[256] */) {
+// All 256 threads cooperate: thread t owns bins [47t, 47t+47) in registers, a block-wide suffix scan of
+// the 256 chunk sums finds the one chunk in which the running count (from the top bin down) first
+// reaches the threshold, and that thread alone walks its 47 bins from the top.  The result is exactly
+// the sequential scan's.  LDS: 2 KiB.
+static __device__ __forceinline__ RgLoudness rg_block_loudness(const uint32_t *__restrict__ h, uint64_t *scan /* LDS[256] */) {
     const int t = threadIdx.x;
-    {   // 12000 bins = 3000 16-byte vectors, 12 per thread, all loads in flight before the first store
-        const uint4 *__restrict__ h4 = reinterpret_cast<const uint4 *>(h);  // rows are 48000 B apart: 16-byte aligned
-        uint4 *b4 = reinterpret_cast<uint4 *>(bins);
-        uint4 v[12];
+    uint32_t mine[RG_PCT_CHUNK];
 #pragma unroll
-        for (int u = 0; u < 12; ++u) {
-            const int i = t + u * RG_PCT_THREADS;
-            v[u] = i < RG_HISTOGRAM_SIZE / 4 ? h4[i] : make_uint4(0u, 0u, 0u, 0u);
-        }
-#pragma unroll
-        for (int u = 0; u < 12; ++u) {
-            const int i = t + u * RG_PCT_THREADS;
-            if (i < RG_PCT_THREADS * RG_PCT_CHUNK / 4) b4[i] = v[u];
-        }
+    for (int i = 0; i < RG_PCT_CHUNK; ++i) {
+        const int b = t * RG_PCT_CHUNK + i;
+        mine[i] = b < RG_HISTOGRAM_SIZE ? h[b] : 0u;  // 47 independent loads in flight
     }
-    __syncthreads();
-    const uint32_t *mine = bins + t * RG_PCT_CHUNK;
     uint64_t s = 0;
 #pragma unroll
     for (int i = 0; i < RG_PCT_CHUNK; ++i) s += mine[i];
@@ -87,13 +75,13 @@ static __device__ __forceinline__ RgLoudness rg_block_loudness(const uint32_t *_
         const uint64_t threshold = (uint64_t)ceil((double)total * RG_ONE_MINUS_PERCENTILE);
         if (suffix >= threshold && above < threshold) {  // exactly one thread
             uint64_t count = above;
+            int found = -1;
+#pragma unroll
             for (int i = RG_PCT_CHUNK - 1; i >= 0; --i) {
                 count += mine[i];
-                if (count >= threshold) {
-                    res.loudness_db = (double)(t * RG_PCT_CHUNK + i - RG_HISTOGRAM_OFFSET) / 100.0;
-                    break;
-                }
+                if (found < 0 && count >= threshold) found = i;
             }
+            res.loudness_db = (double)(t * RG_PCT_CHUNK + found - RG_HISTOGRAM_OFFSET) / 100.0;
         }
     }
     __syncthreads();

@@ -306,9 +306,10 @@ __global__ void __launch_bounds__(RG_TM_BLOCK)
 rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restrict__ tracks, uint32_t n_tracks,
                   double *__restrict__ rec, uint32_t total_recs, uint32_t lds_tables,
                   uint32_t *__restrict__ zero_words, uint64_t zero_count /* batch accumulators to clear, or nullptr */,
-                  unsigned long long *__restrict__ dbg /* nullptr, or 4 words per wave: start, end, hw id, path */) {
+                  unsigned long long *__restrict__ dbg /* nullptr, or 6 words per wave: start, end, hw id, path, cycle counter start, end */) {
     typedef Fmt<FMT> F;
     const unsigned long long dbg_t0 = dbg ? wall_clock64() : 0ull;
+    const unsigned long long dbg_c0 = dbg ? __builtin_readcyclecounter() : 0ull;
     typedef typename F::elem elem;
     typedef __attribute__((address_space(1))) const elem gelem;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -398,7 +399,9 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
     }
 
     if (dbg && (threadIdx.x & 63) == 0) {
-        const size_t w = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (RG_TM_BLOCK / 64) + (threadIdx.x >> 6)) * 4;
+        const size_t w = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (RG_TM_BLOCK / 64) + (threadIdx.x >> 6)) * 6;
+        dbg[w + 4] = dbg_c0;
+        dbg[w + 5] = __builtin_readcyclecounter();
         dbg[w + 0] = dbg_t0;
         dbg[w + 1] = wall_clock64();
         dbg[w + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |  // XCC_ID
@@ -446,13 +449,25 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
                  const double *__restrict__ rec, uint32_t total_recs, uint32_t *__restrict__ hist,
                  unsigned long long *__restrict__ peak_bits, uint32_t *__restrict__ done_count,
                  rg_track_result *__restrict__ results) {
-    // LDS: the scan exchange buffer is reused as the histogram staging area of the percentile epilogue
-    __shared__ __attribute__((aligned(16))) char lds_raw[2 * RG_TM_DIM * RG_TM_BLOCK * sizeof(double)];  // 48 KiB >= 12032 * 4
+    // LDS (about 17 KiB, so that fix-up blocks fit next to resident main-kernel blocks of other pipeline
+    // slots): lanes exchange scan values with wave shuffles; only the last RG_TM_EDGE lanes of each wave go
+    // through LDS for the lanes of the next wave
+    __shared__ double edge[RG_TM_BLOCK / 64][RG_TM_EDGE][NCH * RG_TM_DIM];
     __shared__ uint64_t pct_scan[RG_PCT_THREADS];
     __shared__ double pieces[RG_TM_BLOCK];
     __shared__ int bins[RG_TM_BLOCK];
     __shared__ int is_last;
-    double (*wx)[RG_TM_DIM][RG_TM_BLOCK] = reinterpret_cast<double (*)[RG_TM_DIM][RG_TM_BLOCK]>(lds_raw);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // value of `x` held by the lane d (<= RG_TM_EDGE) positions below in the block, 0.0 before the block's first lane;
+    // `slot` = index of x among the values exchanged in this step (all lanes call with the same sequence)
+    auto publish_edge = [&](const double x, const int slot) {
+        if (lane >= 64 - RG_TM_EDGE) edge[wave][lane - (64 - RG_TM_EDGE)][slot] = x;
+    };
+    auto from_below = [&](const double x, const int d, const int slot) -> double {
+        double v = __shfl_up(x, d, 64);
+        if (lane < d) v = wave > 0 ? edge[wave - 1][RG_TM_EDGE - d + lane][slot] : 0.0;
+        return v;
+    };
 
     const uint32_t t = find_track(tracks, n_tracks, blockIdx.x, &RgTmTrack::fix_block_base);
     const RgTmTrack tr = tracks[t];
@@ -500,18 +515,20 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     // ---- doubling scan: after round r, w_k = sum_{q < 2^(r+1)} Phi^q e_{k-q} ------------------------------
     for (uint32_t rd = 0; rd < G.rounds; ++rd) {
         const int d = 1 << rd;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int j = 0; j < RG_TM_DIM; ++j) wx[c][j][i] = w[c][j];
-        __syncthreads();
+        const bool fast = rd < G.rounds_fast;  // the fast (Yule) block has usually decayed within one segment
         double wn[NCH][RG_TM_DIM];
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
-            for (int j = 0; j < RG_TM_DIM; ++j) wn[c][j] = i >= d ? wx[c][j][i - d] : 0.0;
+            for (int j = 0; j < RG_TM_DIM; ++j)
+                if (j >= 10 || fast) publish_edge(w[c][j], c * RG_TM_DIM + j);
         __syncthreads();
-        if (rd < G.rounds_fast) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int j = 0; j < RG_TM_DIM; ++j) wn[c][j] = (j >= 10 || fast) ? from_below(w[c][j], d, c * RG_TM_DIM + j) : 0.0;
+        __syncthreads();
+        if (fast) {
             rg_cdouble *__restrict__ PY = (rg_cdouble *)FT.PhiY + (size_t)rd * 100;
 #pragma unroll
             for (int a = 0; a < 10; ++a) {
@@ -535,8 +552,13 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int j = 0; j < RG_TM_DIM; ++j) wx[c][j][i] = w[c][j];
+        for (int j = 0; j < RG_TM_DIM; ++j) publish_edge(w[c][j], c * RG_TM_DIM + j);
     __syncthreads();
+    double sgm[NCH][RG_TM_DIM];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < RG_TM_DIM; ++j) sgm[c][j] = from_below(w[c][j], 1, c * RG_TM_DIM + j);
 
     double S = 0.0;
     if (owner) {
@@ -548,7 +570,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
         for (int c = 0; c < NCH; ++c) {
             double sg[RG_TM_DIM];
 #pragma unroll
-            for (int j = 0; j < RG_TM_DIM; ++j) sg[j] = wx[c][j][i - 1];  // owner => i >= warm >= 1
+            for (int j = 0; j < RG_TM_DIM; ++j) sg[j] = sgm[c][j];
             double lin = 0.0;
 #pragma unroll
             for (int j = 0; j < RG_TM_DIM; ++j) lin = fma(Bm[c][j], sg[j], lin);
@@ -608,8 +630,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     __syncthreads();
     if (is_last) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const RgLoudness l = rg_block_loudness(hist + (size_t)tr.track_index * RG_HISTOGRAM_SIZE,
-                                               reinterpret_cast<uint32_t *>(lds_raw), pct_scan);
+        const RgLoudness l = rg_block_loudness(hist + (size_t)tr.track_index * RG_HISTOGRAM_SIZE, pct_scan);
         if (i == 0) {
             const unsigned long long pb = atomicMax(&peak_bits[tr.track_index], 0ull);  // coherent read
             rg_store_track_result(results + tr.track_index, l, __longlong_as_double((long long)pb), tr.sample_rate,

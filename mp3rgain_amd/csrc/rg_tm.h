@@ -27,7 +27,8 @@
 #define RG_TM_GRAM 78         // upper triangle of a symmetric 12x12
 #define RG_TM_REC 26          // doubles per (segment, channel): A, B[12], E[12], peak
 #define RG_TM_BLOCK 256
-#define RG_TM_MAX_ROUNDS 5
+#define RG_TM_MAX_ROUNDS 4    // the doubling scan reaches 2^4 = 16 predecessors
+#define RG_TM_EDGE 16         // lanes of a wave whose scan values are visible to the next wave (>= 2^(MAX_ROUNDS-1), and 1 for the final shift)
 
 // filter constants of one launch group, passed by value (wave-uniform -> SGPRs)
 struct RgTmCoef {

@@ -13,27 +13,30 @@ import mp3rgain_amd as rg  # noqa: E402
 from mp3rgain_amd import _capi  # noqa: E402
 
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+NT = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rate, frames = 44100, 44100 * 600
 an = rg.Analyzer(0)
 if L:
     an.set_tuning(1, L)
-pcm = torch.empty((1, 2, frames), dtype=torch.float32, device="cuda")
-for c in range(2):
-    an.synth_fill_device(pcm[0, c].data_ptr(), 0x5EED0000, c, rate, 0, frames)
-d = (_capi.TrackDesc * 1)()
-d[0].offset_bytes, d[0].frames, d[0].sample_rate, d[0].channels, d[0].format = 0, frames, rate, 2, 0
+an.set_tuning(3, 1)
+pcm = torch.empty((NT, 2, frames), dtype=torch.float32, device="cuda")
+d = (_capi.TrackDesc * NT)()
+for t in range(NT):
+    for c in range(2):
+        an.synth_fill_device(pcm[t, c].data_ptr(), 0x5EED0000 + t, c, rate, 0, frames)
+    d[t].offset_bytes, d[t].frames, d[t].sample_rate, d[t].channels, d[t].format = t * 2 * frames * 4, frames, rate, 2, 0
 raw = C.CDLL(str(_capi.LIB_PATH))
 raw.rg_tm_set_debug_buffer.argtypes = [C.c_void_p]
-nw = 1 << 16
-dbg = torch.zeros(nw * 4, dtype=torch.int64, device="cuda")
+nw = 1 << 18
+dbg = torch.zeros(nw * 6, dtype=torch.int64, device="cuda")
 for _ in range(3):
-    an.enqueue_device(d, 1, pcm.data_ptr(), pcm.numel() * 4)
-an.collect(1)
+    an.enqueue_device(d, NT, pcm.data_ptr(), pcm.numel() * 4)
+an.collect(NT)
 raw.rg_tm_set_debug_buffer(dbg.data_ptr())
-an.enqueue_device(d, 1, pcm.data_ptr(), pcm.numel() * 4)
-an.collect(1)
+an.enqueue_device(d, NT, pcm.data_ptr(), pcm.numel() * 4)
+an.collect(NT)
 raw.rg_tm_set_debug_buffer(None)
-a = dbg.cpu().numpy().reshape(-1, 4)
+a = dbg.cpu().numpy().reshape(-1, 6)
 a = a[a[:, 0] != 0]
 t0 = a[:, 0].min()
 st, en = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0  # wall_clock64 ticks at 100 MHz -> us
@@ -50,4 +53,8 @@ uk, cnt = np.unique(key, return_counts=True)
 print(f"distinct (xcc,se,sh,cu) = {len(uk)}; waves per CU: min {cnt.min()} med {int(np.median(cnt))} max {cnt.max()}")
 for q in (0.1, 0.25, 0.5, 0.75, 0.9, 1.0):
     print(f"  {int(q*100):3d}% of waves finished by {np.quantile(en, q):8.1f} us")
+dur_us = (a[:, 1] - a[:, 0]) / 100.0
+cyc = (a[:, 5] - a[:, 4]).astype(np.float64)
+ok = dur_us > 5
+print(f"shader clock from s_memtime/wall: median {np.median(cyc[ok] / dur_us[ok]) / 1000:.3f} GHz (min {np.min(cyc[ok] / dur_us[ok]) / 1000:.3f}, max {np.max(cyc[ok] / dur_us[ok]) / 1000:.3f})")
 print("per-XCD wave counts:", np.bincount(xcc.astype(int), minlength=8))
