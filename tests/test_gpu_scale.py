@@ -1,0 +1,117 @@
+"""GPU tests at BASELINE.json's sizes: direct comparison where the oracle finishes in seconds, and
+size-independent properties (album histogram == sum of track histograms, window conservation,
+idempotence across pipeline slots) for the large batches."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RATE = 44100
+W = 2205
+
+
+def _device_batch(analyzer, seeds, frames_list, rate=RATE, channels=2):
+    import torch
+
+    from mp3rgain_amd import _capi
+
+    total = sum(f * channels for f in frames_list)
+    buf = torch.empty(total + 4, dtype=torch.float32, device="cuda:0")
+    descs = (_capi.TrackDesc * len(seeds))()
+    off = 0
+    for t, (s, f) in enumerate(zip(seeds, frames_list)):
+        for c in range(channels):
+            analyzer.synth_fill_device(buf.data_ptr() + 4 * (off + c * f), s, c, rate, 0, f)
+        descs[t].offset_bytes = 4 * off
+        descs[t].frames = f
+        descs[t].sample_rate = rate
+        descs[t].channels = channels
+        descs[t].format = _capi.FMT_F32_PLANAR
+        off += channels * f
+    return buf, descs
+
+
+def test_config2_ten_minute_track_full_size(analyzer, oracle):
+    """BASELINE configs[1] at full size (26 460 000 frames): every one of the 12 000 windows in the oracle's bin."""
+    frames = 600 * RATE
+    buf, descs = _device_batch(analyzer, [0x5EED0000], [frames])
+    analyzer.enqueue_device(descs, 1, buf.data_ptr(), buf.numel() * 4)
+    got, h = analyzer.collect(1, want_hist=True)
+    l, r = oracle.synth_f32(0x5EED0000, 0, RATE, frames), oracle.synth_f32(0x5EED0000, 1, RATE, frames)
+    want, wh = oracle.analyze_pcm(l, r, RATE)
+    diff = np.nonzero(h[0] != wh)[0]
+    assert diff.size == 0, f"{diff.size} bins differ, first {diff[:5]}"
+    assert got[0].loudness_db == want["loudness_db"] and got[0].peak == want["peak"]
+    assert abs(got[0].loudness_db - want["loudness_db"]) <= 0.1  # the north_star tolerance, for the record
+    # the 1 s digital-silence gap: its windows are dropped, not clamped (replaygain.rs:757); the first one still
+    # carries the filter's ringing and counts
+    assert got[0].windows == int(wh.sum()) == 12000 - 19
+
+
+def test_config3_shape_batch_properties(analyzer, oracle):
+    """A slice of BASELINE configs[2]/[3] (3-minute tracks): album histogram is the sum of the track histograms,
+    every track conserves its windows, per-track gains differ, and a sample of tracks matches the oracle."""
+    n, frames = 24, 180 * RATE
+    seeds = [0x5EED1000 + t for t in range(n)]
+    buf, descs = _device_batch(analyzer, seeds, [frames] * n)
+    analyzer.enqueue_device(descs, n, buf.data_ptr(), buf.numel() * 4, album=True)
+    got, h = analyzer.collect(n, want_hist=True)
+    alb, ah = analyzer.album_finish(want_hist=True)
+    assert np.array_equal(ah, h.sum(axis=0, dtype=np.uint64).astype(np.uint32))  # accumulate (replaygain.rs:658-662)
+    assert alb.album_peak == max(g.peak for g in got)
+    assert alb.album_loudness_db == oracle.hist_loudness(ah)
+    for g, hh in zip(got, h):
+        assert g.windows == int(hh.sum()) and 3600 - 21 <= g.windows <= 3600 - 18  # the silent second is dropped
+        assert g.loudness_db == oracle.hist_loudness(hh)
+    assert len({g.gain_db for g in got}) > 4  # per-track levels differ
+    for t in (0, 7, 23):
+        l, r = oracle.synth_f32(seeds[t], 0, RATE, frames), oracle.synth_f32(seeds[t], 1, RATE, frames)
+        want, wh = oracle.analyze_pcm(l, r, RATE)
+        assert np.array_equal(h[t], wh) and got[t].peak == want["peak"]
+
+
+def test_pipelined_enqueues_are_idempotent(analyzer, oracle):
+    """Back-to-back enqueues rotate through the pipeline slots and overlap on the GPU; every one of them
+    must produce the same bits (no cross-slot interference), including the in-kernel clearing of accumulators."""
+    lens = [RATE * 20 + 31, RATE * 7, 2205 * 13, 5000]
+    seeds = [0x5EED2000 + t for t in range(len(lens))]
+    buf, descs = _device_batch(analyzer, seeds, lens)
+    ref = None
+    for rep in range(9):
+        analyzer.enqueue_device(descs, len(lens), buf.data_ptr(), buf.numel() * 4, album=True)
+        if rep % 2 == 0:
+            got, h = analyzer.collect(len(lens), want_hist=True)
+            alb, ah = analyzer.album_finish(want_hist=True)
+            cur = (h.copy(), ah.copy(), [(g.loudness_db, g.peak, g.windows) for g in got], alb.album_loudness_db)
+            if ref is None:
+                ref = cur
+                for t, (s, f) in enumerate(zip(seeds, lens)):
+                    l, r = oracle.synth_f32(s, 0, RATE, f), oracle.synth_f32(s, 1, RATE, f)
+                    _, wh = oracle.analyze_pcm(l, r, RATE)
+                    assert np.array_equal(h[t], wh)
+            else:
+                assert np.array_equal(cur[0], ref[0]) and np.array_equal(cur[1], ref[1])
+                assert cur[2] == ref[2] and cur[3] == ref[3]
+
+
+def test_mixed_48k_mono_and_hot_tracks(analyzer, oracle):
+    """BASELINE configs[4] ingredients: 44.1/48 kHz mixed, mono tracks, full-scale ("hot") tracks whose peak
+    reaches 1.0, and the -k rule applied to the GPU's numbers (src/main.rs:2033-2058)."""
+    import mp3rgain_amd as rg
+
+    specs = [(44100, 2, 0x5EED3000), (48000, 2, 0x5EED3001), (48000, 1, 0x5EED3002), (44100, 2, 0x5EED3003 | (1 << 40)),
+             (48000, 2, 0x5EED3004 | (1 << 40)), (44100, 1, 0x5EED3005)]
+    tracks, wants = [], []
+    for rate, ch, seed in specs:
+        n = rate * 6 + 99
+        chans = [oracle.synth_f32(seed, c, rate, n) for c in range(ch)]
+        tracks.append(rg.PcmTrack(chans, rate))
+        wants.append(oracle.analyze_pcm(chans[0], chans[1] if ch == 2 else None, rate))
+    got, h = analyzer.analyze_tracks(tracks, return_histograms=True)
+    L = oracle.lib()
+    for g, hh, (w, wh) in zip(got, h, wants):
+        assert np.array_equal(hh, wh) and g.peak == w["peak"] and g.loudness_db == w["loudness_db"]
+        for k in (0, 1):
+            assert rg.replaygain.clip_limit_steps(g.gain_steps(), g.gain_db, g.peak, bool(k)) == \
+                L.rgo_clip_limit_steps(w["gain_steps"], w["gain_db"], w["peak"], k, 0)
+    assert got[3].peak == 1.0 and got[4].peak == 1.0
