@@ -68,6 +68,9 @@ template <> struct Fmt<RG_FMT_F32_PLANAR> {
     typedef float peak_t;
     static __device__ __forceinline__ double cvt(float v, float &pk) { pk = fmaxf(pk, fabsf(v)); return (double)v; }
     static __device__ __forceinline__ double peak_norm(float pk) { return (double)pk; }
+    // 32-bit LDS word <-> sample
+    static __device__ __forceinline__ uint32_t word(float v) { return __float_as_uint(v); }
+    static __device__ __forceinline__ double cvt_word(uint32_t w, float &pk) { return cvt(__uint_as_float(w), pk); }
 };
 template <> struct Fmt<RG_FMT_S16_PLANAR> {
     typedef int16_t elem;
@@ -79,6 +82,8 @@ template <> struct Fmt<RG_FMT_S16_PLANAR> {
         return (double)w;
     }
     static __device__ __forceinline__ double peak_norm(uint32_t pk) { return (double)pk / 32768.0; }
+    static __device__ __forceinline__ uint32_t word(int16_t v) { return (uint32_t)(int32_t)v; }
+    static __device__ __forceinline__ double cvt_word(uint32_t w, uint32_t &pk) { return cvt((int16_t)(int32_t)w, pk); }
 };
 template <> struct Fmt<RG_FMT_S32_PLANAR> {
     typedef int32_t elem;
@@ -89,6 +94,8 @@ template <> struct Fmt<RG_FMT_S32_PLANAR> {
         return (double)v;
     }
     static __device__ __forceinline__ double peak_norm(uint32_t pk) { return (double)pk / 2147483648.0; }
+    static __device__ __forceinline__ uint32_t word(int32_t v) { return (uint32_t)v; }
+    static __device__ __forceinline__ double cvt_word(uint32_t w, uint32_t &pk) { return cvt((int32_t)w, pk); }
 };
 
 template <typename T>
@@ -125,7 +132,9 @@ __device__ __forceinline__ uint32_t find_track(const RgTmTrack *__restrict__ tra
 #define RG_TM_TILE 16
 #define RG_TM_WAVE_TILE_BYTES 4096  // 64 rows x 16 frames x 4 B
 
-typedef float __attribute__((ext_vector_type(4), aligned(4))) rg_f32x4u;  // 16-byte load, 4-byte aligned
+typedef uint32_t __attribute__((ext_vector_type(4))) rg_u32x4;
+typedef uint32_t __attribute__((ext_vector_type(4), aligned(4))) rg_u32x4u;  // 16-byte load, 4-byte aligned
+typedef short __attribute__((ext_vector_type(4), aligned(2))) rg_s16x4u;     // 8-byte load, 2-byte aligned
 
 // One frame of one lane: cascade step + moments.  NX = live transient moments (12, or only the slow
 // pair); MASK: frames at or past `len` do not count (tail of a track).
@@ -139,13 +148,12 @@ typedef float __attribute__((ext_vector_type(4), aligned(4))) rg_f32x4u;  // 16-
 //   G2  z,  w_1 = bb_1 y + t_1,  w_2 = bb_2 y + c          (need y, issued 10 slots earlier)
 //   G3  s_i = u_i - a_{i+1} y                              (10, need y and u_i)
 //   G4  t_0, t_1, A, B_j                                   (need z, issued 10 slots earlier)
-template <int NX, bool MASK>
-__device__ __forceinline__ void tm_frame(TmLane<1> &st, const float f, float &pk, const double (&tr)[NX],
-                                         const RgTmCoef &K, const uint32_t n, const uint32_t len) {
+template <int FMT, int NX, bool MASK>
+__device__ __forceinline__ void tm_frame(TmLane<1> &st, const uint32_t wbits, typename Fmt<FMT>::peak_t &pk,
+                                         const double (&tr)[NX], const RgTmCoef &K, const uint32_t n, const uint32_t len) {
     double (&s)[10] = st.s[0];
     double (&t)[2] = st.t[0];
-    pk = fmaxf(pk, fabsf(f));  // frames past the end were staged as zeros
-    const double x = (double)f;
+    const double x = Fmt<FMT>::cvt_word(wbits, pk);  // also tracks the peak; frames past the end were staged as zeros
     const double y = fma(K.b[0], x, s[0]);
     double u[10];
 #pragma unroll
@@ -190,13 +198,15 @@ __device__ __forceinline__ void tm_load_row(double (&dst)[NX], const double *__r
 // Per wave, no block barrier: the global loads of tile t+1 are issued when tile t has just been
 // written to the wave's LDS tile and stay in flight during tile t's arithmetic; inside a tile the
 // next 4-frame piece is read from LDS while the current one computes.
-template <bool TAIL>
-__device__ __forceinline__ void tm_fast_path(TmLane<1> &st, float &pk, const RgTmCoef &K, const uint32_t L,
-                                             const uint32_t H, const __attribute__((address_space(1))) float *chp,
+template <int FMT, bool TAIL>
+__device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::peak_t &pk, const RgTmCoef &K, const uint32_t L,
+                                             const uint32_t H,
+                                             const __attribute__((address_space(1))) typename Fmt<FMT>::elem *chp,
                                              const uint64_t frames, const uint32_t wave_seg0, const uint32_t len,
                                              const double *__restrict__ T12, const double *__restrict__ T2,
                                              char *const wtile /* RG_TM_WAVE_TILE_BYTES */) {
-    typedef const __attribute__((address_space(1))) float gfloat;
+    typedef Fmt<FMT> F;
+    typedef const __attribute__((address_space(1))) typename F::elem gelem;
     const int lane = threadIdx.x & 63;
     // loader role: instruction q covers rows 16q .. 16q+15; this lane fetches for row 16q + (lane >> 2)
     const int lrow = lane >> 2, lslot = lane & 3;
@@ -216,7 +226,15 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, float &pk, const RgT
     const int rswz = (lane >> 2) & 3;
     const uint32_t ntiles = (L + RG_TM_TILE - 1) / RG_TM_TILE;
 
-    rg_f32x4u stage[4];
+    rg_u32x4 stage[4];  // four samples of one row as 32-bit LDS words (float bits, or sign-extended integers)
+    auto load4 = [&](gelem *src) -> rg_u32x4 {
+        if constexpr (FMT == RG_FMT_S16_PLANAR) {
+            const rg_s16x4u v = *(const __attribute__((address_space(1))) rg_s16x4u *)src;
+            return rg_u32x4{(uint32_t)(int32_t)v.x, (uint32_t)(int32_t)v.y, (uint32_t)(int32_t)v.z, (uint32_t)(int32_t)v.w};
+        } else {
+            return *(const __attribute__((address_space(1))) rg_u32x4u *)src;
+        }
+    };
     auto load_tile = [&](uint32_t tile) {
         const uint32_t n0 = tile * RG_TM_TILE;
 #pragma unroll
@@ -226,17 +244,16 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, float &pk, const RgT
             const uint32_t pn = n0 + 4u * piece;  // frame index of the piece within its row
             if (!TAIL) {
                 // pieces starting past the row's end are never read; only the last tile can have such pieces
-                if (n0 + RG_TM_TILE <= L || pn < L)
-                    stage[q] = *(const __attribute__((address_space(1))) rg_f32x4u *)(chp + lfirst[q] + n0);
+                if (n0 + RG_TM_TILE <= L || pn < L) stage[q] = load4(chp + lfirst[q] + n0);
             } else {
-                gfloat *src = chp + lfirst[q] + n0;
+                gelem *src = chp + lfirst[q] + n0;
                 if (pn + 4u <= llen[q]) {
-                    stage[q] = *(const __attribute__((address_space(1))) rg_f32x4u *)src;
+                    stage[q] = load4(src);
                 } else {
-                    stage[q].x = pn + 0u < llen[q] ? src[0] : 0.0f;
-                    stage[q].y = pn + 1u < llen[q] ? src[1] : 0.0f;
-                    stage[q].z = pn + 2u < llen[q] ? src[2] : 0.0f;
-                    stage[q].w = pn + 3u < llen[q] ? src[3] : 0.0f;
+                    stage[q].x = pn + 0u < llen[q] ? F::word(src[0]) : 0u;
+                    stage[q].y = pn + 1u < llen[q] ? F::word(src[1]) : 0u;
+                    stage[q].z = pn + 2u < llen[q] ? F::word(src[2]) : 0u;
+                    stage[q].w = pn + 3u < llen[q] ? F::word(src[3]) : 0u;
                 }
             }
         }
@@ -245,11 +262,11 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, float &pk, const RgT
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4 *>(wtile + q * 1024 + lane * 16) = make_float4(stage[q].x, stage[q].y, stage[q].z, stage[q].w);
+            *reinterpret_cast<uint4 *>(wtile + q * 1024 + lane * 16) = make_uint4(stage[q].x, stage[q].y, stage[q].z, stage[q].w);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    auto read_piece = [&](int p) -> float4 { return *reinterpret_cast<const float4 *>(rrow + 16 * (p ^ rswz)); };
+    auto read_piece = [&](int p) -> uint4 { return *reinterpret_cast<const uint4 *>(rrow + 16 * (p ^ rswz)); };
 
     load_tile(0);
     for (uint32_t tile = 0; tile < ntiles; ++tile) {
@@ -257,19 +274,19 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, float &pk, const RgT
         if (tile + 1 < ntiles) load_tile(tile + 1);  // in flight during this tile's arithmetic
         const uint32_t n0 = tile * RG_TM_TILE;
         const int np = L - n0 >= RG_TM_TILE ? 4 : (int)((L - n0) >> 2);  // full 4-frame pieces in this tile
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (np) v = read_piece(0);
 #pragma unroll 1
         for (int p = 0; p < np; ++p) {
-            const float4 vn = p + 1 < np ? read_piece(p + 1) : v;
-            const float f[4] = {v.x, v.y, v.z, v.w};
+            const uint4 vn = p + 1 < np ? read_piece(p + 1) : v;
+            const uint32_t f[4] = {v.x, v.y, v.z, v.w};
             const uint32_t n = n0 + 4u * p;
             if (n < H) {  // all 12 transient moments live (H is a multiple of 4)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     double row[12];
                     tm_load_row<12>(row, T12 + (size_t)(n + u) * 12);
-                    tm_frame<12, TAIL>(st, f[u], pk, row, K, n + u, len);
+                    tm_frame<FMT, 12, TAIL>(st, f[u], pk, row, K, n + u, len);
                 }
             } else {  // only the slow (Butterworth) pair
                 double rows[8];
@@ -278,7 +295,7 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, float &pk, const RgT
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const double tr[2] = {rows[2 * u], rows[2 * u + 1]};
-                    tm_frame<2, TAIL>(st, f[u], pk, tr, K, n + u, len);
+                    tm_frame<FMT, 2, TAIL>(st, f[u], pk, tr, K, n + u, len);
                 }
             }
             v = vn;
@@ -287,14 +304,14 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, float &pk, const RgT
             // L & 3 trailing frames, in this (the last) tile
             for (uint32_t n = L & ~3u; n < L; ++n) {
                 const uint32_t o = n - n0;
-                const float f = *reinterpret_cast<const float *>(rrow + 16 * ((int)(o >> 2) ^ rswz) + 4 * (o & 3));
+                const uint32_t f = *reinterpret_cast<const uint32_t *>(rrow + 16 * ((int)(o >> 2) ^ rswz) + 4 * (o & 3));
                 if (n < H) {
                     double row[12];
                     tm_load_row<12>(row, T12 + (size_t)n * 12);
-                    tm_frame<12, TAIL>(st, f, pk, row, K, n, len);
+                    tm_frame<FMT, 12, TAIL>(st, f, pk, row, K, n, len);
                 } else {
                     const double tr[2] = {T2[(size_t)(n - H) * 2], T2[(size_t)(n - H) * 2 + 1]};
-                    tm_frame<2, TAIL>(st, f, pk, tr, K, n, len);
+                    tm_frame<FMT, 2, TAIL>(st, f, pk, tr, K, n, len);
                 }
             }
         }
@@ -347,7 +364,7 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
     typename F::peak_t pk = 0;
 
     bool done = false;
-    if constexpr (FMT == RG_FMT_F32_PLANAR) {
+    {
         if (lds_tables) {
             done = true;
             // ---- block-shared tables, one packed image: T12[n][12] for n < H, then T2[n - H][2] -------------
@@ -375,9 +392,9 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
             // of the channel go through the element-wise staging of the TAIL variant too
             const bool plain = len == L && start + ((L + 3u) & ~3u) <= tr.frames;
             if (__all(plain))
-                tm_fast_path<false>(st, pk, K, L, H, chp, tr.frames, wave_seg0, len, T12, T2, wtile);
+                tm_fast_path<FMT, false>(st, pk, K, L, H, chp, tr.frames, wave_seg0, len, T12, T2, wtile);
             else if (__any(len != 0))
-                tm_fast_path<true>(st, pk, K, L, H, chp, tr.frames, wave_seg0, len, T12, T2, wtile);
+                tm_fast_path<FMT, true>(st, pk, K, L, H, chp, tr.frames, wave_seg0, len, T12, T2, wtile);
         }
     }
     if (!done) {
@@ -651,7 +668,7 @@ static hipError_t launch_main_fmt(int nch, const RgTmCoef &K, const RgTmGeom &G,
     // LDS: T12 (H10 x 12 doubles) + T2 ((L - H10) x 2 doubles) + one 4 KiB PCM tile per wave
     size_t lds = ((size_t)G.H10 * 12 + (size_t)(G.L - G.H10) * 2) * sizeof(double) +
                  (size_t)(RG_TM_BLOCK / 64) * RG_TM_WAVE_TILE_BYTES;
-    uint32_t lds_tables = FMT == RG_FMT_F32_PLANAR && lds <= 96 * 1024 ? 1u : 0u;
+    uint32_t lds_tables = lds <= 96 * 1024 ? 1u : 0u;
     if (!lds_tables) lds = 0;
     static bool attr_set = false;
     if (lds > 48 * 1024 && !attr_set) {
