@@ -215,7 +215,8 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
         // FP64 issue efficiency by waves per SIMD (tools/ubench/frame.hip: 188 / 160 / 147 cycles per frame)
         const double wps = std::min(blocks_cu, std::max(1.0, waves / 1024.0));
         const double eff = wps >= 3.0 ? 1.0 : (wps >= 2.0 ? 1.09 + (3.0 - wps) * 0.0 : 1.28 - (wps - 1.0) * 0.19);
-        const double tm = rounds * cost * eff;
+        // tables that do not fit the kernel's LDS budget (96 KiB) send the whole launch down the generic path
+        const double tm = rounds * cost * eff * (lds > 96.0 * 1024.0 ? 8.0 : 1.0);
         if (tm < best) { best = tm; bestL = L; }
     }
     // walk outwards from the best candidate until one designs (tiny L can need too many scan rounds)
