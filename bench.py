@@ -56,6 +56,7 @@ def main() -> int:
     ap.add_argument("--minutes", type=float, default=10.0, help="track length (default: BASELINE's 10 min)")
     ap.add_argument("--tm-segment", type=int, default=0, help="force variant 2 segment length (tuning)")
     ap.add_argument("--slots", type=int, default=0, help="pipeline slots of the library (0 = default)")
+    ap.add_argument("--album", action="store_true", help="force the album path (collectives) even on one GPU")
     ap.add_argument("--cpu-reps", type=int, default=16, help="oracle repetitions for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -77,7 +78,7 @@ def main() -> int:
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or (args.album and "RANK" in os.environ):
         import torch.distributed as dist  # noqa: PLC0415
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -110,8 +111,8 @@ def main() -> int:
     pcm_bytes = pcm.numel() * 4
     torch.cuda.synchronize()
 
-    album = world > 1
-    views = {}  # the library rotates through pipeline slots: one pair of tensor views per slot
+    album = world > 1 or args.album
+    views = {}  # the library rotates through pipeline slots: one set of tensor views / gather buffers per slot
 
     def step():
         an.enqueue_device(descs, ntr, pcm.data_ptr(), pcm_bytes, album=album)
@@ -119,11 +120,14 @@ def main() -> int:
             view = an.device_view()
             if view.d_album_hist not in views:
                 views[view.d_album_hist] = (
-                    torch.as_tensor(_DevArray(view.d_album_hist, (_capi.HISTOGRAM_SIZE,), "<i4"), device="cuda"),
-                    torch.as_tensor(_DevArray(view.d_album_peak, (1,), "<f8"), device="cuda"))
-            hist_t, peak_t = views[view.d_album_hist]
-            # LoudnessHistogram::accumulate / album_peak.max across ranks (replaygain.rs:1056-1059)
-            album_mod.allreduce_album(hist_t, peak_t)
+                    torch.as_tensor(_DevArray(view.d_album_hist, (album_mod.ALBUM_PACK_WORDS,), "<i4"), device="cuda"),
+                    torch.empty(world * album_mod.ALBUM_PACK_WORDS, dtype=torch.int32, device="cuda"))
+            pack_t, gathered_t = views[view.d_album_hist]
+            # LoudnessHistogram::accumulate / album_peak.max across ranks (replaygain.rs:1056-1059) as ONE
+            # collective: all-gather the 48 KB [histogram | peak] packs, fold them on the device
+            if dist is not None:
+                album_mod.allgather_album(pack_t, gathered_t)
+                an.album_reduce_gathered(gathered_t.data_ptr(), world)
             an.album_result_enqueue()
 
     def fence():
@@ -213,7 +217,7 @@ def main() -> int:
                 "workload": ("configs[1]: 1 track, 10 min synthetic 44.1 kHz stereo PCM resident in HBM" if world == 1 and ntr == 1 and frames == FRAMES_10MIN
                              else f"album mode: {ntr} x {frames / RATE / 60:.1f}-min 44.1 kHz stereo track(s) per GPU, {world} GPU(s)"),
                 "tracks_per_gpu": ntr, "frames_per_track": frames, "sample_rate": RATE,
-                "mode": "album (-a), RCCL all-reduce of the 12000-bin histogram + peak" if album else "track (-r)",
+                "mode": "album (-a): RCCL all-gather of the per-rank [12000-bin histogram | peak] packs + device fold" if album else "track (-r)",
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

@@ -132,14 +132,16 @@ int rg_rate_design_info(uint32_t sample_rate, int *stable, uint32_t *halo_frames
 rg_ctx *rg_create(int device);
 void rg_destroy(rg_ctx *ctx);
 const char *rg_last_error(const rg_ctx *ctx);
-/* Attach a caller-owned HIP stream (hipStream_t as void*; NULL detaches).  The analysis kernels keep
+/* Attach (attach = 1) a caller-owned HIP stream, given as void*; NULL then means the HIP default stream,
+ * which is what torch.cuda.current_stream().cuda_stream is unless the caller switched streams.
+ * attach = 0 detaches (the stream argument is ignored).  The analysis kernels keep
  * running on the context's own pipeline streams; the caller's stream is used for (a) input ordering:
  * the first enqueue after rg_set_stream / rg_wait_user_stream / rg_synth_fill_device waits for
  * everything submitted to it so far, and (b) the album tail: after an album enqueue the caller's
  * stream waits for the batch, and rg_album_allreduce / rg_album_result_enqueue / rg_album_finish run
  * on it, so that a collective the caller issues on that stream (RCCL through torch.distributed, say)
  * sits between them in stream order. */
-int rg_set_stream(rg_ctx *ctx, void *hip_stream);
+int rg_set_stream(rg_ctx *ctx, void *hip_stream, int attach);
 /* order the next enqueue behind everything submitted to the caller's stream so far (PCM produced there) */
 int rg_wait_user_stream(rg_ctx *ctx);
 /* kernel variant: 0 = auto, 1 = halo-tiled reference kernel, 2 = transient-moment kernel */
@@ -183,6 +185,12 @@ int rg_collect(rg_ctx *ctx, rg_track_result *tracks_out, uint32_t *hist_out);
  * (an ncclComm_t; NULL = single GPU, no-op).  The RCCL entry points are resolved from the
  * already-loaded process image first, then from librccl.so. */
 int rg_album_allreduce(rg_ctx *ctx, void *nccl_comm);
+/* The same exchange as ONE collective: d_album_hist and d_album_peak are contiguous (12000 u32 + one f64 =
+ * 12002 words, RG_ALBUM_PACK_WORDS).  All-gather every rank's pack (ncclAllGather / all_gather_into_tensor),
+ * then this call folds the `world` gathered packs (sum of bins, max of peaks) into this context's album
+ * histogram / peak, on the same stream as the other album-tail calls. */
+#define RG_ALBUM_PACK_WORDS (RG_HISTOGRAM_SIZE + 2)
+int rg_album_reduce_gathered(rg_ctx *ctx, const void *d_gathered, uint32_t world);
 /* percentile scan of d_album_hist on the device, result to host */
 int rg_album_finish(rg_ctx *ctx, rg_album_result *album_out, uint32_t *album_hist_out);
 /* the same scan, enqueued only: the rg_album_result stays in HBM until rg_album_finish */

@@ -97,7 +97,7 @@ SYMBOLS = [
     ("rg_create", _vp, [_int]),
     ("rg_destroy", None, [_vp]),
     ("rg_last_error", C.c_char_p, [_vp]),
-    ("rg_set_stream", _int, [_vp, _vp]),
+    ("rg_set_stream", _int, [_vp, _vp, _int]),
     ("rg_wait_user_stream", _int, [_vp]),
     ("rg_set_kernel", _int, [_vp, _int]),
     ("rg_set_tuning", _int, [_vp, _int, C.c_int64]),
@@ -110,6 +110,7 @@ SYMBOLS = [
     ("rg_collect", _int, [_vp, _P(TrackResult), _vp]),
     ("rg_album_allreduce", _int, [_vp, _vp]),
     ("rg_album_finish", _int, [_vp, _P(AlbumResult), _vp]),
+    ("rg_album_reduce_gathered", _int, [_vp, _vp, _u32]),
     ("rg_album_result_enqueue", _int, [_vp]),
     ("rg_timing_enable", _int, [_vp, _int]),
     ("rg_timing_read", _int, [_vp, _P(_dbl), _P(_u64), _P(_dbl), _int]),

@@ -25,17 +25,36 @@ def shard_indices(n_tracks: int, world: int, rank: int) -> List[int]:
     return list(range(rank, n_tracks, world))
 
 
-def allreduce_album(hist_i32, peak_f64, group=None) -> None:
+def allreduce_album(hist_i32, peak_f64, group=None, even_if_alone: bool = False) -> None:
     """In-place: histogram bins summed, peak maximised over the ranks of `group`.
 
     hist_i32: int32 tensor [12000] (a view of the context's d_album_hist, or a CPU tensor in tests);
     peak_f64: float64 tensor [1]."""
     import torch.distributed as dist
 
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not even_if_alone):
         return
     dist.all_reduce(hist_i32, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(peak_f64, op=dist.ReduceOp.MAX, group=group)
+
+
+ALBUM_PACK_WORDS = _capi.HISTOGRAM_SIZE + 2  # 12000 bins + the f64 peak, contiguous in the context (RG_ALBUM_PACK_WORDS)
+
+
+def allgather_album(pack_i32, gathered_i32, group=None) -> None:
+    """One collective instead of two: every rank's [histogram | peak] pack (int32[12002]) into
+    gathered_i32 (int32[world * 12002]); fold with Analyzer.album_reduce_gathered / fold_gathered."""
+    import torch.distributed as dist
+
+    dist.all_gather_into_tensor(gathered_i32, pack_i32, group=group)
+
+
+def fold_gathered(gathered_u32: np.ndarray, world: int):
+    """Host restatement of rg_album_reduce_gathered_kernel (tests): -> (hist uint32[12000], peak)."""
+    g = np.ascontiguousarray(gathered_u32, dtype=np.uint32).reshape(world, ALBUM_PACK_WORDS)
+    hist = g[:, :_capi.HISTOGRAM_SIZE].sum(axis=0, dtype=np.uint64).astype(np.uint32)
+    peaks = g[:, _capi.HISTOGRAM_SIZE:].copy().view(np.float64).reshape(world)
+    return hist, float(peaks.max()) if world else 0.0
 
 
 def album_result_from_hist(hist_u32: np.ndarray, peak: float) -> dict:

@@ -28,6 +28,7 @@ hipError_t rg_launch_track_results(const uint32_t *, const unsigned long long *,
 hipError_t rg_launch_album_merge(const uint32_t *, const unsigned long long *, uint32_t, uint32_t *, double *,
                                  hipStream_t);
 hipError_t rg_launch_album_result(const uint32_t *, const double *, rg_album_result *, hipStream_t);
+hipError_t rg_launch_album_reduce_gathered(const uint32_t *, uint32_t, uint32_t *, double *, hipStream_t);
 hipError_t rg_launch_peak_all(const void *, uint64_t, uint32_t, unsigned long long *, hipStream_t);
 hipError_t rg_launch_synth_fill(float *, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, hipStream_t);
 }
@@ -90,7 +91,7 @@ int drain_timing(rg_ctx *c) {
 int sync_all(rg_ctx *c) {
     for (int k = 0; k < RG_MAX_SLOTS; ++k)
         if (c->slots[k].stream) RG_HIP(c, hipStreamSynchronize(c->slots[k].stream));
-    if (c->user_stream) RG_HIP(c, hipStreamSynchronize(c->user_stream));
+    if (c->user_attached) RG_HIP(c, hipStreamSynchronize(c->user_stream));
     return RG_OK;
 }
 
@@ -179,8 +180,9 @@ extern "C" rg_ctx *rg_create(int device) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&S.staging_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&S.batch_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&S.album_done, hipEventDisableTiming);
-        if (e == hipSuccess) e = S.d_album_hist.reserve(RG_HISTOGRAM_SIZE);
-        if (e == hipSuccess) e = S.d_album_peak.reserve(1);
+        // [album histogram 12000 x u32 | album peak f64]: one contiguous pack, so that one all-gather moves both
+        if (e == hipSuccess) e = S.d_album_hist.reserve(RG_HISTOGRAM_SIZE + 2);
+        if (e == hipSuccess) S.d_album_peak.p = reinterpret_cast<double *>(S.d_album_hist.p + RG_HISTOGRAM_SIZE);
         if (e == hipSuccess) e = S.d_album_result.reserve(1);
         if (e == hipSuccess) e = S.h_album_result.reserve(1);
     }
@@ -225,7 +227,7 @@ extern "C" void rg_destroy(rg_ctx *c) {
         S.d_results.release();
         S.h_results.release();
         S.d_album_hist.release();
-        S.d_album_peak.release();
+        S.d_album_peak.p = nullptr;  // lives inside d_album_hist
         S.d_album_result.release();
         S.h_album_result.release();
         if (S.staging_done) (void)hipEventDestroy(S.staging_done);
@@ -241,19 +243,20 @@ extern "C" void rg_destroy(rg_ctx *c) {
     delete c;
 }
 
-extern "C" int rg_set_stream(rg_ctx *c, void *s) {
+extern "C" int rg_set_stream(rg_ctx *c, void *s, int attach) {
     if (!c) return RG_ERR_INVALID_ARG;
     if (rg_bind_device(c) != RG_OK) return RG_ERR_DEVICE;
     int rc = sync_all(c);
     if (rc != RG_OK) return rc;
-    c->user_stream = (hipStream_t)s;
-    c->user_dirty = s != nullptr;
+    c->user_stream = attach ? (hipStream_t)s : nullptr;
+    c->user_attached = attach != 0;
+    c->user_dirty = c->user_attached;
     return RG_OK;
 }
 
 extern "C" int rg_wait_user_stream(rg_ctx *c) {
     if (!c) return RG_ERR_INVALID_ARG;
-    c->user_dirty = c->user_stream != nullptr;
+    c->user_dirty = c->user_attached;
     return RG_OK;
 }
 
@@ -372,13 +375,27 @@ extern "C" int rg_collect(rg_ctx *c, rg_track_result *out, uint32_t *hist_out) {
     return RG_OK;
 }
 
+extern "C" int rg_album_reduce_gathered(rg_ctx *c, const void *d_gathered, uint32_t world) {
+    if (!c || !d_gathered || world == 0) return RG_ERR_INVALID_ARG;
+    if (!c->slot().album_ready) return rg_set_err(c, RG_ERR_STATE, "rg_album_reduce_gathered without an album enqueue");
+    int rc = rg_bind_device(c);
+    if (rc != RG_OK) return rc;
+    RG_HIP(c, rg_launch_album_reduce_gathered((const uint32_t *)d_gathered, world, c->slot().d_album_hist.p,
+                                              c->slot().d_album_peak.p, c->album_stream()));
+    if (c->user_attached) {
+        RG_HIP(c, hipEventRecord(c->slot().album_done, c->user_stream));
+        c->slot().album_pending = true;
+    }
+    return RG_OK;
+}
+
 extern "C" int rg_album_result_enqueue(rg_ctx *c) {
     if (!c) return RG_ERR_INVALID_ARG;
     if (!c->slot().album_ready) return rg_set_err(c, RG_ERR_STATE, "rg_album_result_enqueue without an album enqueue");
     int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
     RG_HIP(c, rg_launch_album_result(c->slot().d_album_hist.p, c->slot().d_album_peak.p, c->slot().d_album_result.p, c->album_stream()));
-    if (c->user_stream) {
+    if (c->user_attached) {
         RG_HIP(c, hipEventRecord(c->slot().album_done, c->user_stream));
         c->slot().album_pending = true;
     }
@@ -433,7 +450,7 @@ extern "C" int rg_album_allreduce(rg_ctx *c, void *comm) {
     if (r == 0) r = ar(c->slot().d_album_peak.p, c->slot().d_album_peak.p, 1, kNcclFloat64, kNcclMax, comm, c->album_stream());
     int r2 = ge();
     if (r != 0 || r2 != 0) return rg_set_err(c, RG_ERR_COLLECTIVE, "ncclAllReduce failed (%d/%d)", r, r2);
-    if (c->user_stream) {
+    if (c->user_attached) {
         RG_HIP(c, hipEventRecord(c->slot().album_done, c->user_stream));
         c->slot().album_pending = true;
     }
@@ -479,12 +496,12 @@ extern "C" int rg_find_peak_pcm(rg_ctx *c, const rg_track_desc *track, const voi
     int rc = stage_pcm(c, pcm_base, pcm_bytes, on_device, &d_base);
     if (rc != RG_OK) return rc;
     RG_HIP(c, c->d_peak_bits.reserve(1));
-    RG_HIP(c, hipMemsetAsync(c->d_peak_bits.p, 0, sizeof(unsigned long long), (c->user_stream ? c->user_stream : c->slot().stream)));
+    RG_HIP(c, hipMemsetAsync(c->d_peak_bits.p, 0, sizeof(unsigned long long), (c->user_attached ? c->user_stream : c->slot().stream)));
     RG_HIP(c, rg_launch_peak_all((const unsigned char *)d_base + track->offset_bytes, total, track->format,
-                                 c->d_peak_bits.p, (c->user_stream ? c->user_stream : c->slot().stream)));
+                                 c->d_peak_bits.p, (c->user_attached ? c->user_stream : c->slot().stream)));
     unsigned long long bits = 0;
-    RG_HIP(c, hipMemcpyAsync(&bits, c->d_peak_bits.p, sizeof bits, hipMemcpyDeviceToHost, (c->user_stream ? c->user_stream : c->slot().stream)));
-    RG_HIP(c, hipStreamSynchronize((c->user_stream ? c->user_stream : c->slot().stream)));
+    RG_HIP(c, hipMemcpyAsync(&bits, c->d_peak_bits.p, sizeof bits, hipMemcpyDeviceToHost, (c->user_attached ? c->user_stream : c->slot().stream)));
+    RG_HIP(c, hipStreamSynchronize((c->user_attached ? c->user_stream : c->slot().stream)));
     double pk;
     memcpy(&pk, &bits, sizeof pk);
     out->peak = pk;
@@ -499,10 +516,10 @@ extern "C" int rg_synth_fill_device(rg_ctx *c, void *d_dst, uint64_t seed, uint3
     if (!c || (!d_dst && frames)) return RG_ERR_INVALID_ARG;
     int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
-    hipStream_t fs = c->user_stream ? c->user_stream : c->slot().stream;
+    hipStream_t fs = c->user_attached ? c->user_stream : c->slot().stream;
     RG_HIP(c, rg_launch_synth_fill((float *)d_dst, seed, channel, sample_rate, first_frame, frames, fs));
     // every pipeline stream must see the generated PCM: the next enqueue waits for this point
-    if (!c->user_stream) RG_HIP(c, hipEventRecord(c->user_ev, fs));
+    if (!c->user_attached) RG_HIP(c, hipEventRecord(c->user_ev, fs));
     c->user_dirty = true;
     return RG_OK;
 }

@@ -78,6 +78,30 @@ rg_album_merge_kernel(const uint32_t *__restrict__ hist, const unsigned long lon
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same merge one level up: every rank's [album histogram | album peak] pack (12000 + 2 words) after
+// an all-gather, `world` packs back to back -> this rank's album histogram / peak.  One collective
+// instead of an all-reduce(sum) plus an all-reduce(max).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+rg_album_reduce_gathered_kernel(const uint32_t *__restrict__ g, uint32_t world, uint32_t *__restrict__ album_hist,
+                                double *__restrict__ album_peak) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const size_t pack = RG_HISTOGRAM_SIZE + 2;
+    if (b < RG_HISTOGRAM_SIZE) {
+        uint32_t s = 0;
+        for (uint32_t r = 0; r < world; ++r) s += g[(size_t)r * pack + b];
+        album_hist[b] = s;
+    } else if (b == RG_HISTOGRAM_SIZE) {
+        double m = 0.0;
+        for (uint32_t r = 0; r < world; ++r) {
+            const double p = *reinterpret_cast<const double *>(g + (size_t)r * pack + RG_HISTOGRAM_SIZE);
+            m = p > m ? p : m;
+        }
+        *album_peak = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // find_peak_amplitude's scan (src/replaygain.rs:1210-1241): max |x| over ALL channels, normalised.
 // `total` samples = channels * frames, contiguous because the layout is planar.
 // ---------------------------------------------------------------------------------------------
@@ -137,6 +161,14 @@ extern "C" hipError_t rg_launch_album_merge(const uint32_t *d_hist, const unsign
     const int nb = (RG_HISTOGRAM_SIZE + 255) / 256;
     hipLaunchKernelGGL(rg_album_merge_kernel, dim3(nb + 1), dim3(256), 0, s, d_hist, d_peak_bits, n_tracks,
                        d_album_hist, d_album_peak);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rg_launch_album_reduce_gathered(const uint32_t *d_gathered, uint32_t world, uint32_t *d_album_hist,
+                                                      double *d_album_peak, hipStream_t s) {
+    const int nb = (RG_HISTOGRAM_SIZE + 1 + 255) / 256;
+    hipLaunchKernelGGL(rg_album_reduce_gathered_kernel, dim3(nb), dim3(256), 0, s, d_gathered, world, d_album_hist,
+                       d_album_peak);
     return hipGetLastError();
 }
 

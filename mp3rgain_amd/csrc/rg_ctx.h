@@ -108,11 +108,12 @@ struct rg_ctx {
     RgSlot slots[RG_MAX_SLOTS];
     int cur = 0;                        // slot of the most recent enqueue
     hipStream_t user_stream = nullptr;  // rg_set_stream: the album tail (collectives, album percentile) runs on it
+    bool user_attached = false;         // user_stream may legitimately be the HIP default stream (nullptr)
     hipEvent_t user_ev = nullptr;
     bool user_dirty = false;            // the next enqueue must first wait for what was submitted to user_stream
     RgSlot &slot() { return slots[cur]; }
     // stream on which the album tail (all-reduce, album percentile, its D2H) runs
-    hipStream_t album_stream() { return user_stream ? user_stream : slots[cur].stream; }
+    hipStream_t album_stream() { return user_attached ? user_stream : slots[cur].stream; }
 
     RgRateDesign design[RG_NUM_RATES];
     DevBuf<RgCoefDev> d_coefs;

@@ -272,7 +272,7 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
     RgSlot &S = c->slot();
     hipStream_t s = S.stream;
     if (c->user_dirty) {  // inputs produced on the caller's stream (or by rg_synth_fill_device) must be complete first
-        if (c->user_stream) RG_HIP(c, hipEventRecord(c->user_ev, c->user_stream));
+        if (c->user_attached) RG_HIP(c, hipEventRecord(c->user_ev, c->user_stream));
         for (int k = 0; k < RG_MAX_SLOTS; ++k) RG_HIP(c, hipStreamWaitEvent(c->slots[k].stream, c->user_ev, 0));
         c->user_dirty = false;
     }
@@ -457,7 +457,7 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
         RG_HIP(c, rg_launch_album_merge(S.d_hist.p, S.peak_ptr, (uint32_t)n, S.d_album_hist.p,
                                         S.d_album_peak.p, s));
         S.album_ready = true;
-        if (c->user_stream) {  // the caller's collective (on its own stream) follows the merge
+        if (c->user_attached) {  // the caller's collective (on its own stream) follows the merge
             RG_HIP(c, hipEventRecord(S.batch_done, s));
             RG_HIP(c, hipStreamWaitEvent(c->user_stream, S.batch_done, 0));
         }

@@ -197,7 +197,12 @@ class Analyzer:
         return self._ctx
 
     def set_stream(self, hip_stream: Optional[int]):
-        self._check(self._lib.rg_set_stream(self._ctx, hip_stream))
+        """Attach a HIP stream handle (0 = the default stream, e.g. torch.cuda.current_stream().cuda_stream);
+        None detaches."""
+        if hip_stream is None:
+            self._check(self._lib.rg_set_stream(self._ctx, None, 0))
+        else:
+            self._check(self._lib.rg_set_stream(self._ctx, hip_stream or None, 1))
 
     def wait_user_stream(self):
         """Order the next enqueue behind what the attached stream has been given so far."""
@@ -265,6 +270,9 @@ class Analyzer:
 
     def album_allreduce(self, nccl_comm: Optional[int] = None):
         self._check(self._lib.rg_album_allreduce(self._ctx, nccl_comm))
+
+    def album_reduce_gathered(self, d_gathered: int, world: int):
+        self._check(self._lib.rg_album_reduce_gathered(self._ctx, d_gathered, world))
 
     def album_result_enqueue(self):
         self._check(self._lib.rg_album_result_enqueue(self._ctx))

@@ -51,6 +51,15 @@ def _worker(rank, world, port, outdir):
     peak_t = torch.tensor([peak], dtype=torch.float64)
     album.allreduce_album(hist_t, peak_t)
     merged = hist_t.numpy().view(np.uint32)
+    # the single-collective variant bench.py uses: all-gather the [histogram | peak] packs, fold locally
+    pack = np.zeros(album.ALBUM_PACK_WORDS, dtype=np.uint32)
+    pack[:12000] = hist
+    pack[12000:] = np.array([peak], dtype=np.float64).view(np.uint32)
+    pack_t = torch.from_numpy(pack.view(np.int32).copy())
+    gathered_t = torch.empty(world * album.ALBUM_PACK_WORDS, dtype=torch.int32)
+    album.allgather_album(pack_t, gathered_t)
+    h2, p2 = album.fold_gathered(gathered_t.numpy().view(np.uint32), world)
+    assert np.array_equal(h2, merged) and p2 == float(peak_t.item())
     alb = album.album_result_from_hist(merged, float(peak_t.item()))
     ordered = album.gather_track_results(local_results, len(LENS))
     np.save(Path(outdir) / f"hist_{rank}.npy", merged)

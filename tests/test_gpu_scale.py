@@ -115,3 +115,41 @@ def test_mixed_48k_mono_and_hot_tracks(analyzer, oracle):
             assert rg.replaygain.clip_limit_steps(g.gain_steps(), g.gain_db, g.peak, bool(k)) == \
                 L.rgo_clip_limit_steps(w["gain_steps"], w["gain_db"], w["peak"], k, 0)
     assert got[3].peak == 1.0 and got[4].peak == 1.0
+
+
+def test_attached_stream_orders_the_album_tail(analyzer, oracle):
+    """rg_set_stream(default stream): work the caller submits to its stream right after an album enqueue (here a
+    torch copy of the [histogram | peak] pack, in production the RCCL collective) sees the merged histogram, and
+    the fold + album percentile that follow on that stream see the caller's result."""
+    import torch
+
+    from mp3rgain_amd import album
+
+    lens = [RATE * 15, RATE * 9 + 7]
+    seeds = [0x5EED4000, 0x5EED4001]
+    buf, descs = _device_batch(analyzer, seeds, lens)
+    analyzer.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        want_h = np.zeros(12000, dtype=np.uint32)
+        peaks = []
+        for s, f in zip(seeds, lens):
+            r, h = oracle.analyze_pcm(oracle.synth_f32(s, 0, RATE, f), oracle.synth_f32(s, 1, RATE, f), RATE)
+            want_h += h
+            peaks.append(r["peak"])
+
+        class _View:
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 3}
+
+        for rep in range(6):  # every pipeline slot at least once
+            analyzer.enqueue_device(descs, 2, buf.data_ptr(), buf.numel() * 4, album=True)
+            view = analyzer.device_view()
+            pack = torch.as_tensor(_View(view.d_album_hist, album.ALBUM_PACK_WORDS), device="cuda")
+            gathered = torch.cat([pack, pack])  # stands in for the all-gather of a 2-rank job, on the caller's stream
+            analyzer.album_reduce_gathered(gathered.data_ptr(), 2)
+            analyzer.album_result_enqueue()
+            alb, ah = analyzer.album_finish(want_hist=True)
+            assert np.array_equal(ah, 2 * want_h)  # two identical "ranks"
+            assert alb.album_peak == max(peaks) and alb.album_loudness_db == oracle.hist_loudness(2 * want_h)
+    finally:
+        analyzer.set_stream(None)
