@@ -38,21 +38,18 @@ struct RgLoudness {
     uint64_t total;
 };
 
-// All 256 threads cooperate: thread t owns bins [47t, 47t+47) in registers, a block-wide suffix scan of
-// the 256 chunk sums finds the one chunk in which the running count (from the top bin down) first
-// reaches the threshold, and that thread alone walks its 47 bins from the top.  The result is exactly
-// the sequential scan's.  LDS: 2 KiB.
+// All 256 threads cooperate: thread t owns bins [47t, 47t+47), a block-wide suffix scan of the 256 chunk
+// sums finds the one chunk in which the running count (from the top bin down) first reaches the threshold,
+// and that thread alone walks its 47 bins from the top.  The result is exactly the sequential scan's.
+// LDS: 2 KiB; no per-thread bin array (the kernels that inline this keep their register budget).
 static __device__ __forceinline__ RgLoudness rg_block_loudness(const uint32_t *__restrict__ h, uint64_t *scan /* LDS[256] */) {
     const int t = threadIdx.x;
-    uint32_t mine[RG_PCT_CHUNK];
-#pragma unroll
+    uint64_t s = 0;
+#pragma unroll 8
     for (int i = 0; i < RG_PCT_CHUNK; ++i) {
         const int b = t * RG_PCT_CHUNK + i;
-        mine[i] = b < RG_HISTOGRAM_SIZE ? h[b] : 0u;  // 47 independent loads in flight
+        s += b < RG_HISTOGRAM_SIZE ? h[b] : 0u;
     }
-    uint64_t s = 0;
-#pragma unroll
-    for (int i = 0; i < RG_PCT_CHUNK; ++i) s += mine[i];
     // inclusive suffix sum over threads: suffix[t] = sum_{u >= t} chunk[u]
     scan[t] = s;
     __syncthreads();
@@ -73,15 +70,16 @@ static __device__ __forceinline__ RgLoudness rg_block_loudness(const uint32_t *_
     __syncthreads();
     if (total != 0) {
         const uint64_t threshold = (uint64_t)ceil((double)total * RG_ONE_MINUS_PERCENTILE);
-        if (suffix >= threshold && above < threshold) {  // exactly one thread
+        if (suffix >= threshold && above < threshold) {  // exactly one thread: re-read its 47 bins from the top
             uint64_t count = above;
-            int found = -1;
-#pragma unroll
             for (int i = RG_PCT_CHUNK - 1; i >= 0; --i) {
-                count += mine[i];
-                if (found < 0 && count >= threshold) found = i;
+                const int b = t * RG_PCT_CHUNK + i;
+                count += b < RG_HISTOGRAM_SIZE ? h[b] : 0u;
+                if (count >= threshold) {
+                    res.loudness_db = (double)(b - RG_HISTOGRAM_OFFSET) / 100.0;
+                    break;
+                }
             }
-            res.loudness_db = (double)(t * RG_PCT_CHUNK + found - RG_HISTOGRAM_OFFSET) / 100.0;
         }
     }
     __syncthreads();

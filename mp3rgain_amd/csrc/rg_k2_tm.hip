@@ -444,6 +444,12 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
 // Fix-up kernel.  One lane = one segment (all channels).  Lanes [0, warm) of a block repeat the last
 // `warm` segments of the previous block so that every owner lane finds its 2^R predecessors in LDS.
 
+// Device-scope atomics are performed at the memory side; waiting for the returned value is waiting for that.
+template <typename V>
+__device__ __forceinline__ void tm_performed(V old) {
+    asm volatile("" ::"v"(old));
+}
+
 // sigma' G sigma for the packed upper triangle G (row major), evaluated as sum_j s_j (G_jj s_j / 2 + sum_{q>j} G_jq s_q) * 2
 template <typename GP>
 __device__ __forceinline__ double tm_quad_half(GP Gm, const double (&sg)[RG_TM_DIM]) {
@@ -474,7 +480,13 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     __shared__ double pieces[RG_TM_BLOCK];
     __shared__ int bins[RG_TM_BLOCK];
     __shared__ int is_last;
+    // the (at most one) segment of this block that the track ends in: its start state and length, for the
+    // cooperative evaluation of its quadratic term below
+    __shared__ double part_sg[NCH][RG_TM_DIM];
+    __shared__ uint32_t part_len;
+    __shared__ int part_lane;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) part_len = 0;
     // value of `x` held by the lane d (<= RG_TM_EDGE) positions below in the block, 0.0 before the block's first lane;
     // `slot` = index of x among the values exchanged in this step (all lanes call with the same sequence)
     auto publish_edge = [&](const double x, const int slot) {
@@ -500,17 +512,14 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     rg_cdouble *const X = (rg_cdouble *)FT.X;
     rg_cdouble *const S0 = (rg_cdouble *)FT.sigma0;
 
-    // ---- everything this lane needs from the segment records, issued up front ------------------------
-    double w[NCH][RG_TM_DIM], Bm[NCH][RG_TM_DIM], Am[NCH], pk = 0.0;
+    // ---- zero-state end states of this segment, all channels (the moments are fetched where they are used:
+    // the kernel is latency bound and lives on occupancy, so the live register set is kept small) ----------
+    double w[NCH][RG_TM_DIM], pk = 0.0;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const double *__restrict__ r = rec + (size_t)c * RG_TM_REC * total_recs + idx;
 #pragma unroll
         for (int j = 0; j < RG_TM_DIM; ++j) w[c][j] = seg_valid ? r[(size_t)(13 + j) * total_recs] : 0.0;
-#pragma unroll
-        for (int j = 0; j < RG_TM_DIM; ++j) Bm[c][j] = owner ? r[(size_t)(1 + j) * total_recs] : 0.0;
-        Am[c] = owner ? r[0] : 0.0;
-        if (owner) pk = fmax(pk, r[(size_t)25 * total_recs]);
     }
     // zero-state end state in block-diagonal coordinates: t' = t + X s; virtual segment -1 carries the
     // track-start state
@@ -585,20 +594,46 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
         const bool full = len == G.L;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
+            const double *__restrict__ r = rec + (size_t)c * RG_TM_REC * total_recs + idx;
             double sg[RG_TM_DIM];
 #pragma unroll
             for (int j = 0; j < RG_TM_DIM; ++j) sg[j] = sgm[c][j];
             double lin = 0.0;
 #pragma unroll
-            for (int j = 0; j < RG_TM_DIM; ++j) lin = fma(Bm[c][j], sg[j], lin);
-            double quad;
-            if (full) quad = tm_quad_half((rg_cdouble *)FT.Gp + (size_t)(G.L - 1) * RG_TM_GRAM, sg);  // wave-uniform table
-            else quad = tm_quad_half(FT.Gp + (size_t)(len - 1) * RG_TM_GRAM, sg);
-            S += Am[c] + 2.0 * (lin + quad);
+            for (int j = 0; j < RG_TM_DIM; ++j) lin = fma(r[(size_t)(1 + j) * total_recs], sg[j], lin);
+            pk = fmax(pk, r[(size_t)25 * total_recs]);
+            // full segments share one Gram matrix (wave-uniform, scalar loads).  The segment a track ends in
+            // needs the prefix matrix of its own length: 78 per-lane loads that would cost every lane of
+            // the kernel 150 VGPRs, so that one lane parks its state in LDS and wave 0 evaluates it below.
+            double quad = 0.0;
+            if (full) quad = tm_quad_half((rg_cdouble *)FT.Gp + (size_t)(G.L - 1) * RG_TM_GRAM, sg);
+            else {
+#pragma unroll
+                for (int j = 0; j < RG_TM_DIM; ++j) part_sg[c][j] = sg[j];
+                part_len = len;
+                part_lane = i;
+            }
+            S += r[0] + 2.0 * (lin + quad);
         }
     }
-    if (NCH == 1) S *= 2.0;  // add_mono_sample feeds both sums (src/replaygain.rs:731-740)
     pieces[i] = owner ? S : 0.0;
+    __syncthreads();
+    if (wave == 0 && part_len != 0) {
+        // term p of the packed upper triangle is G[p] s_j s_q (halved on the diagonal); two terms per lane
+        const double *__restrict__ Gm = FT.Gp + (size_t)(part_len - 1) * RG_TM_GRAM;
+        double quad = 0.0;
+        for (int p = lane; p < RG_TM_GRAM; p += 64) {
+            int j = 0, base = 0;
+            while (p >= base + RG_TM_DIM - j) { base += RG_TM_DIM - j; ++j; }
+            const int q = j + (p - base);
+            const double g = Gm[p] * (q == j ? 0.5 : 1.0);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) quad = fma(g * part_sg[c][j], part_sg[c][q], quad);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) quad += __shfl_xor(quad, off, 64);
+        if (lane == 0) pieces[part_lane] += 2.0 * quad;
+    }
     // peak of the block's segments: wave max, then one atomic per wave (the bit pattern of a
     // non-negative double is ordered like the value)
     {
@@ -608,7 +643,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
             const unsigned long long o = __shfl_xor(pb, off, 64);
             pb = o > pb ? o : pb;
         }
-        if ((i & 63) == 0 && pb != 0) atomicMax(&peak_bits[tr.track_index], pb);
+        if ((i & 63) == 0 && pb != 0) tm_performed(atomicMax(&peak_bits[tr.track_index], pb));
     }
     __syncthreads();
 
@@ -619,6 +654,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
         if (widx < tr.n_windows) {
             double total = 0.0;
             for (uint32_t q = 0; q < G.k; ++q) total += pieces[warm + i * G.k + q];
+            if (NCH == 1) total *= 2.0;  // add_mono_sample feeds both sums (src/replaygain.rs:731-740)
             const uint64_t rem = tr.frames - widx * G.W;
             const uint32_t n = rem < G.W ? (uint32_t)rem : G.W;
             bin = rg_window_bin(total, 0.0, n);
@@ -634,14 +670,16 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
         if (leader) {
             uint32_t count = 1;
             for (uint32_t q = i + 1; q < G.fix_windows; ++q) count += bins[q] == bin ? 1u : 0u;
-            atomicAdd(&hist[(size_t)tr.track_index * RG_HISTOGRAM_SIZE + bin], count);
+            tm_performed(atomicAdd(&hist[(size_t)tr.track_index * RG_HISTOGRAM_SIZE + bin], count));
         }
     }
 
     // ---- the last block of a track to get here finishes the track: percentile, gain, peak -> result
-    // (tail of analyze_track_internal, src/replaygain.rs:910-918).  Release: every thread's atomics are
-    // device-visible before the arrival counter moves; acquire: the finisher drops stale lines first.
-    __threadfence();
+    // (tail of analyze_track_internal, src/replaygain.rs:910-918).  Everything a block publishes goes through
+    // device-scope atomics whose results have come back (tm_performed) before the barrier, so the arrival
+    // counter moves after them without a release fence: an agent-scope release on this multi-XCD part writes
+    // the whole L2 back, and one per wave made that the most expensive thing in the kernel.  The finisher
+    // drops its XCD's possibly stale histogram lines before reading.
     __syncthreads();
     if (i == 0) is_last = atomicAdd(&done_count[tr.track_index], 1u) + 1u == tr.fix_blocks ? 1 : 0;
     __syncthreads();
