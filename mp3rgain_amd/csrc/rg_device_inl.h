@@ -31,56 +31,75 @@ static __device__ __forceinline__ int rg_window_bin(double lsum, double rsum, ui
 //   scan i = 11999 .. 0 accumulating; first i with count >= threshold -> (i - 2000) / 100.0
 // ---------------------------------------------------------------------------------------------
 #define RG_PCT_THREADS 256
-#define RG_PCT_CHUNK 47  // 256 * 47 = 12032 >= 12000
+#define RG_PCT_CHUNK 48    // bins per owner thread: twelve 16-byte loads
+#define RG_PCT_OWNERS 250  // 250 * 48 = 12000
 
 struct RgLoudness {
     double loudness_db;
     uint64_t total;
 };
 
-// All 256 threads cooperate: thread t owns bins [47t, 47t+47), a block-wide suffix scan of the 256 chunk
-// sums finds the one chunk in which the running count (from the top bin down) first reaches the threshold,
-// and that thread alone walks its 47 bins from the top.  The result is exactly the sequential scan's.
-// LDS: 2 KiB; no per-thread bin array (the kernels that inline this keep their register budget).
+// All 256 threads cooperate, and every step is one round of independent loads (the finisher of a track is
+// on the critical path of a whole batch): threads 0..249 own 48 consecutive bins each (twelve 16-byte loads),
+// a suffix scan over the 250 chunk sums (wave shuffles + one LDS hop) finds the one chunk in which the
+// running count from the top bin down first reaches the threshold, and wave 0 resolves the bin inside that
+// chunk with one load per lane and a ballot.  The result is exactly the sequential scan's.
+// LDS: scan[256] is used for the four wave totals and the crossing chunk.
 static __device__ __forceinline__ RgLoudness rg_block_loudness(const uint32_t *__restrict__ h, uint64_t *scan /* LDS[256] */) {
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     uint64_t s = 0;
+    if (t < RG_PCT_OWNERS) {
+        if (((uintptr_t)h & 15) == 0) {
+            const uint4 *__restrict__ h4 = reinterpret_cast<const uint4 *>(h) + t * (RG_PCT_CHUNK / 4);
+            uint4 v[RG_PCT_CHUNK / 4];
+#pragma unroll
+            for (int i = 0; i < RG_PCT_CHUNK / 4; ++i) v[i] = h4[i];
+#pragma unroll
+            for (int i = 0; i < RG_PCT_CHUNK / 4; ++i) s += (uint64_t)v[i].x + v[i].y + v[i].z + v[i].w;
+        } else {
 #pragma unroll 8
-    for (int i = 0; i < RG_PCT_CHUNK; ++i) {
-        const int b = t * RG_PCT_CHUNK + i;
-        s += b < RG_HISTOGRAM_SIZE ? h[b] : 0u;
+            for (int i = 0; i < RG_PCT_CHUNK; ++i) s += h[t * RG_PCT_CHUNK + i];
+        }
     }
     // inclusive suffix sum over threads: suffix[t] = sum_{u >= t} chunk[u]
-    scan[t] = s;
-    __syncthreads();
-    for (int d = 1; d < RG_PCT_THREADS; d <<= 1) {
-        const uint64_t add = t + d < RG_PCT_THREADS ? scan[t + d] : 0;
-        __syncthreads();
-        scan[t] += add;
-        __syncthreads();
+    uint64_t suffix = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t o = __shfl_down(suffix, d, 64);
+        if (lane + d < 64) suffix += o;
     }
-    const uint64_t total = scan[0];
-    const uint64_t suffix = scan[t];
-    const uint64_t above = t + 1 < RG_PCT_THREADS ? scan[t + 1] : 0;  // count of all bins above this chunk
+    if (lane == 0) scan[wave] = suffix;  // wave totals
+    __syncthreads();
+    uint64_t higher = 0;  // chunks of the waves above this one
+#pragma unroll
+    for (int w = 1; w < RG_PCT_THREADS / 64; ++w) higher += w > wave ? scan[w] : 0;
+    const uint64_t total = scan[0] + scan[1] + scan[2] + scan[3];
+    suffix += higher;
+    const uint64_t above = suffix - s;  // count of all bins above this chunk
     __shared__ RgLoudness res;  // one instance per kernel: the helper is called once per block
+    __shared__ int cross_chunk;
+    __shared__ uint64_t cross_above;
     if (t == 0) {
         res.loudness_db = -20.0;  // empty histogram, or the fall-through of src/replaygain.rs:681
         res.total = total;
     }
+    const uint64_t threshold = (uint64_t)ceil((double)total * RG_ONE_MINUS_PERCENTILE);
+    if (total != 0 && suffix >= threshold && above < threshold) {  // exactly one thread
+        cross_chunk = t;
+        cross_above = above;
+    }
     __syncthreads();
-    if (total != 0) {
-        const uint64_t threshold = (uint64_t)ceil((double)total * RG_ONE_MINUS_PERCENTILE);
-        if (suffix >= threshold && above < threshold) {  // exactly one thread: re-read its 47 bins from the top
-            uint64_t count = above;
-            for (int i = RG_PCT_CHUNK - 1; i >= 0; --i) {
-                const int b = t * RG_PCT_CHUNK + i;
-                count += b < RG_HISTOGRAM_SIZE ? h[b] : 0u;
-                if (count >= threshold) {
-                    res.loudness_db = (double)(b - RG_HISTOGRAM_OFFSET) / 100.0;
-                    break;
-                }
-            }
+    if (total != 0 && wave == 0) {
+        const int b = cross_chunk * RG_PCT_CHUNK + lane;
+        uint64_t c = lane < RG_PCT_CHUNK ? h[b] : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t o = __shfl_down(c, d, 64);
+            if (lane + d < 64) c += o;
         }
+        // the count from the top reaches the threshold at the highest bin whose suffix does
+        const unsigned long long m = __ballot(lane < RG_PCT_CHUNK && cross_above + c >= threshold);
+        if (lane == 0) res.loudness_db = (double)(cross_chunk * RG_PCT_CHUNK + (63 - __clzll((long long)m)) - RG_HISTOGRAM_OFFSET) / 100.0;
     }
     __syncthreads();
     return res;

@@ -471,7 +471,13 @@ __global__ void __launch_bounds__(RG_TM_BLOCK)
 rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__restrict__ tracks, uint32_t n_tracks,
                  const double *__restrict__ rec, uint32_t total_recs, uint32_t *__restrict__ hist,
                  unsigned long long *__restrict__ peak_bits, uint32_t *__restrict__ done_count,
-                 rg_track_result *__restrict__ results) {
+                 rg_track_result *__restrict__ results,
+                 unsigned long long *__restrict__ dbg /* nullptr, or 8 stage timestamps per block */) {
+#define TM_FIX_STAMP(k)                                                            \
+    do {                                                                           \
+        if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); \
+    } while (0)
+    TM_FIX_STAMP(0);
     // LDS (about 17 KiB, so that fix-up blocks fit next to resident main-kernel blocks of other pipeline
     // slots): lanes exchange scan values with wave shuffles; only the last RG_TM_EDGE lanes of each wave go
     // through LDS for the lanes of the next wave
@@ -509,8 +515,20 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     const bool seg_valid = in_block && seg >= 0 && seg < (long long)tr.nseg;
     const bool owner = seg_valid && i >= warm;
     const size_t idx = (size_t)tr.rec_base + (size_t)(seg_valid ? seg : 0);
-    rg_cdouble *const X = (rg_cdouble *)FT.X;
-    rg_cdouble *const S0 = (rg_cdouble *)FT.sigma0;
+    // ---- the wave-uniform tables, one contiguous image in the design blob (rg_enqueue.hip: the last prefix
+    // Gram matrix is followed by PhiY, PhiB, X, sigma0), copied to LDS under the record loads: as scalar
+    // loads they missed the constant cache in every wave and sat on the critical path of each scan round
+    __shared__ double ftab[RG_TM_GRAM + RG_TM_MAX_ROUNDS * 104 + 32];
+    {
+        const double *__restrict__ src = FT.Gp + (size_t)(G.L - 1) * RG_TM_GRAM;
+        const int n = RG_TM_GRAM + (int)G.rounds * 104 + 32;
+        for (int q = i; q < n; q += RG_TM_BLOCK) ftab[q] = src[q];
+    }
+    const double *const Gfull = ftab;
+    const double *const PhiY = ftab + RG_TM_GRAM;
+    const double *const PhiB = PhiY + G.rounds * 100;
+    const double *const X = PhiB + G.rounds * 4;
+    const double *const S0 = X + 20;
 
     // ---- zero-state end states of this segment, all channels (the moments are fetched where they are used:
     // the kernel is latency bound and lives on occupancy, so the live register set is kept small) ----------
@@ -523,6 +541,8 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     }
     // zero-state end state in block-diagonal coordinates: t' = t + X s; virtual segment -1 carries the
     // track-start state
+    __syncthreads();  // ftab
+    TM_FIX_STAMP(1);
     const bool vstart = in_block && seg == -1;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -555,19 +575,23 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
             for (int j = 0; j < RG_TM_DIM; ++j) wn[c][j] = (j >= 10 || fast) ? from_below(w[c][j], d, c * RG_TM_DIM + j) : 0.0;
         __syncthreads();
         if (fast) {
-            rg_cdouble *__restrict__ PY = (rg_cdouble *)FT.PhiY + (size_t)rd * 100;
+            const double *PY = PhiY + (size_t)rd * 100;
 #pragma unroll
             for (int a = 0; a < 10; ++a) {
+                double py[10];
+#pragma unroll
+                for (int q = 0; q < 10; ++q) py[q] = PY[a * 10 + q];
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     double acc = w[c][a];
 #pragma unroll
-                    for (int q = 0; q < 10; ++q) acc = fma(PY[a * 10 + q], wn[c][q], acc);
+                    for (int q = 0; q < 10; ++q) acc = fma(py[q], wn[c][q], acc);
                     w[c][a] = acc;
                 }
+                if (a & 1) __builtin_amdgcn_sched_barrier(0);  // two rows of the table in flight, not all ten
             }
         }
-        rg_cdouble *__restrict__ PB = (rg_cdouble *)FT.PhiB + (size_t)rd * 4;
+        const double *PB = PhiB + (size_t)rd * 4;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             w[c][10] = fma(PB[0], wn[c][10], fma(PB[1], wn[c][11], w[c][10]));
@@ -586,35 +610,59 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
 #pragma unroll
         for (int j = 0; j < RG_TM_DIM; ++j) sgm[c][j] = from_below(w[c][j], 1, c * RG_TM_DIM + j);
 
+    TM_FIX_STAMP(2);
     double S = 0.0;
     if (owner) {
         const uint64_t start = (uint64_t)seg * G.L;
         const uint64_t rem = tr.frames - start;
         const uint32_t len = rem < G.L ? (uint32_t)rem : G.L;
         const bool full = len == G.L;
+        double lin[NCH], quad[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const double *__restrict__ r = rec + (size_t)c * RG_TM_REC * total_recs + idx;
-            double sg[RG_TM_DIM];
+            double acc = 0.0;
 #pragma unroll
-            for (int j = 0; j < RG_TM_DIM; ++j) sg[j] = sgm[c][j];
-            double lin = 0.0;
-#pragma unroll
-            for (int j = 0; j < RG_TM_DIM; ++j) lin = fma(r[(size_t)(1 + j) * total_recs], sg[j], lin);
+            for (int j = 0; j < RG_TM_DIM; ++j) acc = fma(r[(size_t)(1 + j) * total_recs], sgm[c][j], acc);
+            lin[c] = acc;
+            quad[c] = 0.0;
             pk = fmax(pk, r[(size_t)25 * total_recs]);
-            // full segments share one Gram matrix (wave-uniform, scalar loads).  The segment a track ends in
-            // needs the prefix matrix of its own length: 78 per-lane loads that would cost every lane of
-            // the kernel 150 VGPRs, so that one lane parks its state in LDS and wave 0 evaluates it below.
-            double quad = 0.0;
-            if (full) quad = tm_quad_half((rg_cdouble *)FT.Gp + (size_t)(G.L - 1) * RG_TM_GRAM, sg);
-            else {
-#pragma unroll
-                for (int j = 0; j < RG_TM_DIM; ++j) part_sg[c][j] = sg[j];
-                part_len = len;
-                part_lane = i;
-            }
-            S += r[0] + 2.0 * (lin + quad);
+            S += r[0];
         }
+        // full segments share one Gram matrix (LDS broadcast reads, one row at a time for all channels: the
+        // scheduling fences keep the compiler from hoisting all 78 reads into registers).  The segment a
+        // track ends in needs the prefix matrix of its own length: 78 per-lane loads that would cost every
+        // lane of the kernel 150 VGPRs, so that one lane parks its state in LDS and wave 0 evaluates it below.
+        if (full) {
+            // constant trip counts on both loops (the triangle is a compile-time predicate), so that the
+            // unroller resolves every index before the register promotion of sgm runs
+#pragma unroll
+            for (int j = 0; j < RG_TM_DIM; ++j) {
+                const int p = j * RG_TM_DIM - (j * (j - 1)) / 2 - j;  // packed index of G[j][q] is p + q
+                double g[RG_TM_DIM];
+#pragma unroll
+                for (int q = 0; q < RG_TM_DIM; ++q)
+                    if (q >= j) g[q] = Gfull[p + q];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    double row = 0.5 * g[j] * sgm[c][j];
+#pragma unroll
+                    for (int q = 0; q < RG_TM_DIM; ++q)
+                        if (q > j) row = fma(g[q], sgm[c][q], row);
+                    quad[c] = fma(row, sgm[c][j], quad[c]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int j = 0; j < RG_TM_DIM; ++j) part_sg[c][j] = sgm[c][j];
+            part_len = len;
+            part_lane = i;
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) S += 2.0 * (lin[c] + quad[c]);
     }
     pieces[i] = owner ? S : 0.0;
     __syncthreads();
@@ -647,6 +695,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     }
     __syncthreads();
 
+    TM_FIX_STAMP(3);
     // ---- 50 ms windows: k consecutive segments each (finish_window, src/replaygain.rs:743-765) ----
     int bin = -1;
     if ((uint32_t)i < G.fix_windows) {
@@ -674,6 +723,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
         }
     }
 
+    TM_FIX_STAMP(4);
     // ---- the last block of a track to get here finishes the track: percentile, gain, peak -> result
     // (tail of analyze_track_internal, src/replaygain.rs:910-918).  Everything a block publishes goes through
     // device-scope atomics whose results have come back (tm_performed) before the barrier, so the arrival
@@ -683,21 +733,27 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     __syncthreads();
     if (i == 0) is_last = atomicAdd(&done_count[tr.track_index], 1u) + 1u == tr.fix_blocks ? 1 : 0;
     __syncthreads();
+    TM_FIX_STAMP(5);
     if (is_last) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        TM_FIX_STAMP(6);
         const RgLoudness l = rg_block_loudness(hist + (size_t)tr.track_index * RG_HISTOGRAM_SIZE, pct_scan);
         if (i == 0) {
             const unsigned long long pb = atomicMax(&peak_bits[tr.track_index], 0ull);  // coherent read
             rg_store_track_result(results + tr.track_index, l, __longlong_as_double((long long)pb), tr.sample_rate,
                                   tr.file_type);
         }
+        TM_FIX_STAMP(7);
     }
+#undef TM_FIX_STAMP
 }
 
 // =================================================================================================
 // diagnostic timeline buffer (tools/ubench/timeline.py); nullptr in normal operation
 static unsigned long long *g_tm_debug = nullptr;
 extern "C" void rg_tm_set_debug_buffer(unsigned long long *d_buf) { g_tm_debug = d_buf; }
+static unsigned long long *g_tm_fix_debug = nullptr;
+extern "C" void rg_tm_set_fix_debug_buffer(unsigned long long *d_buf) { g_tm_fix_debug = d_buf; }
 
 template <int FMT>
 static hipError_t launch_main_fmt(int nch, const RgTmCoef &K, const RgTmGeom &G, const RgTmTrack *d_tracks,
@@ -736,9 +792,9 @@ extern "C" hipError_t rg_launch_tm_fix(int nch, const RgTmGeom *G, const RgTmFix
     if (grid == 0) return hipSuccess;
     if (nch == 1)
         hipLaunchKernelGGL((rg_tm_fix_kernel<1>), dim3(grid), dim3(RG_TM_BLOCK), 0, s, *G, *FT, d_tracks, n_tracks, d_rec,
-                           total_recs, d_hist, d_peak_bits, d_done, d_results);
+                           total_recs, d_hist, d_peak_bits, d_done, d_results, g_tm_fix_debug);
     else
         hipLaunchKernelGGL((rg_tm_fix_kernel<2>), dim3(grid), dim3(RG_TM_BLOCK), 0, s, *G, *FT, d_tracks, n_tracks, d_rec,
-                           total_recs, d_hist, d_peak_bits, d_done, d_results);
+                           total_recs, d_hist, d_peak_bits, d_done, d_results, g_tm_fix_debug);
     return hipGetLastError();
 }
