@@ -150,6 +150,8 @@ int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out) {
     g.rounds_fast = D.rounds_fast;
     g.warm = 1u << D.rounds;
     g.fix_windows = (RG_TM_BLOCK - g.warm) / g.k;
+    g.block = rg_tm_choose_block(D.L, D.H10);
+    g.pad_ = 0;
     g.T = tb->d_blob + oT;
     g.Tlds = tb->d_blob + oL;
     tb->fix.Gp = tb->d_blob + oG;
@@ -168,7 +170,7 @@ int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out) {
 // segment; the choice trades arithmetic (all 12 transient moments are live for the first H10 frames
 // of a segment, 2 afterwards, so short segments cost up to 40 instead of 30 FP64 ops per sample)
 // against how evenly the resulting waves fill 256 CUs x 4 SIMDs x 4 resident waves.
-//   cost(L)  = L*30 + min(L, H10)*10 + fixed          [VALU slots per lane]
+//   cost(L)  = L*30 + min(L, H10)*10 + fixed          [VALU slots per lane; fixed covers the fix-up kernel too]
 //   waves(L) = sum over tracks and channels of ceil(nseg / 256) * 4
 //   time(L)  ~ ceil(waves / 1024) * cost   when everything is resident at once (waves <= 3072),
 //              (waves / 1024 + 1) * cost   otherwise (many rounds, one extra for the ragged tail)
@@ -199,24 +201,28 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
     double best = 1e300;
     uint32_t bestL = 0;
     for (uint32_t L : cand) {
+        const uint32_t Hl = std::min(H10, L & ~3u);
+        const uint32_t block = rg_tm_choose_block(L, Hl);
         double waves = 0;
         for (uint32_t id : g.ids) {
             const uint64_t nseg = (tracks[id].frames + L - 1) / L;
-            waves += (double)((nseg + RG_TM_BLOCK - 1) / RG_TM_BLOCK) * (RG_TM_BLOCK / 64) * g.nch;
+            waves += (double)((nseg + block - 1) / block) * (block / 64) * g.nch;
         }
         waves *= c->n_slots;
-        const double cost = (double)L * 30.0 + (double)std::min(L, H10) * 10.0 + 1500.0;
+        // per segment: the main kernel's prologue/record write, and the fix-up kernel's share (one 208-byte
+        // record per channel read back plus ~400 FMAs; measured 2.4 ms per 10.8 M segments beside 24 ms of main)
+        const double cost = (double)L * 30.0 + (double)std::min(L, H10) * 10.0 + 1500.0 + 1500.0;
         // residency: the LDS image of the response tables + one 4 KiB tile per wave bound the blocks per CU
-        const uint32_t Hl = std::min(H10, L & ~3u);
-        const double lds = ((double)Hl * 12 + (double)(L - Hl) * 2) * 8.0 + 4.0 * 4096.0;
-        const double blocks_cu = std::max(1.0, std::min(3.0, floor(160.0 * 1024.0 / lds)));
+        const double lds = (double)rg_tm_lds_bytes(L, Hl, block);
+        // waves per SIMD that can be resident: three narrow blocks, or one wide block, per CU
+        const double blocks_cu = block == RG_TM_BLOCK ? std::max(1.0, std::min(3.0, floor((double)RG_TM_LDS_BYTES / lds))) : 3.0;
         const double cap = 1024.0 * blocks_cu;
         const double rounds = waves <= cap ? ceil(waves / 1024.0) : waves / 1024.0 + 1.0;
         // FP64 issue efficiency by waves per SIMD (tools/ubench/frame.hip: 188 / 160 / 147 cycles per frame)
         const double wps = std::min(blocks_cu, std::max(1.0, waves / 1024.0));
         const double eff = wps >= 3.0 ? 1.0 : (wps >= 2.0 ? 1.09 + (3.0 - wps) * 0.0 : 1.28 - (wps - 1.0) * 0.19);
-        // tables that do not fit the kernel's LDS budget (96 KiB) send the whole launch down the generic path
-        const double tm = rounds * cost * eff * (lds > 96.0 * 1024.0 ? 8.0 : 1.0);
+        // tables that do not fit a CU's LDS (160 KiB) send the whole launch down the generic path
+        const double tm = rounds * cost * eff * (lds > (double)RG_TM_LDS_BYTES ? 8.0 : 1.0);
         if (tm < best) { best = tm; bestL = L; }
     }
     // walk outwards from the best candidate until one designs (tiny L can need too many scan rounds)
@@ -356,6 +362,7 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
         gl.list_n = g.ids.size();
         uint64_t recs = 0, mb = 0, fb = 0;
         const uint32_t NB = geo.fix_windows * geo.k;
+        const uint32_t geom_block = geo.block;
         for (uint32_t id : g.ids) {
             const RgTrackDev &cd = c->h_tracks[id];
             RgTmTrack &o = c->h_tm_tracks[tm_off++];
@@ -379,7 +386,7 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
                 ++n_k1;
             }
             recs += o.nseg;
-            mb += (o.nseg + RG_TM_BLOCK - 1) / RG_TM_BLOCK;
+            mb += (o.nseg + geom_block - 1) / geom_block;
             fb += (o.nseg + NB - 1) / NB;
             if (recs > 0x7FFFFFFFull || mb > 0x7FFFFFFFull || fb > 0x7FFFFFFFull)
                 return rg_set_err(c, RG_ERR_INVALID_ARG, "batch too large");

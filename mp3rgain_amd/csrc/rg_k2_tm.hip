@@ -130,7 +130,6 @@ __device__ __forceinline__ uint32_t find_track(const RgTmTrack *__restrict__ tra
 //    frame for n < H10, then only the Butterworth pair) and reads them as broadcast ds_read_b128,
 //    which the compiler can keep in flight with counted lgkmcnt waits.
 #define RG_TM_TILE 16
-#define RG_TM_WAVE_TILE_BYTES 4096  // 64 rows x 16 frames x 4 B
 
 typedef uint32_t __attribute__((ext_vector_type(4))) rg_u32x4;
 typedef uint32_t __attribute__((ext_vector_type(4), aligned(4))) rg_u32x4u;  // 16-byte load, 4-byte aligned
@@ -319,7 +318,7 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
 }
 
 template <int FMT>
-__global__ void __launch_bounds__(RG_TM_BLOCK)
+__global__ void __launch_bounds__(RG_TM_BLOCK_WIDE)
 rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restrict__ tracks, uint32_t n_tracks,
                   double *__restrict__ rec, uint32_t total_recs, uint32_t lds_tables,
                   uint32_t *__restrict__ zero_words, uint64_t zero_count /* batch accumulators to clear, or nullptr */,
@@ -334,14 +333,14 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
     // the batch's histograms, peaks and arrival counters are cleared here instead of by a memset of
     // their own: nothing in this kernel reads them, and everything that does is behind it in the stream
     if (zero_words) {
-        const uint64_t stride = (uint64_t)gridDim.x * gridDim.y * RG_TM_BLOCK;
-        for (uint64_t w = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * RG_TM_BLOCK + threadIdx.x; w < zero_count; w += stride)
+        const uint64_t stride = (uint64_t)gridDim.x * gridDim.y * blockDim.x;
+        for (uint64_t w = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; w < zero_count; w += stride)
             zero_words[w] = 0u;
     }
     const uint32_t t = find_track(tracks, n_tracks, blockIdx.x, &RgTmTrack::main_block_base);
     const RgTmTrack tr = tracks[t];
     const int chan = blockIdx.y;
-    const uint32_t seg = (blockIdx.x - tr.main_block_base) * RG_TM_BLOCK + threadIdx.x;
+    const uint32_t seg = (blockIdx.x - tr.main_block_base) * blockDim.x + threadIdx.x;
     const uint32_t L = G.L;
     const uint32_t H = G.H10;
     const bool active = seg < tr.nseg;
@@ -373,15 +372,16 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
                 const double2 *__restrict__ src = reinterpret_cast<const double2 *>(G.Tlds);
                 double2 *dst = reinterpret_cast<double2 *>(smem);
                 const uint32_t n16 = tbl_doubles / 2;
+                const uint32_t BS = blockDim.x;
                 uint32_t i = threadIdx.x;
-                for (; i + 3 * RG_TM_BLOCK < n16; i += 4 * RG_TM_BLOCK) {  // four loads in flight per thread
-                    const double2 a = src[i], b = src[i + RG_TM_BLOCK], c = src[i + 2 * RG_TM_BLOCK], d = src[i + 3 * RG_TM_BLOCK];
+                for (; i + 3 * BS < n16; i += 4 * BS) {  // four loads in flight per thread
+                    const double2 a = src[i], b = src[i + BS], c = src[i + 2 * BS], d = src[i + 3 * BS];
                     dst[i] = a;
-                    dst[i + RG_TM_BLOCK] = b;
-                    dst[i + 2 * RG_TM_BLOCK] = c;
-                    dst[i + 3 * RG_TM_BLOCK] = d;
+                    dst[i + BS] = b;
+                    dst[i + 2 * BS] = c;
+                    dst[i + 3 * BS] = d;
                 }
-                for (; i < n16; i += RG_TM_BLOCK) dst[i] = src[i];
+                for (; i < n16; i += BS) dst[i] = src[i];
                 __syncthreads();
             }
             const double *const T12 = reinterpret_cast<const double *>(smem);
@@ -416,7 +416,7 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
     }
 
     if (dbg && (threadIdx.x & 63) == 0) {
-        const size_t w = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (RG_TM_BLOCK / 64) + (threadIdx.x >> 6)) * 6;
+        const size_t w = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x / 64) + (threadIdx.x >> 6)) * 6;
         dbg[w + 4] = dbg_c0;
         dbg[w + 5] = __builtin_readcyclecounter();
         dbg[w + 0] = dbg_t0;
@@ -760,16 +760,15 @@ static hipError_t launch_main_fmt(int nch, const RgTmCoef &K, const RgTmGeom &G,
                                   uint32_t n_tracks, uint32_t grid, double *d_rec, uint32_t total_recs,
                                   uint32_t *d_zero, uint64_t zero_count, hipStream_t s) {
     // LDS: T12 (H10 x 12 doubles) + T2 ((L - H10) x 2 doubles) + one 4 KiB PCM tile per wave
-    size_t lds = ((size_t)G.H10 * 12 + (size_t)(G.L - G.H10) * 2) * sizeof(double) +
-                 (size_t)(RG_TM_BLOCK / 64) * RG_TM_WAVE_TILE_BYTES;
-    uint32_t lds_tables = lds <= 96 * 1024 ? 1u : 0u;
+    size_t lds = rg_tm_lds_bytes(G.L, G.H10, G.block);
+    uint32_t lds_tables = lds <= RG_TM_LDS_BYTES ? 1u : 0u;
     if (!lds_tables) lds = 0;
     static bool attr_set = false;
     if (lds > 48 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void *)rg_tm_main_kernel<FMT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void *)rg_tm_main_kernel<FMT>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_TM_LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((rg_tm_main_kernel<FMT>), dim3(grid, nch), dim3(RG_TM_BLOCK), lds, s, K, G, d_tracks, n_tracks,
+    hipLaunchKernelGGL((rg_tm_main_kernel<FMT>), dim3(grid, nch), dim3(G.block), lds, s, K, G, d_tracks, n_tracks,
                        d_rec, total_recs, lds_tables, d_zero, zero_count, g_tm_debug);
     return hipGetLastError();
 }

@@ -27,6 +27,11 @@
 #define RG_TM_GRAM 78         // upper triangle of a symmetric 12x12
 #define RG_TM_REC 26          // doubles per (segment, channel): A, B[12], E[12], peak
 #define RG_TM_BLOCK 256
+// Main kernel only: when the LDS image of the response tables is so large that fewer than three 256-thread
+// blocks fit a CU (160 KiB), one 768-thread block shares a single image and still puts 3 waves on each SIMD.
+#define RG_TM_BLOCK_WIDE 768
+#define RG_TM_WAVE_TILE_BYTES 4096  // PCM staging tile of one wave: 64 rows x 16 frames x 4 B
+#define RG_TM_LDS_BYTES (160u * 1024u)
 #define RG_TM_MAX_ROUNDS 4    // the doubling scan reaches 2^4 = 16 predecessors
 #define RG_TM_EDGE 16         // lanes of a wave whose scan values are visible to the next wave (>= 2^(MAX_ROUNDS-1), and 1 for the final shift)
 
@@ -65,6 +70,8 @@ struct RgTmGeom {
     uint32_t rounds_fast;  // rounds in which the fast block still contributes
     uint32_t warm;         // warm-up lanes per fix-up block (2^R)
     uint32_t fix_windows;  // whole windows per fix-up block
+    uint32_t block;        // threads per main-kernel block: RG_TM_BLOCK, or RG_TM_BLOCK_WIDE when the LDS image is large
+    uint32_t pad_;
     const double *T;       // [L][12] homogeneous responses, block-diagonal coordinates
     const double *Tlds;    // the same packed for LDS: [H10][12] then [L - H10][2] (only the slow pair)
 };
@@ -77,3 +84,13 @@ struct RgTmFixTables {
     const double *PhiB;    // [rounds][2][2]    (F_b^L)^(2^r)
     const double *Gp;      // [L][78]  prefix Gram matrices: Gp[len-1] = sum_{n<len} T T'
 };
+
+// LDS bytes of a main-kernel block of `block` threads, and the block size for an (L, H10) design
+static inline size_t rg_tm_lds_bytes(uint32_t L, uint32_t H10, uint32_t block) {
+    return ((size_t)H10 * 12 + (size_t)(L - H10) * 2) * sizeof(double) + (size_t)(block / 64) * RG_TM_WAVE_TILE_BYTES;
+}
+static inline uint32_t rg_tm_choose_block(uint32_t L, uint32_t H10) {
+    if (3 * rg_tm_lds_bytes(L, H10, RG_TM_BLOCK) <= RG_TM_LDS_BYTES) return RG_TM_BLOCK;
+    if (rg_tm_lds_bytes(L, H10, RG_TM_BLOCK_WIDE) <= RG_TM_LDS_BYTES) return RG_TM_BLOCK_WIDE;
+    return RG_TM_BLOCK;
+}
