@@ -44,7 +44,9 @@ typedef enum rg_status {
     RG_ERR_NO_DEVICE = -4,        /* no usable gfx950 device: there is no CPU path */
     RG_ERR_NOMEM = -5,
     RG_ERR_STATE = -6,            /* e.g. collect with nothing enqueued */
-    RG_ERR_COLLECTIVE = -7        /* RCCL symbol lookup or call failed */
+    RG_ERR_COLLECTIVE = -7,       /* RCCL symbol lookup or call failed */
+    RG_ERR_IO = -8,               /* "Failed to open: {path}" src/replaygain.rs:804-805 */
+    RG_ERR_FORMAT = -9            /* "Failed to probe format: {path}" src/replaygain.rs:815-822 */
 } rg_status;
 
 /* planar sample formats, the three AudioBufferRef arms of src/replaygain.rs:959-1024 */
@@ -208,6 +210,37 @@ int rg_timing_read(rg_ctx *ctx, double *sum_ms, uint64_t *launches, double *span
 /* ---- synthetic PCM directly in HBM (bench / tests; include/rg_synth.h) --------------------- */
 int rg_synth_fill_device(rg_ctx *ctx, void *d_dst_f32, uint64_t seed, uint32_t channel,
                          uint32_t sample_rate, uint64_t first_frame, uint64_t frames);
+
+/* ---- file level (last row): the reference's public functions on files -------------------
+ * The reference decodes MP3/AAC with a third-party decoder (symphonia) that is outside this library; here a
+ * file is a RIFF/WAVE file (integer PCM 8/16/24/32 bit, IEEE float 32 bit), or anything else run through an
+ * external decoder command that writes a WAV stream to stdout.  The interleaved samples are copied to HBM and
+ * de-interleaved into the planar arena by a device kernel; the rest is rg_analyze_pcm_batch's path. */
+typedef struct rg_wav_info {
+    uint32_t sample_rate;
+    uint16_t channels;
+    uint16_t bits_per_sample;
+    uint16_t sample_format; /* 1 = integer PCM, 3 = IEEE float (WAVE_FORMAT_EXTENSIBLE resolved to its sub-format) */
+    uint16_t block_align;
+    uint32_t reserved;
+    uint64_t data_offset;   /* first sample byte */
+    uint64_t frames;        /* a data size of 0 / 0xFFFFFFFF (streamed WAV) means "to the end of the buffer" */
+} rg_wav_info;
+/* pure host helper: RG_OK, or RG_ERR_INVALID_ARG when `data` is not a usable RIFF/WAVE stream */
+int rg_wav_parse(const void *data, size_t len, rg_wav_info *out);
+/* command template run through /bin/sh for files that are not RIFF/WAVE; "{}" is replaced by the shell-quoted
+ * path (appended when absent); it must write a WAV stream to stdout.  NULL or "" = none. */
+int rg_set_decoder_command(rg_ctx *ctx, const char *command_template);
+/* n WAV streams in host memory -> per-track results (+ album result when album != 0) */
+int rg_analyze_wav_batch(rg_ctx *ctx, const void *const *wav, const size_t *wav_len, size_t n, int album,
+                         rg_track_result *out, rg_album_result *album_out);
+/* analyze_track_with_index (src/replaygain.rs:935-941); track_index < 0 = None */
+int rg_analyze_track(rg_ctx *ctx, const char *path, int32_t track_index, rg_track_result *out);
+/* analyze_album_with_index (src/replaygain.rs:1044-1074): results in input order; the first failing file aborts */
+int rg_analyze_album(rg_ctx *ctx, const char *const *paths, size_t n, int32_t track_index,
+                     rg_track_result *tracks_out, rg_album_result *album_out);
+/* find_peak_amplitude (src/replaygain.rs:1140-1249) */
+int rg_find_peak_amplitude(rg_ctx *ctx, const char *path, rg_peak_result *out);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,12 @@ class DeviceView(C.Structure):
 # every symbol include/mp3rgain_amd.h declares: (name, restype, argtypes)
 _vp, _sz, _u32, _i32, _u64, _dbl, _int = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int32, C.c_uint64, C.c_double, C.c_int
 _P = C.POINTER
+class WavInfo(C.Structure):
+    _fields_ = [("sample_rate", C.c_uint32), ("channels", C.c_uint16), ("bits_per_sample", C.c_uint16),
+                ("sample_format", C.c_uint16), ("block_align", C.c_uint16), ("reserved", C.c_uint32),
+                ("data_offset", C.c_uint64), ("frames", C.c_uint64)]
+
+
 SYMBOLS = [
     ("rg_abi_version", _int, []),
     ("rg_is_available", _int, []),
@@ -115,6 +121,12 @@ SYMBOLS = [
     ("rg_timing_enable", _int, [_vp, _int]),
     ("rg_timing_read", _int, [_vp, _P(_dbl), _P(_u64), _P(_dbl), _int]),
     ("rg_synth_fill_device", _int, [_vp, _vp, _u64, _u32, _u32, _u64, _u64]),
+    ("rg_wav_parse", _int, [_vp, _sz, _P(WavInfo)]),
+    ("rg_set_decoder_command", _int, [_vp, C.c_char_p]),
+    ("rg_analyze_wav_batch", _int, [_vp, _P(_vp), _P(_sz), _sz, _int, _P(TrackResult), _P(AlbumResult)]),
+    ("rg_analyze_track", _int, [_vp, C.c_char_p, _i32, _P(TrackResult)]),
+    ("rg_analyze_album", _int, [_vp, _P(C.c_char_p), _sz, _i32, _P(TrackResult), _P(AlbumResult)]),
+    ("rg_find_peak_amplitude", _int, [_vp, C.c_char_p, _P(PeakResult)]),
 ]
 
 _lib = None

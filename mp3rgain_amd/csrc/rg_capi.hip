@@ -239,6 +239,7 @@ extern "C" void rg_destroy(rg_ctx *c) {
     c->d_coefs.release();
     c->d_peak_bits.release();
     c->d_arena.release();
+    c->d_wav.release();
     rg_tm_tables_release(c);
     delete c;
 }

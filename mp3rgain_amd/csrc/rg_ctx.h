@@ -125,6 +125,8 @@ struct rg_ctx {
 
     DevBuf<unsigned long long> d_peak_bits;  // rg_find_peak_pcm
     DevBuf<unsigned char> d_arena;           // staging for host PCM (synchronous API)
+    DevBuf<unsigned char> d_wav;             // interleaved WAV samples awaiting de-interleave (rg_files.hip)
+    std::string decoder_cmd;                 // rg_set_decoder_command
 
     bool timing = false;
     double timing_sum_ms = 0.0;

@@ -1,0 +1,373 @@
+// rg_files.hip -- the file-level entry points of the path (last row): analyze_track /
+// analyze_album / find_peak_amplitude on files, as the reference's public functions take them
+// (src/replaygain.rs:929-941, 1033-1074, 1140-1249).
+//
+// The reference gets PCM from a third-party decoder (symphonia) that is not part of this repo's scope and
+// cannot be restated offline.  What is accepted here instead:
+//   * RIFF/WAVE files (integer PCM 8/16/24/32 bit, IEEE float 32 bit, plain or WAVE_FORMAT_EXTENSIBLE);
+//   * any other file through an external decoder command that writes a WAV stream to stdout
+//     (rg_set_decoder_command, e.g. "ffmpeg -v error -i {} -f wav -c:a pcm_f32le -").
+// The interleaved bytes are copied to HBM as they are and turned into the planar arena of the analysis by a
+// device kernel; everything after that is the same path as rg_analyze_pcm_batch.
+#include <errno.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mp3rgain_amd.h"
+#include "../../include/mp3rgain_amd_mp4.h"
+#include "rg_ctx.h"
+
+// =================================================================================================
+// WAV container (host)
+namespace {
+
+uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+enum WavKind { WAV_U8 = 0, WAV_S16 = 1, WAV_S24 = 2, WAV_S32 = 3, WAV_F32 = 4 };
+
+int wav_kind(const rg_wav_info &w) {
+    if (w.sample_format == 3) return w.bits_per_sample == 32 ? WAV_F32 : -1;
+    if (w.sample_format != 1) return -1;
+    switch (w.bits_per_sample) {
+        case 8: return WAV_U8;
+        case 16: return WAV_S16;
+        case 24: return WAV_S24;
+        case 32: return WAV_S32;
+        default: return -1;
+    }
+}
+
+// the sample format of the planar arena a WAV kind is converted to: 8/16-bit -> S16, 24/32-bit -> S32
+// (same normalised amplitude: x/2^15 resp. x/2^31, src/replaygain.rs:984-1018), float -> F32
+uint16_t planar_format(int kind) { return kind == WAV_F32 ? RG_FMT_F32_PLANAR : (kind <= WAV_S16 ? RG_FMT_S16_PLANAR : RG_FMT_S32_PLANAR); }
+
+}  // namespace
+
+extern "C" int rg_wav_parse(const void *data, size_t len, rg_wav_info *out) {
+    if (!data || !out) return RG_ERR_INVALID_ARG;
+    const uint8_t *d = (const uint8_t *)data;
+    memset(out, 0, sizeof *out);
+    if (len < 12 || memcmp(d, "RIFF", 4) != 0 || memcmp(d + 8, "WAVE", 4) != 0) return RG_ERR_INVALID_ARG;
+    bool have_fmt = false;
+    size_t pos = 12;
+    while (pos + 8 <= len) {
+        const uint32_t size = le32(d + pos + 4);
+        const size_t body = pos + 8;
+        if (memcmp(d + pos, "fmt ", 4) == 0) {
+            if (size < 16 || body + 16 > len) return RG_ERR_INVALID_ARG;
+            uint16_t tag = le16(d + body);
+            out->channels = le16(d + body + 2);
+            out->sample_rate = le32(d + body + 4);
+            out->block_align = le16(d + body + 12);
+            out->bits_per_sample = le16(d + body + 14);
+            if (tag == 0xFFFE && size >= 40 && body + 40 <= len) tag = le16(d + body + 24);  // SubFormat GUID, first field
+            out->sample_format = tag;
+            have_fmt = true;
+        } else if (memcmp(d + pos, "data", 4) == 0) {
+            if (!have_fmt) return RG_ERR_INVALID_ARG;
+            const uint32_t bytes_per_frame = (uint32_t)out->channels * (out->bits_per_sample / 8u);
+            if (out->channels == 0 || bytes_per_frame == 0 || out->block_align != bytes_per_frame) return RG_ERR_INVALID_ARG;
+            // a streamed WAV (decoder pipe) cannot know its length: 0 or 0xFFFFFFFF mean "to the end"
+            uint64_t avail = len - body;
+            uint64_t n = (size == 0 || size == 0xFFFFFFFFu || size > avail) ? avail : size;
+            out->data_offset = body;
+            out->frames = n / bytes_per_frame;
+            return RG_OK;
+        }
+        const uint64_t next = (uint64_t)body + size + (size & 1u);  // chunks are word aligned
+        if (next > len) break;
+        pos = (size_t)next;
+    }
+    return RG_ERR_INVALID_ARG;
+}
+
+// =================================================================================================
+// interleaved bytes -> planar arena (device).  One thread per frame in the general kernel; stereo f32 and
+// stereo s16 (what decoders emit) move 16 bytes per lane per access when the planes are 16-byte aligned.
+namespace {
+
+template <int KIND> struct WavIn;
+template <> struct WavIn<WAV_U8> { typedef int16_t out_t; static constexpr int bytes = 1;
+    static __device__ out_t load(const uint8_t *p) { return (int16_t)(((int)p[0] - 128) * 256); } };
+template <> struct WavIn<WAV_S16> { typedef int16_t out_t; static constexpr int bytes = 2;
+    static __device__ out_t load(const uint8_t *p) { return (int16_t)(p[0] | (p[1] << 8)); } };
+template <> struct WavIn<WAV_S24> { typedef int32_t out_t; static constexpr int bytes = 3;
+    static __device__ out_t load(const uint8_t *p) { return (int32_t)(((uint32_t)p[0] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 24)); } };
+template <> struct WavIn<WAV_S32> { typedef int32_t out_t; static constexpr int bytes = 4;
+    static __device__ out_t load(const uint8_t *p) { return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); } };
+template <> struct WavIn<WAV_F32> { typedef float out_t; static constexpr int bytes = 4;
+    static __device__ out_t load(const uint8_t *p) {
+        return __uint_as_float((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); } };
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+rg_deinterleave_kernel(const uint8_t *__restrict__ src, void *__restrict__ dst, uint64_t first, uint64_t frames, uint32_t channels) {
+    typedef WavIn<KIND> W;
+    typedef typename W::out_t T;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t f = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; f < frames; f += stride) {
+        const uint8_t *p = src + f * channels * W::bytes;
+        for (uint32_t c = 0; c < channels; ++c) reinterpret_cast<T *>(dst)[(uint64_t)c * frames + f] = W::load(p + c * W::bytes);
+    }
+}
+
+// stereo, 4-byte samples (float and s32 share the bit copy): `quads` groups of four frames
+__global__ void __launch_bounds__(256)
+rg_deinterleave_stereo32_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ left, uint4 *__restrict__ right, uint64_t quads) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += stride) {
+        const uint4 a = src[2 * q], b = src[2 * q + 1];  // L0 R0 L1 R1 | L2 R2 L3 R3
+        left[q] = make_uint4(a.x, a.z, b.x, b.z);
+        right[q] = make_uint4(a.y, a.w, b.y, b.w);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+rg_deinterleave_stereo16_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ left, uint4 *__restrict__ right, uint64_t octs) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < octs; q += stride) {
+        const uint4 a = src[2 * q], b = src[2 * q + 1];  // eight frames: each word = L (low half) | R (high half)
+        auto lo = [](uint32_t x, uint32_t y) { return (x & 0xFFFFu) | (y << 16); };
+        auto hi = [](uint32_t x, uint32_t y) { return (x >> 16) | (y & 0xFFFF0000u); };
+        left[q] = make_uint4(lo(a.x, a.y), lo(a.z, a.w), lo(b.x, b.y), lo(b.z, b.w));
+        right[q] = make_uint4(hi(a.x, a.y), hi(a.z, a.w), hi(b.x, b.y), hi(b.z, b.w));
+    }
+}
+
+uint32_t grid_for(uint64_t items) {
+    const uint64_t blocks = (items + 255) / 256;
+    return (uint32_t)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks));  // 8192 blocks = 32 per CU; grid-stride beyond
+}
+
+template <int KIND>
+void launch_general(const uint8_t *src, void *dst, uint64_t first, uint64_t frames, uint32_t channels, hipStream_t s) {
+    if (first >= frames) return;
+    hipLaunchKernelGGL((rg_deinterleave_kernel<KIND>), dim3(grid_for(frames - first)), dim3(256), 0, s, src, dst, first, frames, channels);
+}
+
+hipError_t launch_deinterleave(int kind, const uint8_t *src, void *dst, uint64_t frames, uint32_t channels, hipStream_t s) {
+    if (frames == 0) return hipSuccess;
+    uint64_t done = 0;
+    const bool aligned = (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+    if (channels == 2 && aligned && (kind == WAV_F32 || kind == WAV_S32) && (frames * 4) % 16 == 0) {
+        const uint64_t quads = frames / 4;
+        hipLaunchKernelGGL(rg_deinterleave_stereo32_kernel, dim3(grid_for(quads)), dim3(256), 0, s, (const uint4 *)src,
+                           (uint4 *)dst, (uint4 *)((uint8_t *)dst + frames * 4), quads);
+        done = quads * 4;
+    } else if (channels == 2 && aligned && kind == WAV_S16 && (frames * 2) % 16 == 0) {
+        const uint64_t octs = frames / 8;
+        hipLaunchKernelGGL(rg_deinterleave_stereo16_kernel, dim3(grid_for(octs)), dim3(256), 0, s, (const uint4 *)src, (uint4 *)dst,
+                           (uint4 *)((uint8_t *)dst + frames * 2), octs);
+        done = octs * 8;
+    }
+    switch (kind) {
+        case WAV_U8: launch_general<WAV_U8>(src, dst, done, frames, channels, s); break;
+        case WAV_S16: launch_general<WAV_S16>(src, dst, done, frames, channels, s); break;
+        case WAV_S24: launch_general<WAV_S24>(src, dst, done, frames, channels, s); break;
+        case WAV_S32: launch_general<WAV_S32>(src, dst, done, frames, channels, s); break;
+        default: launch_general<WAV_F32>(src, dst, done, frames, channels, s); break;
+    }
+    return hipGetLastError();
+}
+
+// =================================================================================================
+// host plumbing
+struct WavItem {
+    const uint8_t *bytes;
+    rg_wav_info info;
+    int kind;
+    uint64_t src_off;  // in the interleaved staging buffer
+    uint64_t src_len;
+};
+
+size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// parse, copy to HBM, de-interleave: on return `descs` describe the planar arena c->d_arena
+int stage_wavs(rg_ctx *c, const void *const *wav, const size_t *wav_len, size_t n, std::vector<rg_track_desc> *descs, size_t *arena_bytes) {
+    std::vector<WavItem> items(n);
+    size_t src_total = 0, dst_total = 0;
+    descs->assign(n ? n : 1, rg_track_desc{});
+    for (size_t i = 0; i < n; ++i) {
+        WavItem &it = items[i];
+        it.bytes = (const uint8_t *)wav[i];
+        if (!wav[i] || rg_wav_parse(wav[i], wav_len[i], &it.info) != RG_OK)
+            return rg_set_err(c, RG_ERR_INVALID_ARG, "input %zu is not a RIFF/WAVE stream", i);
+        it.kind = wav_kind(it.info);
+        if (it.kind < 0)
+            return rg_set_err(c, RG_ERR_INVALID_ARG, "input %zu: unsupported WAV sample format (tag %u, %u bits)", i,
+                              it.info.sample_format, it.info.bits_per_sample);
+        it.src_off = src_total;
+        it.src_len = it.info.frames * it.info.block_align;
+        src_total = align16(src_total + it.src_len);
+        rg_track_desc &d = (*descs)[i];
+        d.offset_bytes = dst_total;
+        d.frames = it.info.frames;
+        d.sample_rate = it.info.sample_rate;
+        d.channels = it.info.channels;
+        d.format = planar_format(it.kind);
+        dst_total = align16(dst_total + (size_t)it.info.frames * it.info.channels * rg_bytes_per_sample(d.format));
+    }
+    int rc = rg_bind_device(c);
+    if (rc != RG_OK) return rc;
+    // the staging buffers may still be read by an earlier batch
+    for (int s = 0; s < c->n_slots; ++s) RG_HIP(c, hipStreamSynchronize(c->slots[s].stream));
+    RG_HIP(c, c->d_wav.reserve(src_total ? src_total : 16));
+    RG_HIP(c, c->d_arena.reserve(dst_total ? dst_total : 16));
+    hipStream_t fs = c->user_attached ? c->user_stream : c->slot().stream;
+    for (size_t i = 0; i < n; ++i) {
+        const WavItem &it = items[i];
+        if (it.src_len == 0) continue;
+        RG_HIP(c, hipMemcpyAsync(c->d_wav.p + it.src_off, it.bytes + it.info.data_offset, it.src_len, hipMemcpyHostToDevice, fs));
+        RG_HIP(c, launch_deinterleave(it.kind, c->d_wav.p + it.src_off, c->d_arena.p + (*descs)[i].offset_bytes, it.info.frames,
+                                      it.info.channels, fs));
+    }
+    // every pipeline stream must see the arena: the next enqueue waits for this point (as rg_synth_fill_device)
+    if (!c->user_attached) RG_HIP(c, hipEventRecord(c->user_ev, fs));
+    c->user_dirty = true;
+    *arena_bytes = dst_total;
+    return RG_OK;
+}
+
+bool read_all(FILE *f, std::vector<uint8_t> *out) {
+    uint8_t chunk[1 << 16];
+    size_t n;
+    while ((n = fread(chunk, 1, sizeof chunk, f)) > 0) out->insert(out->end(), chunk, chunk + n);
+    return !ferror(f);
+}
+
+std::string shell_quote(const char *s) {
+    std::string q = "'";
+    for (; *s; ++s) {
+        if (*s == '\'') q += "'\\''";
+        else q += *s;
+    }
+    return q + "'";
+}
+
+// bytes of a WAV stream for `path`: the file itself when it is RIFF/WAVE, else the decoder command's stdout
+int load_wav_for(rg_ctx *c, const char *path, std::vector<uint8_t> *out) {
+    if (!path) return rg_set_err(c, RG_ERR_INVALID_ARG, "null path");
+    FILE *f = fopen(path, "rb");
+    if (!f) return rg_set_err(c, RG_ERR_IO, "Failed to open: %s", path);  // src/replaygain.rs:804-805
+    uint8_t head[12];
+    const size_t got = fread(head, 1, sizeof head, f);
+    const bool riff = got == 12 && memcmp(head, "RIFF", 4) == 0 && memcmp(head + 8, "WAVE", 4) == 0;
+    if (riff) {
+        out->assign(head, head + got);
+        const bool ok = read_all(f, out);
+        fclose(f);
+        if (!ok) return rg_set_err(c, RG_ERR_IO, "Failed to read: %s", path);
+        return RG_OK;
+    }
+    fclose(f);
+    if (c->decoder_cmd.empty())  // src/replaygain.rs:815-822: the probe knows no such format
+        return rg_set_err(c, RG_ERR_FORMAT,
+                          "Failed to probe format: %s (not RIFF/WAVE, and no decoder command is set: rg_set_decoder_command)", path);
+    std::string cmd = c->decoder_cmd;
+    const std::string q = shell_quote(path);
+    size_t at = cmd.find("{}");
+    if (at == std::string::npos) cmd += " " + q;
+    else
+        for (; at != std::string::npos; at = cmd.find("{}", at + q.size())) cmd.replace(at, 2, q);
+    FILE *p = popen(cmd.c_str(), "r");
+    if (!p) return rg_set_err(c, RG_ERR_IO, "Failed to run decoder: %s", strerror(errno));
+    out->clear();
+    const bool ok = read_all(p, out);
+    const int status = pclose(p);
+    if (!ok || status != 0 || out->empty())
+        return rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s (decoder command exited with status %d)", path, status);
+    return RG_OK;
+}
+
+// Some(idx) selects among the audio tracks of a container (src/replaygain.rs:838-851); a WAV stream has one
+int check_track_index(rg_ctx *c, int32_t track_index) {
+    if (track_index > 0)
+        return rg_set_err(c, RG_ERR_INVALID_ARG, "Track index %d out of range (file has 1 audio track(s))", track_index);
+    return RG_OK;
+}
+
+uint32_t file_type_of(const char *path) {  // detect_file_type, src/replaygain.rs:777-783
+    return rg_mp4_is_mp4_file(path) ? RG_FILE_AAC : RG_FILE_MP3;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" int rg_set_decoder_command(rg_ctx *c, const char *command_template) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    c->decoder_cmd = command_template ? command_template : "";
+    return RG_OK;
+}
+
+extern "C" int rg_analyze_wav_batch(rg_ctx *c, const void *const *wav, const size_t *wav_len, size_t n, int album,
+                                    rg_track_result *out, rg_album_result *album_out) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    if (n && (!wav || !wav_len)) return rg_set_err(c, RG_ERR_INVALID_ARG, "null input array");
+    std::vector<rg_track_desc> descs;
+    size_t arena_bytes = 0;
+    int rc = stage_wavs(c, wav, wav_len, n, &descs, &arena_bytes);
+    if (rc != RG_OK) return rc;
+    rc = rg_enqueue_impl(c, descs.data(), n, c->d_arena.p, arena_bytes, album ? 1 : 0);
+    if (rc != RG_OK) return rc;
+    rc = rg_collect(c, out, nullptr);
+    if (rc != RG_OK) return rc;
+    if (album) return rg_album_finish(c, album_out, nullptr);
+    return RG_OK;
+}
+
+extern "C" int rg_analyze_track(rg_ctx *c, const char *path, int32_t track_index, rg_track_result *out) {
+    if (!c || !out) return RG_ERR_INVALID_ARG;
+    std::vector<uint8_t> bytes;
+    int rc = load_wav_for(c, path, &bytes);
+    if (rc != RG_OK) return rc;
+    rc = check_track_index(c, track_index);
+    if (rc != RG_OK) return rc;
+    const void *p = bytes.data();
+    const size_t len = bytes.size();
+    rc = rg_analyze_wav_batch(c, &p, &len, 1, 0, out, nullptr);
+    if (rc == RG_ERR_INVALID_ARG && c->err.rfind("input 0", 0) == 0) return rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s", path);
+    if (rc != RG_OK) return rc;
+    out->file_type = file_type_of(path);
+    return RG_OK;
+}
+
+// analyze_album_with_index (src/replaygain.rs:1044-1074): the first failing file aborts the album (:1055)
+extern "C" int rg_analyze_album(rg_ctx *c, const char *const *paths, size_t n, int32_t track_index, rg_track_result *tracks_out,
+                                rg_album_result *album_out) {
+    if (!c || (n && (!paths || !tracks_out)) || !album_out) return RG_ERR_INVALID_ARG;
+    std::vector<std::vector<uint8_t>> bytes(n);
+    std::vector<const void *> ptrs(n);
+    std::vector<size_t> lens(n);
+    for (size_t i = 0; i < n; ++i) {
+        int rc = load_wav_for(c, paths[i], &bytes[i]);
+        if (rc != RG_OK) return rc;
+        rc = check_track_index(c, track_index);
+        if (rc != RG_OK) return rc;
+        ptrs[i] = bytes[i].data();
+        lens[i] = bytes[i].size();
+    }
+    int rc = rg_analyze_wav_batch(c, ptrs.data(), lens.data(), n, 1, tracks_out, album_out);
+    if (rc != RG_OK) return rc;
+    for (size_t i = 0; i < n; ++i) tracks_out[i].file_type = file_type_of(paths[i]);
+    return RG_OK;
+}
+
+// find_peak_amplitude (src/replaygain.rs:1140-1249): max |x| over ALL channels, no loudness analysis
+extern "C" int rg_find_peak_amplitude(rg_ctx *c, const char *path, rg_peak_result *out) {
+    if (!c || !out) return RG_ERR_INVALID_ARG;
+    std::vector<uint8_t> bytes;
+    int rc = load_wav_for(c, path, &bytes);
+    if (rc != RG_OK) return rc;
+    const void *p = bytes.data();
+    const size_t len = bytes.size();
+    std::vector<rg_track_desc> descs;
+    size_t arena_bytes = 0;
+    rc = stage_wavs(c, &p, &len, 1, &descs, &arena_bytes);
+    if (rc != RG_OK) return rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s", path);
+    // the arena was produced on the stream rg_find_peak_pcm uses, so no further ordering is needed
+    return rg_find_peak_pcm(c, &descs[0], c->d_arena.p, arena_bytes, 1, out);
+}

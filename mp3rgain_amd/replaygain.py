@@ -19,6 +19,7 @@ arithmetic happens in libmp3rgain_amd.so on the GPU; this file is plumbing.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import enum
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
@@ -252,6 +253,47 @@ class Analyzer:
         self._check(self._lib.rg_find_peak_pcm(self._ctx, descs, arena.ctypes.data, arena.nbytes, 0, C.byref(pk)))
         return PeakAmplitudeResult(pk.peak, pk.peak_pcm, pk.sample_rate)
 
+    # -- file level: the reference's public functions (src/replaygain.rs:929-941, 1033-1074, 1140-1249) ----
+    def set_decoder_command(self, command_template: Optional[str]):
+        """Command (run by /bin/sh, `{}` = quoted path) that writes a WAV stream to stdout for files that are
+        not RIFF/WAVE, e.g. "ffmpeg -v error -i {} -f wav -c:a pcm_f32le -".  None = WAV files only."""
+        self._check(self._lib.rg_set_decoder_command(self._ctx, command_template.encode() if command_template else None))
+
+    def analyze_track_file(self, file_path, track_index: Optional[int] = None) -> ReplayGainResult:
+        """analyze_track_with_index (src/replaygain.rs:935-941)."""
+        out = _capi.TrackResult()
+        self._check(self._lib.rg_analyze_track(self._ctx, os.fsencode(os.fspath(file_path)),
+                                               -1 if track_index is None else int(track_index), C.byref(out)))
+        return _to_result(out, out.file_type)
+
+    def analyze_album_files(self, files, track_index: Optional[int] = None) -> AlbumGainResult:
+        """analyze_album_with_index (src/replaygain.rs:1044-1074)."""
+        n = len(files)
+        paths = (C.c_char_p * max(1, n))(*[os.fsencode(os.fspath(f)) for f in files])
+        out = (_capi.TrackResult * max(1, n))()
+        alb = _capi.AlbumResult()
+        self._check(self._lib.rg_analyze_album(self._ctx, paths, n, -1 if track_index is None else int(track_index),
+                                               out, C.byref(alb)))
+        return AlbumGainResult([_to_result(out[i], out[i].file_type) for i in range(n)], alb.album_loudness_db,
+                               alb.album_gain_db, alb.album_peak)
+
+    def find_peak_amplitude_file(self, file_path) -> PeakAmplitudeResult:
+        pk = _capi.PeakResult()
+        self._check(self._lib.rg_find_peak_amplitude(self._ctx, os.fsencode(os.fspath(file_path)), C.byref(pk)))
+        return PeakAmplitudeResult(pk.peak, pk.peak_pcm, pk.sample_rate)
+
+    def analyze_wav_bytes(self, wavs: Sequence[bytes], album: bool = False):
+        """WAV streams already in memory -> [ReplayGainResult] (+ AlbumGainResult fields when album)."""
+        n = len(wavs)
+        keep = [(C.c_uint8 * max(1, len(w))).from_buffer_copy(w if w else b"\0") for w in wavs]
+        ptrs = (C.c_void_p * max(1, n))(*[C.addressof(k) for k in keep])
+        lens = (C.c_size_t * max(1, n))(*[len(w) for w in wavs])
+        out = (_capi.TrackResult * max(1, n))()
+        alb = _capi.AlbumResult()
+        self._check(self._lib.rg_analyze_wav_batch(self._ctx, ptrs, lens, n, int(album), out, C.byref(alb)))
+        res = [_to_result(out[i], AudioFileType.Mp3) for i in range(n)]
+        return AlbumGainResult(res, alb.album_loudness_db, alb.album_gain_db, alb.album_peak) if album else res
+
     # -- device-resident pipeline --------------------------------------------------------------
     def enqueue_device(self, descs, n: int, d_pcm_base: int, pcm_bytes: int, album: bool = False):
         self._check(self._lib.rg_enqueue_pcm_batch(self._ctx, descs, n, d_pcm_base, pcm_bytes, int(album)))
@@ -310,13 +352,35 @@ def _default_analyzer() -> Analyzer:
     return _default
 
 
-def analyze_track(track: PcmTrack) -> ReplayGainResult:
-    return _default_analyzer().analyze_track(track)
+def _is_path(x) -> bool:
+    return isinstance(x, (str, bytes, os.PathLike))
 
 
-def analyze_album(tracks: Sequence[PcmTrack]) -> AlbumGainResult:
-    return _default_analyzer().analyze_album(tracks)
+def analyze_track(track) -> ReplayGainResult:
+    """analyze_track (src/replaygain.rs:929-932) for a file path, or for decoded PCM (PcmTrack)."""
+    a = _default_analyzer()
+    return a.analyze_track_file(track) if _is_path(track) else a.analyze_track(track)
 
 
-def find_peak_amplitude(track: PcmTrack) -> PeakAmplitudeResult:
-    return _default_analyzer().find_peak_amplitude(track)
+def analyze_track_with_index(file_path, track_index: Optional[int]) -> ReplayGainResult:
+    return _default_analyzer().analyze_track_file(file_path, track_index)
+
+
+def analyze_album(tracks) -> AlbumGainResult:
+    """analyze_album (src/replaygain.rs:1033-1036) for file paths, or for decoded PCM (PcmTracks)."""
+    a = _default_analyzer()
+    tracks = list(tracks)
+    return a.analyze_album_files(tracks) if tracks and _is_path(tracks[0]) else a.analyze_album(tracks)
+
+
+def analyze_album_with_index(files, track_index: Optional[int]) -> AlbumGainResult:
+    return _default_analyzer().analyze_album_files(list(files), track_index)
+
+
+def find_peak_amplitude(track) -> PeakAmplitudeResult:
+    a = _default_analyzer()
+    return a.find_peak_amplitude_file(track) if _is_path(track) else a.find_peak_amplitude(track)
+
+
+def set_decoder_command(command_template: Optional[str]) -> None:
+    _default_analyzer().set_decoder_command(command_template)
