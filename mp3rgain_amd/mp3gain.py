@@ -202,3 +202,14 @@ def remove_ape_tag_value(file_path, key: str) -> None:
 
 def delete_ape_tag(file_path) -> None:
     _ok(lib().rg_ape_delete(_p(file_path)))
+
+
+def has_ape_tag(file_path) -> bool:
+    """read_ape_tag_from_file(..)?.is_some() (src/lib.rs:1030-1038): raises like the reference when unreadable."""
+    try:
+        with open(file_path, "rb") as f:
+            data = f.read()
+    except OSError:
+        raise Mp3GainError(-101, f"Failed to read: {os.fspath(file_path)}")
+    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data if data else b"\0")
+    return lib().rg_ape_item_count_data(buf, len(data)) >= 0

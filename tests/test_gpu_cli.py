@@ -1,0 +1,199 @@
+"""Command-line façade on the GPU box: -r, -a, -e, -x and the beets TSV line run the analysis through the C ABI.
+MP3 fixtures (byte copies of the reference's) are paired with a stand-in decoder that emits a known WAV stream,
+so every printed number is checked against the CPU oracle on the same samples, and the gain that -r / -a apply
+to the MP3 is checked in the file's global_gain fields."""
+import io
+import json
+import math
+import shutil
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from wavutil import test_signal, wav_bytes  # noqa: E402
+
+test_signal.__test__ = False
+pytestmark = pytest.mark.gpu
+FIX = Path(__file__).parent / "golden" / "fixtures"
+
+DECODER = """\
+import sys, zlib
+sys.path.insert(0, {tests!r})
+from wavutil import test_signal, wav_bytes
+name = sys.argv[1].rsplit('/', 1)[-1]
+seed = zlib.crc32(name.encode()) % 1000
+amp = {{'loud.mp3': 3.0, 'quiet.mp3': 0.05}}.get(name, 1.0)
+ch = [(c * amp).clip(-1, 1).astype('float32') for c in test_signal('f32', 44100, 44100 * 2 + seed, 2, seed)]
+sys.stdout.buffer.write(wav_bytes(ch, 44100, 'f32', streamed=True))
+"""
+
+
+def decoded(name: str):
+    import zlib
+
+    seed = zlib.crc32(name.encode()) % 1000
+    amp = {"loud.mp3": 3.0, "quiet.mp3": 0.05}.get(name, 1.0)
+    return [(c * amp).clip(-1, 1).astype(np.float32) for c in test_signal("f32", 44100, 44100 * 2 + seed, 2, seed)]
+
+
+@pytest.fixture()
+def box(tmp_path, _ctx):
+    from mp3rgain_amd import cli
+
+    (tmp_path / "dec.py").write_text(DECODER.format(tests=str(Path(__file__).resolve().parent)))
+    dec = f"{sys.executable} {tmp_path / 'dec.py'} {{}}"
+
+    def run(*args):
+        out, err = io.StringIO(), io.StringIO()
+        rc = cli.main(["--decoder", dec] + [str(a) for a in args], out, err)
+        return rc, out.getvalue(), err.getvalue()
+
+    def mp3(name, src="test_joint_stereo.mp3"):
+        p = tmp_path / name
+        shutil.copyfile(FIX / src, p)
+        return p
+
+    return run, mp3, tmp_path
+
+
+def want_for(oracle, name):
+    ch = decoded(name)
+    return oracle.analyze_pcm(ch[0], ch[1], 44100)[0], oracle.analyze_pcm(ch[0], ch[1], 44100)[1]
+
+
+def test_track_gain_applies_to_mp3(box, oracle):
+    from mp3rgain_amd import mp3gain
+
+    run, mp3, _ = box
+    f = mp3("quiet.mp3")
+    w, _ = want_for(oracle, "quiet.mp3")
+    steps = w["gain_steps"]
+    assert steps > 0
+    rc, out, err = run("-r", f)
+    assert (rc, err) == (0, "")
+    assert out == ("mp3rgain Analyzing and applying track gain to 1 file(s)\n  Target: 89 dB (ReplayGain 1.0)\n\n"
+                   "  -> Analyzing quiet.mp3...\n"
+                   f"      Loudness: {w['loudness_db']:.1f} dB, Gain: {w['gain_db']:+.1f} dB ({steps} steps), Peak: {w['peak']:.4f}\n"
+                   f"  v quiet.mp3 (40 frames, {steps * 1.5:+.1f} dB)\n")  # src/main.rs:1223-1238, 1956-1969, 2139-2147
+    a = mp3gain.analyze(f)
+    assert (a.min_gain, a.max_gain) == (min(110 + steps, 255), min(210 + steps, 255))
+    assert mp3gain.read_ape_tag_value(f, "MP3GAIN_UNDO") == f"{steps:+04d},{steps:+04d},N"
+    # undo brings the audio bytes back
+    rc, out, _ = run("-u", f)
+    assert "(40 frames restored)" in out and mp3gain.analyze(f).max_gain == 210
+
+
+def test_track_gain_modifier_dry_run_json_and_clipping(box, oracle):
+    from mp3rgain_amd import mp3gain
+
+    run, mp3, _ = box
+    f = mp3("quiet.mp3")
+    w, _ = want_for(oracle, "quiet.mp3")
+    rc, out, _ = run("-n", "-e", "-m", "-2", f)  # -e = track gain only (src/main.rs:527-530)
+    s = w["gain_steps"]
+    assert f"({s} steps + -2 = {s - 2}), Peak:" in out and "  Gain modifier: -2 steps\n" in out
+    assert f"  ~ [DRY RUN] quiet.mp3 (would apply {(s - 2) * 1.5:+.1f} dB, {s - 2} steps)\n" in out
+    assert mp3gain.analyze(f).max_gain == 210
+    rc, out, err = run("-o", "json", "-r", "-n", f)
+    d = json.loads(out)
+    r = d["files"][0]
+    assert r["status"] == "dry_run" and r["loudness_db"] == w["loudness_db"] and r["peak"] == w["peak"]
+    assert r["gain_applied_steps"] == s and r["gain_applied_db"] == s * 1.5 and d["summary"]["dry_run"] is True
+    # a loud, clipped track gets negative gain: no clipping logic; a quiet one with peak*gain > 1 trips -k (:2033-2058)
+    new_peak = w["peak"] * 10 ** (w["gain_db"] / 20)
+    rc, out, err = run("-n", "-r", "-k", f)
+    if new_peak > 1.0:
+        safe = max(round(-20 * math.log10(w["peak"]) / 1.5), 0)
+        assert f"gain reduced from {s} to {safe} steps to prevent clipping (peak: {w['peak']:.4f})" in err
+    else:
+        assert err == ""
+    loud = mp3("loud.mp3")
+    wl, _ = want_for(oracle, "loud.mp3")
+    assert wl["gain_steps"] < 0 and wl["peak"] == 1.0
+    rc, out, err = run("-r", loud)
+    assert err == "" and mp3gain.analyze(loud).max_gain == 210 + wl["gain_steps"]
+
+
+def test_album_gain(box, oracle):
+    from mp3rgain_amd import mp3gain
+
+    run, mp3, _ = box
+    names = ["one.mp3", "quiet.mp3", "three.mp3"]
+    files = [mp3(n, s) for n, s in zip(names, ("test_joint_stereo.mp3", "test_vbr.mp3", "test_joint_stereo.mp3"))]
+    per = [want_for(oracle, n) for n in names]
+    alb, _ = oracle.album_from_hists([h for _, h in per], [w["peak"] for w, _ in per])
+    steps = round(alb["album_gain_db"] / 1.5)
+    before = [mp3gain.analyze(f).max_gain for f in files]
+    rc, out, err = run("-a", "-c", *files)
+    assert (rc, err) == (0, "")
+    assert out.startswith("mp3rgain Analyzing album gain for 3 file(s)\n  Target: 89 dB (ReplayGain 1.0)\n\n  -> Analyzing tracks...\n\n"
+                          f"  Album loudness: {alb['album_loudness_db']:.1f} dB\n"
+                          f"  Album gain:     {alb['album_gain_db']:+.1f} dB ({steps} steps)\n"
+                          f"  Album peak:     {alb['album_peak']:.4f}\n\n")  # src/main.rs:1297-1334
+    if steps != 0:
+        for f, b in zip(files, before):
+            assert mp3gain.analyze(f).max_gain == max(0, min(255, b + steps))
+            assert f"  v {f.name} (" in out
+    rc, out, _ = run("-o", "json", "-n", "-a", *files)
+    d = json.loads(out)
+    assert d["album"] == {"loudness_db": alb["album_loudness_db"], "gain_db": alb["album_gain_db"], "gain_steps": steps, "peak": alb["album_peak"]}
+    assert [r["loudness_db"] for r in d["files"]] == [w["loudness_db"] for w, _ in per]
+    # a file that cannot be decoded aborts the album (:1436-1452)
+    rc, out, err = run("-a", files[0], files[0].parent / "missing.mp3")
+    assert rc == 1 and err.startswith("error: Failed to analyze album: Failed to open: ")
+
+
+def test_beets_tsv_and_max_amplitude(box, oracle):
+    run, mp3, tmp = box
+    f = mp3("one.mp3")
+    w, _ = want_for(oracle, "one.mp3")
+    rc, out, err = run("-o", "-s", "s", "-k", "-d", "0", f)  # what beets runs
+    assert (rc, err) == (0, "")
+    lines = out.splitlines()
+    assert lines[0] == "File\tMP3 gain\tdB gain\tMax Amplitude\tMax global_gain\tMin global_gain"  # src/main.rs:1123
+    assert lines[1] == f"one.mp3\t{w['gain_steps']}\t{w['gain_db']:.6f}\t{w['peak'] * 32768.0:.6f}\t210\t110"  # :1719-1722
+    rc, out, _ = run("-o", "tsv", "-d", "3.0", f)  # -d shifts the suggested gain (:1711-1713)
+    g = w["gain_db"] + 3.0
+    assert out.splitlines()[1].split("\t")[1:3] == [str(round(g / 1.5)), f"{g:.6f}"]
+    # -x, src/main.rs:583-689
+    head = -20.0 * math.log10(w["peak"])
+    rc, out, _ = run("-x", f)
+    assert out == ("mp3rgain Finding maximum amplitude for 1 file(s)\n\none.mp3\n"
+                   f"  Max PCM sample: {w['peak'] * 32768.0:.6f}\n" + ("    (may be clipped - actual peak could be higher)\n" if w["peak"] >= 0.9999 else "") +
+                   f"  Headroom:       {head:+.2f} dB\n  Max global_gain: 210\n  Min global_gain: 110\n\n")
+    rc, out, _ = run("-x", "-q", f)
+    assert out == f"one.mp3\t{w['peak'] * 32768.0:.6f}\t{head:.2f}\n"
+    rc, out, _ = run("-x", "-o", "json", f)
+    r = json.loads(out)["files"][0]
+    assert r["max_amplitude"] == w["peak"] * 32768.0 and r["max_gain"] == 210 and r["min_gain"] == 110
+    # a WAV file needs no decoder; the global_gain columns are whatever the MP3 frame scanner makes of PCM bytes
+    # (false syncs, or the 255/0 fall-back of :1707-1708), as they would be in the reference
+    wav = tmp / "plain.wav"
+    ch = test_signal("s16", 44100, 50000, 2, 5)
+    wav.write_bytes(wav_bytes(ch, 44100, "s16"))
+    ww, _ = oracle.analyze_pcm(np.asarray(ch[0], np.int16), np.asarray(ch[1], np.int16), 44100)
+    rc, out, _ = run("-o", "tsv", wav)
+    assert out.splitlines()[1].split("\t")[:4] == ["plain.wav", str(ww["gain_steps"]), f"{ww['gain_db']:.6f}", f"{ww['peak'] * 32768.0:.6f}"]
+
+
+def test_m4a_gets_tags_only(box, oracle):
+    from mp3rgain_amd import mp4meta
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_mp4meta import make_mp4
+
+    run, _, tmp = box
+    f = tmp / "quiet.m4a"
+    data, _ = make_mp4()
+    f.write_bytes(data)
+    w, _ = want_for(oracle, "quiet.m4a")
+    rc, out, err = run("-r", "-c", f)
+    assert (rc, err) == (0, "")
+    assert out.endswith(f"  v quiet.m4a (tags written, {w['gain_db']:+.1f} dB)\n")  # src/main.rs:2204-2212
+    t = mp4meta.read_replaygain_tags(f)
+    assert (t.track_gain, t.track_peak, t.album_gain) == ("%+.2f dB" % w["gain_db"], "%.6f" % w["peak"], None)
+    rc, out, _ = run("-n", "-r", f)
+    assert "(tags only)" in out or "no adjustment needed" in out
