@@ -285,8 +285,8 @@ class Analyzer:
     def analyze_wav_bytes(self, wavs: Sequence[bytes], album: bool = False):
         """WAV streams already in memory -> [ReplayGainResult] (+ AlbumGainResult fields when album)."""
         n = len(wavs)
-        keep = [(C.c_uint8 * max(1, len(w))).from_buffer_copy(w if w else b"\0") for w in wavs]
-        ptrs = (C.c_void_p * max(1, n))(*[C.addressof(k) for k in keep])
+        keep = [C.c_char_p(bytes(w) if not isinstance(w, bytes) else w) for w in wavs]  # no copy: points into the bytes objects
+        ptrs = (C.c_void_p * max(1, n))(*[C.cast(k, C.c_void_p).value for k in keep])
         lens = (C.c_size_t * max(1, n))(*[len(w) for w in wavs])
         out = (_capi.TrackResult * max(1, n))()
         alb = _capi.AlbumResult()
