@@ -49,8 +49,8 @@ class _DevArray:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--kernel", type=int, default=0, help="kernel variant (0 = library default)")
     ap.add_argument("--tracks-per-rank", type=int, default=1)
     ap.add_argument("--minutes", type=float, default=10.0, help="track length (default: BASELINE's 10 min)")
@@ -77,6 +77,11 @@ def main() -> int:
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
     torch.cuda.set_device(local_rank)
+    frames = int(round(args.minutes * 60 * RATE))
+    ntr = args.tracks_per_rank
+    # The context first: its pipeline streams should each get a hardware queue of their own (the runtime has 4
+    # per process and deals them out as streams are created; torch.distributed / RCCL create several more).
+    an = rg.Analyzer(local_rank)
     dist = None
     if world > 1 or (args.album and "RANK" in os.environ):
         import torch.distributed as dist  # noqa: PLC0415
@@ -84,17 +89,14 @@ def main() -> int:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    frames = int(round(args.minutes * 60 * RATE))
-    ntr = args.tracks_per_rank
-    an = rg.Analyzer(local_rank)
     if args.kernel:
         an.set_kernel(args.kernel)
     if args.tm_segment:
         an.set_tuning(1, args.tm_segment)
     if args.slots:
         an.set_tuning(3, args.slots)
-    stream = torch.cuda.current_stream()
-    an.set_stream(stream.cuda_stream)
+    # No caller stream is attached: every batch, its album tail and the collective in between run on the
+    # context's own pipeline streams (rg_batch_stream), which costs no cross-stream event per step.
 
     # ---- synthetic PCM straight into HBM ---------------------------------------------------
     pcm = torch.empty((ntr, 2, frames), dtype=torch.float32, device="cuda")
@@ -112,21 +114,39 @@ def main() -> int:
     torch.cuda.synchronize()
 
     album = world > 1 or args.album
+    # The album exchange (LoudnessHistogram::accumulate / album_peak.max across ranks, replaygain.rs:1056-1059) is
+    # ONE collective per step: all-gather of the 48 KB [histogram | peak] packs + a device fold.  It runs over a
+    # communicator the library owns (bootstrapped through torch.distributed), on the stream of the batch, so a
+    # step costs no cross-stream event.  Fallback if that communicator cannot be built: the same all-gather
+    # through torch.distributed, issued on the batch's stream.
+    exchange = "none"
+    if dist is not None:
+        try:
+            an.comm_init_torch()
+            exchange = "rccl (library communicator, batch stream)"
+        except Exception as ex:  # noqa: BLE001
+            print(f"[bench] library communicator unavailable ({ex}); falling back to torch.distributed", file=sys.stderr)
+            exchange = "torch.distributed all_gather_into_tensor (batch stream)"
+    ext_streams = {}  # torch views of the library's pipeline streams (fallback path)
     views = {}  # the library rotates through pipeline slots: one set of tensor views / gather buffers per slot
 
     def step():
         an.enqueue_device(descs, ntr, pcm.data_ptr(), pcm_bytes, album=album)
         if album:
-            view = an.device_view()
-            if view.d_album_hist not in views:
-                views[view.d_album_hist] = (
-                    torch.as_tensor(_DevArray(view.d_album_hist, (album_mod.ALBUM_PACK_WORDS,), "<i4"), device="cuda"),
-                    torch.empty(world * album_mod.ALBUM_PACK_WORDS, dtype=torch.int32, device="cuda"))
-            pack_t, gathered_t = views[view.d_album_hist]
-            # LoudnessHistogram::accumulate / album_peak.max across ranks (replaygain.rs:1056-1059) as ONE
-            # collective: all-gather the 48 KB [histogram | peak] packs, fold them on the device
-            if dist is not None:
-                album_mod.allgather_album(pack_t, gathered_t)
+            if exchange.startswith("rccl"):
+                an.album_exchange()
+            elif dist is not None:
+                view = an.device_view()
+                if view.d_album_hist not in views:
+                    views[view.d_album_hist] = (
+                        torch.as_tensor(_DevArray(view.d_album_hist, (album_mod.ALBUM_PACK_WORDS,), "<i4"), device="cuda"),
+                        torch.empty(world * album_mod.ALBUM_PACK_WORDS, dtype=torch.int32, device="cuda"))
+                pack_t, gathered_t = views[view.d_album_hist]
+                h = an.batch_stream()
+                if h not in ext_streams:
+                    ext_streams[h] = torch.cuda.ExternalStream(h)
+                with torch.cuda.stream(ext_streams[h]):
+                    album_mod.allgather_album(pack_t, gathered_t)
                 an.album_reduce_gathered(gathered_t.data_ptr(), world)
             an.album_result_enqueue()
 
@@ -218,6 +238,7 @@ def main() -> int:
                              else f"album mode: {ntr} x {frames / RATE / 60:.1f}-min 44.1 kHz stereo track(s) per GPU, {world} GPU(s)"),
                 "tracks_per_gpu": ntr, "frames_per_track": frames, "sample_rate": RATE,
                 "mode": "album (-a): RCCL all-gather of the per-rank [12000-bin histogram | peak] packs + device fold" if album else "track (-r)",
+                "exchange": exchange,
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

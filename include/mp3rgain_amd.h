@@ -146,13 +146,20 @@ const char *rg_last_error(const rg_ctx *ctx);
 int rg_set_stream(rg_ctx *ctx, void *hip_stream, int attach);
 /* order the next enqueue behind everything submitted to the caller's stream so far (PCM produced there) */
 int rg_wait_user_stream(rg_ctx *ctx);
+/* The HIP stream (as void*) that the most recent enqueue runs on.  With no caller stream attached the album
+ * tail (rg_album_reduce_gathered / rg_album_allreduce / rg_album_result_enqueue) runs on it too, so a
+ * collective the caller issues ON THIS STREAM (torch.cuda.ExternalStream(handle), say) sits between the batch
+ * and the tail in plain stream order: no cross-stream events per step.  This is the fast multi-GPU form --
+ * other batches keep running on the context's other pipeline streams meanwhile. */
+void *rg_batch_stream(rg_ctx *ctx);
 /* kernel variant: 0 = auto, 1 = halo-tiled reference kernel, 2 = transient-moment kernel */
 int rg_set_kernel(rg_ctx *ctx, int variant);
 
 /* tuning knobs (0 restores the default): key 1 = segment length of variant 2 in frames (must divide
  * the 50 ms window), key 2 = number of segments (lanes) variant 2 aims for when it picks one,
- * key 3 = number of pipeline slots (1..8, default 4): consecutive enqueues run on separate HIP streams and
- * overlap on the GPU; rg_collect / rg_album_finish always refer to the most recent enqueue */
+ * key 3 = number of pipeline slots (1..8, default 8): buffer sets that consecutive enqueues rotate through, spread
+ * over min(slots, 4) HIP streams so that batches overlap on the GPU; rg_collect / rg_album_finish always refer to
+ * the most recent enqueue */
 int rg_set_tuning(rg_ctx *ctx, int key, int64_t value);
 /* diagnostic (host only): variant 2's design for one rate and segment length.  T_out: [L][12],
  * gram_last_out: [78]; either may be NULL.  RG_ERR_INVALID_ARG when no design exists. */
@@ -187,6 +194,19 @@ int rg_collect(rg_ctx *ctx, rg_track_result *tracks_out, uint32_t *hist_out);
  * (an ncclComm_t; NULL = single GPU, no-op).  The RCCL entry points are resolved from the
  * already-loaded process image first, then from librccl.so. */
 int rg_album_allreduce(rg_ctx *ctx, void *nccl_comm);
+/* The same exchange over a communicator the context owns, as ONE collective on the stream of the batch
+ * (rg_batch_stream): all-gather of every rank's [histogram | peak] pack + device fold.  No cross-stream event
+ * per step, which is what makes it the fast form (a torch.distributed collective hops into torch's RCCL stream
+ * and back).  Bootstrap: rank 0 calls rg_comm_unique_id, the 128 bytes travel by whatever the host has
+ * (torch.distributed broadcast in bench.py), every rank calls rg_comm_init (ncclCommInitRank).
+ * rg_comm_library names the librccl.so to resolve from first (e.g. the one PyTorch already loaded).
+ * Without a communicator rg_album_exchange is a no-op (single GPU). */
+#define RG_COMM_ID_BYTES 128
+int rg_comm_library(const char *librccl_path);
+int rg_comm_unique_id(void *id_out /* RG_COMM_ID_BYTES */);
+int rg_comm_init(rg_ctx *ctx, const void *id /* RG_COMM_ID_BYTES */, int world, int rank);
+int rg_comm_destroy(rg_ctx *ctx);
+int rg_album_exchange(rg_ctx *ctx);
 /* The same exchange as ONE collective: d_album_hist and d_album_peak are contiguous (12000 u32 + one f64 =
  * 12002 words, RG_ALBUM_PACK_WORDS).  All-gather every rank's pack (ncclAllGather / all_gather_into_tensor),
  * then this call folds the `world` gathered packs (sum of bins, max of peaks) into this context's album

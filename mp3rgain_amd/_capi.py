@@ -15,6 +15,7 @@ import os
 LIB_PATH = Path(os.environ.get("MP3RGAIN_AMD_LIB", PKG_DIR / "libmp3rgain_amd.so"))
 
 HISTOGRAM_SIZE = 12000
+COMM_ID_BYTES = 128
 HISTOGRAM_OFFSET = 2000
 FMT_F32_PLANAR, FMT_S16_PLANAR, FMT_S32_PLANAR = 0, 1, 2
 
@@ -105,6 +106,7 @@ SYMBOLS = [
     ("rg_last_error", C.c_char_p, [_vp]),
     ("rg_set_stream", _int, [_vp, _vp, _int]),
     ("rg_wait_user_stream", _int, [_vp]),
+    ("rg_batch_stream", _vp, [_vp]),
     ("rg_set_kernel", _int, [_vp, _int]),
     ("rg_set_tuning", _int, [_vp, _int, C.c_int64]),
     ("rg_tm_design_info", _int, [_u32, _u32, _P(_u32), _P(_u32), _P(_u32), _P(_dbl), _vp, _vp]),
@@ -116,6 +118,11 @@ SYMBOLS = [
     ("rg_collect", _int, [_vp, _P(TrackResult), _vp]),
     ("rg_album_allreduce", _int, [_vp, _vp]),
     ("rg_album_finish", _int, [_vp, _P(AlbumResult), _vp]),
+    ("rg_comm_library", _int, [C.c_char_p]),
+    ("rg_comm_unique_id", _int, [_vp]),
+    ("rg_comm_init", _int, [_vp, _vp, _int, _int]),
+    ("rg_comm_destroy", _int, [_vp]),
+    ("rg_album_exchange", _int, [_vp]),
     ("rg_album_reduce_gathered", _int, [_vp, _vp, _u32]),
     ("rg_album_result_enqueue", _int, [_vp]),
     ("rg_timing_enable", _int, [_vp, _int]),

@@ -176,7 +176,12 @@ extern "C" rg_ctx *rg_create(int device) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->user_ev, hipEventDisableTiming);
     for (int k = 0; k < RG_MAX_SLOTS && e == hipSuccess; ++k) {
         RgSlot &S = c->slots[k];
-        e = hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking);
+        // RG_SLOT_STREAMS streams carry the batches; the slots beyond them are further BUFFER sets on the same
+        // streams (slot k runs on stream k mod RG_SLOT_STREAMS).  A slot's buffers are reused n_slots batches
+        // later, so with more slots than streams a batch never waits in its queue for the album tail (collective
+        // + percentile on the caller's stream) of the batch that had the buffers before it.
+        if (k < RG_SLOT_STREAMS) e = hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking);
+        else S.stream = c->slots[k % RG_SLOT_STREAMS].stream;
         if (e == hipSuccess) e = hipEventCreateWithFlags(&S.staging_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&S.batch_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&S.album_done, hipEventDisableTiming);
@@ -214,6 +219,7 @@ extern "C" void rg_destroy(rg_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)sync_all(c);
+    (void)rg_comm_destroy(c);
     for (int k = 0; k < RG_MAX_SLOTS; ++k) {
         RgSlot &S = c->slots[k];
         for (auto &p : S.ev_pool) {
@@ -229,11 +235,12 @@ extern "C" void rg_destroy(rg_ctx *c) {
         S.d_album_hist.release();
         S.d_album_peak.p = nullptr;  // lives inside d_album_hist
         S.d_album_result.release();
+        S.d_gather.release();
         S.h_album_result.release();
         if (S.staging_done) (void)hipEventDestroy(S.staging_done);
         if (S.batch_done) (void)hipEventDestroy(S.batch_done);
         if (S.album_done) (void)hipEventDestroy(S.album_done);
-        if (S.stream) (void)hipStreamDestroy(S.stream);
+        if (S.stream && k < RG_SLOT_STREAMS) (void)hipStreamDestroy(S.stream);
     }
     if (c->user_ev) (void)hipEventDestroy(c->user_ev);
     c->d_coefs.release();
@@ -254,6 +261,8 @@ extern "C" int rg_set_stream(rg_ctx *c, void *s, int attach) {
     c->user_dirty = c->user_attached;
     return RG_OK;
 }
+
+extern "C" void *rg_batch_stream(rg_ctx *c) { return c ? (void *)c->slot().stream : nullptr; }
 
 extern "C" int rg_wait_user_stream(rg_ctx *c) {
     if (!c) return RG_ERR_INVALID_ARG;
@@ -276,7 +285,7 @@ extern "C" int rg_set_tuning(rg_ctx *c, int key, int64_t value) {
         case RG_TUNE_TM_TARGET_LANES: c->tune_tm_target_lanes = (uint64_t)value; return RG_OK;
         case RG_TUNE_PIPELINE_SLOTS: {
             if (sync_all(c) != RG_OK) return RG_ERR_DEVICE;
-            c->n_slots = value == 0 ? 4 : (value > RG_MAX_SLOTS ? RG_MAX_SLOTS : (int)value);
+            c->n_slots = value == 0 ? RG_DEFAULT_SLOTS : (value > RG_MAX_SLOTS ? RG_MAX_SLOTS : (int)value);
             c->cur = 0;
             return RG_OK;
         }
@@ -426,7 +435,13 @@ typedef int (*nccl_allreduce_fn)(const void *, void *, size_t, int, int, void *,
 typedef int (*nccl_group_fn)(void);
 const int kNcclUint32 = 3, kNcclFloat64 = 8, kNcclSum = 0, kNcclMax = 2;  // rccl.h enum values
 
+void *g_rccl = nullptr;  // rg_comm_library
+
 void *resolve(const char *name) {
+    if (g_rccl) {
+        void *p = dlsym(g_rccl, name);
+        if (p) return p;
+    }
     void *p = dlsym(RTLD_DEFAULT, name);
     if (p) return p;
     static void *h = nullptr;
@@ -434,7 +449,92 @@ void *resolve(const char *name) {
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     return h ? dlsym(h, name) : nullptr;
 }
+
+struct NcclId { char bytes[RG_COMM_ID_BYTES]; };  // ncclUniqueId
+typedef int (*nccl_get_id_fn)(NcclId *);
+typedef int (*nccl_init_rank_fn)(void **, int, NcclId, int);
+typedef int (*nccl_destroy_fn)(void *);
+typedef int (*nccl_allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef const char *(*nccl_errstr_fn)(int);
+
+const char *nccl_error(int r) {
+    nccl_errstr_fn f = (nccl_errstr_fn)resolve("ncclGetErrorString");
+    return f ? f(r) : "?";
+}
 }  // namespace
+
+// ---- a communicator of the library's own: the album exchange then runs on the batch's stream, with no
+// cross-stream event per step (what a torch.distributed collective costs twice: into its RCCL stream and back)
+extern "C" int rg_comm_library(const char *path) {
+    if (!path) return RG_ERR_INVALID_ARG;
+    void *h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return RG_ERR_COLLECTIVE;
+    g_rccl = h;
+    return RG_OK;
+}
+
+extern "C" int rg_comm_unique_id(void *id_out) {
+    if (!id_out) return RG_ERR_INVALID_ARG;
+    nccl_get_id_fn f = (nccl_get_id_fn)resolve("ncclGetUniqueId");
+    if (!f) return RG_ERR_COLLECTIVE;
+    NcclId id;
+    memset(&id, 0, sizeof id);
+    if (f(&id) != 0) return RG_ERR_COLLECTIVE;
+    memcpy(id_out, &id, sizeof id);
+    return RG_OK;
+}
+
+extern "C" int rg_comm_destroy(rg_ctx *c) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    if (c->comm) {
+        (void)sync_all(c);
+        nccl_destroy_fn f = (nccl_destroy_fn)resolve("ncclCommDestroy");
+        if (f) (void)f(c->comm);
+        c->comm = nullptr;
+        c->comm_world = 1;
+    }
+    return RG_OK;
+}
+
+extern "C" int rg_comm_init(rg_ctx *c, const void *id, int world, int rank) {
+    if (!c || !id || world < 1 || rank < 0 || rank >= world) return RG_ERR_INVALID_ARG;
+    nccl_init_rank_fn f = (nccl_init_rank_fn)resolve("ncclCommInitRank");
+    if (!f) return rg_set_err(c, RG_ERR_COLLECTIVE, "RCCL entry points not found (librccl.so)");
+    int rc = rg_bind_device(c);
+    if (rc != RG_OK) return rc;
+    (void)rg_comm_destroy(c);
+    NcclId nid;
+    memcpy(&nid, id, sizeof nid);
+    void *comm = nullptr;
+    const int r = f(&comm, world, nid, rank);
+    if (r != 0 || !comm) return rg_set_err(c, RG_ERR_COLLECTIVE, "ncclCommInitRank(%d of %d) failed: %s", rank, world, nccl_error(r));
+    c->comm = comm;
+    c->comm_world = world;
+    return RG_OK;
+}
+
+// LoudnessHistogram::accumulate + album_peak.max across ranks (src/replaygain.rs:1056-1059): all-gather of the
+// [histogram | peak] packs and the device fold, on the stream of the batch
+extern "C" int rg_album_exchange(rg_ctx *c) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    RgSlot &S = c->slot();
+    if (!S.album_ready) return rg_set_err(c, RG_ERR_STATE, "rg_album_exchange without an album enqueue");
+    if (!c->comm) return RG_OK;  // single GPU: nothing to exchange
+    nccl_allgather_fn ag = (nccl_allgather_fn)resolve("ncclAllGather");
+    if (!ag) return rg_set_err(c, RG_ERR_COLLECTIVE, "RCCL entry points not found (librccl.so)");
+    int rc = rg_bind_device(c);
+    if (rc != RG_OK) return rc;
+    RG_HIP(c, S.d_gather.reserve((size_t)c->comm_world * RG_ALBUM_PACK_WORDS));
+    hipStream_t s = c->album_stream();
+    const int r = ag(S.d_album_hist.p, S.d_gather.p, RG_ALBUM_PACK_WORDS, kNcclUint32, c->comm, s);
+    if (r != 0) return rg_set_err(c, RG_ERR_COLLECTIVE, "ncclAllGather failed: %s", nccl_error(r));
+    RG_HIP(c, rg_launch_album_reduce_gathered(S.d_gather.p, (uint32_t)c->comm_world, S.d_album_hist.p, S.d_album_peak.p, s));
+    if (c->user_attached) {
+        RG_HIP(c, hipEventRecord(S.album_done, c->user_stream));
+        S.album_pending = true;
+    }
+    return RG_OK;
+}
 
 extern "C" int rg_album_allreduce(rg_ctx *c, void *comm) {
     if (!c) return RG_ERR_INVALID_ARG;

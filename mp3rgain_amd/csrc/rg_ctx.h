@@ -65,6 +65,8 @@ struct RgTmDeviceTables {
 enum { RG_TUNE_TM_SEGMENT = 1, RG_TUNE_TM_TARGET_LANES = 2, RG_TUNE_PIPELINE_SLOTS = 3 };
 
 #define RG_MAX_SLOTS 8
+#define RG_SLOT_STREAMS 4   // HIP streams the slots are spread over (the runtime has 4 hardware queues by default)
+#define RG_DEFAULT_SLOTS 8
 
 // Everything one enqueued batch owns.  A context rotates through several slots, each with its own
 // HIP stream, so that consecutive batches overlap on the GPU: the latency-bound fix-up / percentile
@@ -90,6 +92,7 @@ struct RgSlot {
     DevBuf<uint32_t> d_album_hist;
     DevBuf<double> d_album_peak;
     DevBuf<rg_album_result> d_album_result;
+    DevBuf<uint32_t> d_gather;               // rg_album_exchange: every rank's [histogram | peak] pack
     PinnedBuf<rg_album_result> h_album_result;
     size_t n_enqueued = 0;
     bool album_ready = false;
@@ -103,7 +106,7 @@ struct rg_ctx {
     int kernel_variant = 0;      // 0 auto (= 2), 1 halo/reference-order kernel, 2 transient-moment kernels
     uint32_t tune_tm_segment = 0;          // 0 = choose from the workload
     uint64_t tune_tm_target_lanes = 0;     // 0 = cost model
-    int n_slots = 4;
+    int n_slots = RG_DEFAULT_SLOTS;
 
     RgSlot slots[RG_MAX_SLOTS];
     int cur = 0;                        // slot of the most recent enqueue
@@ -127,6 +130,8 @@ struct rg_ctx {
     DevBuf<unsigned char> d_arena;           // staging for host PCM (synchronous API)
     DevBuf<unsigned char> d_wav;             // interleaved WAV samples awaiting de-interleave (rg_files.hip)
     std::string decoder_cmd;                 // rg_set_decoder_command
+    void *comm = nullptr;                    // ncclComm_t of rg_comm_init (owned)
+    int comm_world = 1;
 
     bool timing = false;
     double timing_sum_ms = 0.0;

@@ -208,7 +208,7 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
             const uint64_t nseg = (tracks[id].frames + L - 1) / L;
             waves += (double)((nseg + block - 1) / block) * (block / 64) * g.nch;
         }
-        waves *= c->n_slots;
+        waves *= c->n_slots < RG_SLOT_STREAMS ? c->n_slots : RG_SLOT_STREAMS;  // batches in flight = streams
         // per segment: the main kernel's prologue/record write, and the fix-up kernel's share (one 208-byte
         // record per channel read back plus ~400 FMAs; measured 2.4 ms per 10.8 M segments beside 24 ms of main)
         const double cost = (double)L * 30.0 + (double)std::min(L, H10) * 10.0 + 1500.0 + 1500.0;

@@ -205,6 +205,10 @@ class Analyzer:
         else:
             self._check(self._lib.rg_set_stream(self._ctx, hip_stream or None, 1))
 
+    def batch_stream(self) -> int:
+        """HIP stream handle of the most recent enqueue (rg_batch_stream): issue the album collective on it."""
+        return int(self._lib.rg_batch_stream(self._ctx) or 0)
+
     def wait_user_stream(self):
         """Order the next enqueue behind what the attached stream has been given so far."""
         self._check(self._lib.rg_wait_user_stream(self._ctx))
@@ -315,6 +319,34 @@ class Analyzer:
 
     def album_reduce_gathered(self, d_gathered: int, world: int):
         self._check(self._lib.rg_album_reduce_gathered(self._ctx, d_gathered, world))
+
+    # -- the library's own RCCL communicator (rg_comm_*): the exchange runs on the batch's stream -----------
+    def comm_init(self, unique_id: bytes, world: int, rank: int):
+        self._check(self._lib.rg_comm_init(self._ctx, unique_id, world, rank))
+
+    def comm_init_torch(self, group=None):
+        """Bootstrap through torch.distributed: rank 0's ncclUniqueId is broadcast over the (already
+        initialised) process group, then every rank joins.  torch's own librccl.so is the one used."""
+        import torch
+        import torch.distributed as dist
+
+        lib = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(lib):
+            self._lib.rg_comm_library(lib.encode())
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        buf = C.create_string_buffer(_capi.COMM_ID_BYTES)
+        if rank == 0 and self._lib.rg_comm_unique_id(buf) != 0:
+            raise ReplayGainError(-7, "ncclGetUniqueId failed (librccl.so not found?)")
+        box = [buf.raw]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self.comm_init(box[0], world, rank)
+
+    def comm_destroy(self):
+        self._check(self._lib.rg_comm_destroy(self._ctx))
+
+    def album_exchange(self):
+        """Sum of histograms / max of peaks across the communicator's ranks, on the batch's stream."""
+        self._check(self._lib.rg_album_exchange(self._ctx))
 
     def album_result_enqueue(self):
         self._check(self._lib.rg_album_result_enqueue(self._ctx))

@@ -153,3 +153,45 @@ def test_attached_stream_orders_the_album_tail(analyzer, oracle):
             assert alb.album_peak == max(peaks) and alb.album_loudness_db == oracle.hist_loudness(2 * want_h)
     finally:
         analyzer.set_stream(None)
+
+
+def test_library_communicator_exchange_on_the_batch_stream(analyzer, oracle):
+    """rg_comm_* + rg_album_exchange: the album exchange as one RCCL all-gather + device fold on the stream of the
+    batch (what bench.py runs at N > 1).  One GPU can host only a 1-rank communicator, so the collective is the
+    identity here; the bootstrap, the call sequence and the stream ordering are the real ones."""
+    import torch.distributed as dist
+
+    lens = [RATE * 12, RATE * 7 + 3, RATE * 3]
+    seeds = [0x5EED5000, 0x5EED5001, 0x5EED5002]
+    buf, descs = _device_batch(analyzer, seeds, lens)
+    want_h = np.zeros(12000, dtype=np.uint32)
+    peaks = []
+    for s, f in zip(seeds, lens):
+        r, h = oracle.analyze_pcm(oracle.synth_f32(s, 0, RATE, f), oracle.synth_f32(s, 1, RATE, f), RATE)
+        want_h += h
+        peaks.append(r["peak"])
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1)
+    try:
+        analyzer.comm_init_torch()
+        for rep in range(10):  # every pipeline slot at least once
+            analyzer.enqueue_device(descs, 3, buf.data_ptr(), buf.numel() * 4, album=True)
+            analyzer.album_exchange()
+            analyzer.album_result_enqueue()
+            if rep % 3 == 0:
+                alb, ah = analyzer.album_finish(want_hist=True)
+                assert np.array_equal(ah, want_h)
+                assert alb.album_peak == max(peaks) and alb.album_loudness_db == oracle.hist_loudness(want_h)
+        res = analyzer.collect(3)
+        assert [r.peak for r in res] == peaks
+    finally:
+        analyzer.comm_destroy()
+        if own_group:
+            dist.destroy_process_group()
+    # without a communicator the exchange is a no-op (single GPU)
+    analyzer.enqueue_device(descs, 3, buf.data_ptr(), buf.numel() * 4, album=True)
+    analyzer.album_exchange()
+    analyzer.album_result_enqueue()
+    alb, ah = analyzer.album_finish(want_hist=True)
+    assert np.array_equal(ah, want_h)
