@@ -13,9 +13,11 @@
 // FP64 vector FMA bound (27 FMA + 1 convert per channel-sample, plus 2..12 moment FMAs); MFMA is
 // not used.  Compiled with the default -ffp-contract (explicit fma() everywhere anyway).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "rg_device.h"
 #include "rg_device_inl.h"
+
 #include "rg_tm.h"
 
 namespace {
@@ -267,12 +269,16 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
     };
     auto read_piece = [&](int p) -> uint4 { return *reinterpret_cast<const uint4 *>(rrow + 16 * (p ^ rswz)); };
 
-    load_tile(0);
-    for (uint32_t tile = 0; tile < ntiles; ++tile) {
+    // One tile.  MODE 1: every piece of the tile lies below H (all 12 moments live); MODE 2: every piece lies at or
+    // past H (slow pair only); MODE 0: decided per piece (the one tile H falls into, and the last tile of a row).
+    // Whole-tile modes keep the piece loop on a single path: with both frame bodies behind a branch inside one
+    // loop the register allocator reconciles the rotated filter state with 15 v_mov_b64 per piece on one of them.
+    auto run_tile = [&](const uint32_t tile, auto mode) {
+        constexpr int MODE = decltype(mode)::value;
         store_tile();                                // tile `tile` -> LDS (every read of the previous tile is behind us)
         if (tile + 1 < ntiles) load_tile(tile + 1);  // in flight during this tile's arithmetic
         const uint32_t n0 = tile * RG_TM_TILE;
-        const int np = L - n0 >= RG_TM_TILE ? 4 : (int)((L - n0) >> 2);  // full 4-frame pieces in this tile
+        const int np = MODE != 0 ? 4 : (L - n0 >= RG_TM_TILE ? 4 : (int)((L - n0) >> 2));  // full 4-frame pieces in this tile
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (np) v = read_piece(0);
 #pragma unroll 1
@@ -280,7 +286,7 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
             const uint4 vn = p + 1 < np ? read_piece(p + 1) : v;
             const uint32_t f[4] = {v.x, v.y, v.z, v.w};
             const uint32_t n = n0 + 4u * p;
-            if (n < H) {  // all 12 transient moments live (H is a multiple of 4)
+            if (MODE == 1 || (MODE == 0 && n < H)) {  // all 12 transient moments live (H is a multiple of 4)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     double row[12];
@@ -299,7 +305,7 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
             }
             v = vn;
         }
-        if (tile + 1 == ntiles) {
+        if (MODE == 0 && tile + 1 == ntiles) {
             // L & 3 trailing frames, in this (the last) tile
             for (uint32_t n = L & ~3u; n < L; ++n) {
                 const uint32_t o = n - n0;
@@ -314,7 +320,19 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
                 }
             }
         }
-    }
+    };
+    typedef std::integral_constant<int, 0> Mixed;
+    typedef std::integral_constant<int, 1> All12;
+    typedef std::integral_constant<int, 2> All2;
+
+    load_tile(0);
+    const uint32_t full_tiles = L / RG_TM_TILE;                         // tiles with four whole pieces
+    const uint32_t t12 = (H / RG_TM_TILE) < full_tiles ? H / RG_TM_TILE : full_tiles;  // tiles entirely below H
+    uint32_t tile = 0;
+    for (; tile < t12; ++tile) run_tile(tile, All12{});
+    if (tile < ntiles && (tile * RG_TM_TILE < H || tile >= full_tiles)) { run_tile(tile, Mixed{}); ++tile; }  // the tile H falls into
+    for (; tile < full_tiles; ++tile) run_tile(tile, All2{});
+    for (; tile < ntiles; ++tile) run_tile(tile, Mixed{});              // the ragged last tile
 }
 
 template <int FMT>
