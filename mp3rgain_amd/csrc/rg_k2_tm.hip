@@ -279,11 +279,7 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
         if (tile + 1 < ntiles) load_tile(tile + 1);  // in flight during this tile's arithmetic
         const uint32_t n0 = tile * RG_TM_TILE;
         const int np = MODE != 0 ? 4 : (L - n0 >= RG_TM_TILE ? 4 : (int)((L - n0) >> 2));  // full 4-frame pieces in this tile
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (np) v = read_piece(0);
-#pragma unroll 1
-        for (int p = 0; p < np; ++p) {
-            const uint4 vn = p + 1 < np ? read_piece(p + 1) : v;
+        auto piece = [&](const int p, const uint4 v) {
             const uint32_t f[4] = {v.x, v.y, v.z, v.w};
             const uint32_t n = n0 + 4u * p;
             if (MODE == 1 || (MODE == 0 && n < H)) {  // all 12 transient moments live (H is a multiple of 4)
@@ -303,7 +299,25 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
                     tm_frame<FMT, 2, TAIL>(st, f[u], pk, tr, K, n + u, len);
                 }
             }
-            v = vn;
+        };
+        if constexpr (MODE != 0) {
+            // whole-tile modes: the four pieces are unrolled (no loop counter, no copy of the prefetched piece)
+            uint4 v[4];
+            v[0] = read_piece(0);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (p + 1 < 4) v[p + 1] = read_piece(p + 1);
+                piece(p, v[p]);
+            }
+        } else {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (np) v = read_piece(0);
+#pragma unroll 1
+            for (int p = 0; p < np; ++p) {
+                const uint4 vn = p + 1 < np ? read_piece(p + 1) : v;
+                piece(p, v);
+                v = vn;
+            }
         }
         if (MODE == 0 && tile + 1 == ntiles) {
             // L & 3 trailing frames, in this (the last) tile
