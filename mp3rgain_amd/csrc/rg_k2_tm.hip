@@ -179,11 +179,6 @@ __device__ __forceinline__ void tm_frame(TmLane<1> &st, const uint32_t wbits, ty
 
 template <int NX>
 __device__ __forceinline__ void tm_load_row(double (&dst)[NX], const double *__restrict__ src) {
-#if defined(RG_EXP) && RG_EXP >= 3
-#pragma unroll
-    for (int j = 0; j < NX; ++j) dst[j] = 1e-3 * j + (double)(size_t)src * 1e-30;
-    return;
-#endif
 #pragma unroll
     for (int j = 0; j < NX; j += 2) {
         const double2 v = *reinterpret_cast<const double2 *>(src + j);  // 16-byte aligned broadcast read
