@@ -195,10 +195,10 @@ int stage_wavs(rg_ctx *c, const void *const *wav, const size_t *wav_len, size_t 
         WavItem &it = items[i];
         it.bytes = (const uint8_t *)wav[i];
         if (!wav[i] || rg_wav_parse(wav[i], wav_len[i], &it.info) != RG_OK)
-            return rg_set_err(c, RG_ERR_INVALID_ARG, "input %zu is not a RIFF/WAVE stream", i);
+            return rg_set_err(c, RG_ERR_FORMAT, "input %zu is not a RIFF/WAVE stream", i);
         it.kind = wav_kind(it.info);
         if (it.kind < 0)
-            return rg_set_err(c, RG_ERR_INVALID_ARG, "input %zu: unsupported WAV sample format (tag %u, %u bits)", i,
+            return rg_set_err(c, RG_ERR_FORMAT, "input %zu: unsupported WAV sample format (tag %u, %u bits)", i,
                               it.info.sample_format, it.info.bits_per_sample);
         it.src_off = src_total;
         it.src_len = it.info.frames * it.info.block_align;
@@ -329,7 +329,7 @@ extern "C" int rg_analyze_track(rg_ctx *c, const char *path, int32_t track_index
     const void *p = bytes.data();
     const size_t len = bytes.size();
     rc = rg_analyze_wav_batch(c, &p, &len, 1, 0, out, nullptr);
-    if (rc == RG_ERR_INVALID_ARG && c->err.rfind("input 0", 0) == 0) return rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s", path);
+    if (rc == RG_ERR_FORMAT) return rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s", path);  // src/replaygain.rs:815-822
     if (rc != RG_OK) return rc;
     out->file_type = file_type_of(path);
     return RG_OK;
@@ -351,6 +351,10 @@ extern "C" int rg_analyze_album(rg_ctx *c, const char *const *paths, size_t n, i
         lens[i] = bytes[i].size();
     }
     int rc = rg_analyze_wav_batch(c, ptrs.data(), lens.data(), n, 1, tracks_out, album_out);
+    if (rc == RG_ERR_FORMAT) {  // "input i ..." -> the reference's text with the file's name
+        size_t i = 0;
+        if (sscanf(c->err.c_str(), "input %zu", &i) == 1 && i < n) return rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s", paths[i]);
+    }
     if (rc != RG_OK) return rc;
     for (size_t i = 0; i < n; ++i) tracks_out[i].file_type = file_type_of(paths[i]);
     return RG_OK;
@@ -367,7 +371,8 @@ extern "C" int rg_find_peak_amplitude(rg_ctx *c, const char *path, rg_peak_resul
     std::vector<rg_track_desc> descs;
     size_t arena_bytes = 0;
     rc = stage_wavs(c, &p, &len, 1, &descs, &arena_bytes);
-    if (rc != RG_OK) return rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s", path);
+    if (rc == RG_ERR_FORMAT) return rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s", path);
+    if (rc != RG_OK) return rc;
     // the arena was produced on the stream rg_find_peak_pcm uses, so no further ordering is needed
     return rg_find_peak_pcm(c, &descs[0], c->d_arena.p, arena_bytes, 1, out);
 }

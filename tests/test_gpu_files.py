@@ -131,6 +131,14 @@ def test_file_level_errors(an, tmp_path):
     # album: the first failing file aborts the whole call (src/replaygain.rs:1055)
     with pytest.raises(rg.ReplayGainError, match="Failed to open: "):
         an.analyze_album_files([ok, tmp_path / "missing.wav", ok])
+    junk = tmp_path / "junk.mp3"
+    junk.write_bytes(b"ID3" + bytes(500))
+    with pytest.raises(rg.ReplayGainError, match="Failed to probe format: .*junk.mp3"):
+        an.analyze_album_files([ok, junk])
+    with pytest.raises(rg.ReplayGainError, match="Failed to probe format: .*junk.mp3"):
+        an.find_peak_amplitude_file(junk)
+    with pytest.raises(rg.ReplayGainError, match="input 1 is not a RIFF/WAVE stream"):
+        an.analyze_wav_bytes([ok.read_bytes(), b"nonsense"])
     f64 = bytearray(wav_bytes([np.zeros(10)], 44100, "f32", extra_chunks=False))
     f64[34:36] = (64).to_bytes(2, "little")
     f64[32:34] = (8).to_bytes(2, "little")
