@@ -326,7 +326,8 @@ class Analyzer:
 
     def comm_init_torch(self, group=None):
         """Bootstrap through torch.distributed: rank 0's ncclUniqueId is broadcast over the (already
-        initialised) process group, then every rank joins.  torch's own librccl.so is the one used."""
+        initialised) process group, then every rank joins.  torch's own librccl.so is the one used.
+        Every rank raises, or none does: failures are agreed on over the process group."""
         import torch
         import torch.distributed as dist
 
@@ -334,12 +335,26 @@ class Analyzer:
         if os.path.exists(lib):
             self._lib.rg_comm_library(lib.encode())
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-        buf = C.create_string_buffer(_capi.COMM_ID_BYTES)
-        if rank == 0 and self._lib.rg_comm_unique_id(buf) != 0:
-            raise ReplayGainError(-7, "ncclGetUniqueId failed (librccl.so not found?)")
-        box = [buf.raw]
-        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        self.comm_init(box[0], world, rank)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        uid = b""
+        if rank == 0:
+            buf = C.create_string_buffer(_capi.COMM_ID_BYTES)
+            if self._lib.rg_comm_unique_id(buf) == 0:
+                uid = buf.raw
+        box = [uid]
+        dist.broadcast_object_list(box, src=src, group=group)
+        if not box[0]:
+            raise ReplayGainError(-7, "ncclGetUniqueId failed on rank 0 (librccl.so not found?)")
+        err = None
+        try:
+            self.comm_init(box[0], world, rank)
+        except ReplayGainError as ex:
+            err = ex
+        flags = [None] * world
+        dist.all_gather_object(flags, err is None, group=group)
+        if not all(flags):
+            self.comm_destroy()
+            raise err or ReplayGainError(-7, "ncclCommInitRank failed on another rank")
 
     def comm_destroy(self):
         self._check(self._lib.rg_comm_destroy(self._ctx))
