@@ -195,3 +195,48 @@ def test_library_communicator_exchange_on_the_batch_stream(analyzer, oracle):
     analyzer.album_result_enqueue()
     alb, ah = analyzer.album_finish(want_hist=True)
     assert np.array_equal(ah, want_h)
+
+
+def test_finisher_handoff_under_uneven_load(_ctx):
+    """The fix-up kernel publishes through device-scope atomics without a release fence, and the last block of a
+    track to arrive reads the histogram after one acquire.  Stale reads, if the ordering were
+    wrong, show up under uneven load with warm caches: 240 tracks from 0.3 s to 90 s in one batch, re-enqueued 60
+    times across all pipeline slots while other batches are in flight; every result of every repetition must
+    equal the first one bit for bit, and the first one must equal the order-faithful variant-1 kernel's bins."""
+    an = _ctx
+    an.set_kernel(2)
+    an.set_tuning(1, 0)
+    an.set_tuning(2, 0)
+    an.set_tuning(3, 0)
+    rng = np.random.default_rng(424242)
+    lens = [int(x) for x in np.concatenate([rng.integers(RATE // 3, RATE * 3, 150), rng.integers(RATE * 20, RATE * 90, 30),
+                                            rng.integers(1, 5000, 60)])]
+    rng.shuffle(lens)
+    seeds = [0x5EED7000 + t for t in range(len(lens))]
+    buf, descs = _device_batch(an, seeds, lens)
+    n = len(lens)
+    small, sdescs = _device_batch(an, [1, 2, 3], [RATE * 5, RATE, 777])
+
+    def run():
+        an.enqueue_device(descs, n, buf.data_ptr(), buf.numel() * 4, album=True)
+        got, h = an.collect(n, want_hist=True)
+        alb, ah = an.album_finish(want_hist=True)
+        return h.copy(), ah.copy(), [(g.loudness_db, g.gain_db, g.peak, g.windows) for g in got], (alb.album_loudness_db, alb.album_peak)
+
+    ref = run()
+    assert np.array_equal(ref[1], ref[0].sum(axis=0, dtype=np.uint64).astype(np.uint32))  # album == sum of tracks
+    assert [w for _, _, _, w in ref[2]] == [int(x) for x in ref[0].sum(axis=1)]
+    import os
+
+    for rep in range(int(os.environ.get("RG_STRESS_REPS", "60"))):
+        for _ in range(rep % 4):  # other batches in flight on the neighbouring pipeline streams
+            an.enqueue_device(sdescs, 3, small.data_ptr(), small.numel() * 4)
+        cur = run()
+        assert np.array_equal(cur[0], ref[0]), f"repetition {rep}: track histograms differ"
+        assert np.array_equal(cur[1], ref[1]) and cur[2] == ref[2] and cur[3] == ref[3], f"repetition {rep}"
+    an.set_kernel(1)
+    an.enqueue_device(descs, n, buf.data_ptr(), buf.numel() * 4, album=True)
+    got1, h1 = an.collect(n, want_hist=True)
+    an.set_kernel(0)
+    assert np.array_equal(h1, ref[0])
+    assert [(g.loudness_db, g.peak) for g in got1] == [(l, p) for l, _, p, _ in ref[2]]
