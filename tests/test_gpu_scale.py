@@ -240,3 +240,43 @@ def test_finisher_handoff_under_uneven_load(_ctx):
     an.set_kernel(0)
     assert np.array_equal(h1, ref[0])
     assert [(g.loudness_db, g.peak) for g in got1] == [(l, p) for l, _, p, _ in ref[2]]
+
+
+def test_config3_full_size_1000_tracks(_ctx, oracle):
+    """BASELINE configs[2] at its full size: 1000 tracks x 3 min x 44.1 kHz stereo = 7.9e9 stereo frames, 63.5 GB of
+    f32 PCM resident in HBM, one batch.  Size-independent properties over all of it, the oracle on a sample."""
+    import torch
+
+    an = _ctx
+    an.set_kernel(0)
+    for key in (1, 2, 3):
+        an.set_tuning(key, 0)
+    free, _ = torch.cuda.mem_get_info()
+    n, frames = 1000, 180 * RATE
+    if free < (n * 2 * frames * 4) * 1.15:
+        pytest.skip("not enough free HBM for the full-size batch")
+    seeds = [0x5EED0000 + t for t in range(n)]
+    buf, descs = _device_batch(an, seeds, [frames] * n)
+    an.enqueue_device(descs, n, buf.data_ptr(), buf.numel() * 4, album=True)
+    got, h = an.collect(n, want_hist=True)
+    alb, ah = an.album_finish(want_hist=True)
+    # LoudnessHistogram::accumulate over all tracks, album_peak.max (replaygain.rs:658-662, 1056-1059)
+    assert np.array_equal(ah, h.sum(axis=0, dtype=np.uint64).astype(np.uint32))
+    assert alb.album_peak == max(g.peak for g in got)
+    assert alb.album_loudness_db == oracle.hist_loudness(ah) and alb.album_gain_db == 64.82 - alb.album_loudness_db
+    wins = h.sum(axis=1)
+    assert [g.windows for g in got] == [int(w) for w in wins]
+    assert wins.min() >= 3600 - 21 and wins.max() <= 3600 - 18  # the silent second of every track is dropped
+    for t in range(0, n, 37):
+        assert got[t].loudness_db == oracle.hist_loudness(h[t])
+    assert len({g.gain_steps() for g in got}) >= 5  # per-track levels differ
+    for t in (0, 499, 999):
+        l, r = oracle.synth_f32(seeds[t], 0, RATE, frames), oracle.synth_f32(seeds[t], 1, RATE, frames)
+        want, wh = oracle.analyze_pcm(l, r, RATE)
+        assert np.array_equal(h[t], wh) and got[t].peak == want["peak"] and got[t].loudness_db == want["loudness_db"]
+    # the same batch again (another pipeline slot): the same bits
+    an.enqueue_device(descs, n, buf.data_ptr(), buf.numel() * 4, album=True)
+    got2, h2 = an.collect(n, want_hist=True)
+    assert np.array_equal(h2, h) and [g.peak for g in got2] == [g.peak for g in got]
+    del buf
+    torch.cuda.empty_cache()
