@@ -280,3 +280,51 @@ def test_config3_full_size_1000_tracks(_ctx, oracle):
     assert np.array_equal(h2, h) and [g.peak for g in got2] == [g.peak for g in got]
     del buf
     torch.cuda.empty_cache()
+
+
+def test_config5_full_size_mixed_batch(_ctx, oracle):
+    """BASELINE configs[4] at its full size: 500 tracks at 44.1 kHz + 500 at 48 kHz, 3 minutes each, 10 % mono, 5 % with
+    full-scale peaks, interleaved in one batch (four launch groups).  Properties over all of it, oracle on one of each."""
+    import torch
+
+    from mp3rgain_amd import _capi
+
+    an = _ctx
+    an.set_kernel(0)
+    for key in (1, 2, 3):
+        an.set_tuning(key, 0)
+    n = 1000
+    rates = [44100 if t % 2 == 0 else 48000 for t in range(n)]
+    chans = [1 if t % 10 == 3 else 2 for t in range(n)]
+    seeds = [(0x5EED8000 + t) | ((1 << 40) if t % 20 == 7 else 0) for t in range(n)]  # bit 40: "hot" track
+    frames = [180 * r for r in rates]
+    total = sum(f * c for f, c in zip(frames, chans))
+    free, _ = torch.cuda.mem_get_info()
+    if free < total * 4 * 1.15:
+        pytest.skip("not enough free HBM for the full-size batch")
+    buf = torch.empty(total + 4, dtype=torch.float32, device="cuda:0")
+    descs = (_capi.TrackDesc * n)()
+    off = 0
+    for t in range(n):
+        for c in range(chans[t]):
+            an.synth_fill_device(buf.data_ptr() + 4 * (off + c * frames[t]), seeds[t], c, rates[t], 0, frames[t])
+        descs[t].offset_bytes, descs[t].frames, descs[t].sample_rate = 4 * off, frames[t], rates[t]
+        descs[t].channels, descs[t].format = chans[t], _capi.FMT_F32_PLANAR
+        off += chans[t] * frames[t]
+    an.enqueue_device(descs, n, buf.data_ptr(), buf.numel() * 4, album=True)
+    got, h = an.collect(n, want_hist=True)
+    alb, ah = an.album_finish(want_hist=True)
+    assert np.array_equal(ah, h.sum(axis=0, dtype=np.uint64).astype(np.uint32))
+    assert alb.album_peak == max(g.peak for g in got) == 1.0
+    assert [g.sample_rate for g in got] == rates  # results come back in input order (replaygain.rs:1061)
+    assert [g.windows for g in got] == [int(w) for w in h.sum(axis=1)]
+    hot = [t for t in range(n) if seeds[t] >> 40]
+    assert len(hot) == 50 and all(got[t].peak == 1.0 for t in hot)
+    assert sum(1 for t in range(n) if got[t].peak < 1.0) >= 900
+    for t in (0, 1, 3, 13, 7, 27, 999):  # 44.1k stereo, 48k stereo, 48k mono, 48k mono, 48k hot, 48k hot, last
+        ch = [oracle.synth_f32(seeds[t], c, rates[t], frames[t]) for c in range(chans[t])]
+        want, wh = oracle.analyze_pcm(ch[0], ch[1] if chans[t] == 2 else None, rates[t])
+        assert np.array_equal(h[t], wh), f"track {t}"
+        assert got[t].peak == want["peak"] and got[t].loudness_db == want["loudness_db"] and got[t].gain_steps() == want["gain_steps"]
+    del buf
+    torch.cuda.empty_cache()
