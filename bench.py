@@ -31,6 +31,7 @@ import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
+PRE_ROLL_SECONDS = 0.25
 sys.path.insert(0, str(ROOT))
 
 RATE = 44100
@@ -168,6 +169,14 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Pre-roll, untimed and before the W warm-up steps: the shader clock and the power controller take some
+    # milliseconds to settle once the kernel starts running (the first ~10 ms run 10-15 % slower), and a short
+    # --warmup would otherwise put that ramp into the timed region.  The timed region below is exactly K steps.
+    pre_end = time.perf_counter() + PRE_ROLL_SECONDS
+    while time.perf_counter() < pre_end:
+        for _ in range(16):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()
