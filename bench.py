@@ -172,11 +172,12 @@ def main() -> int:
     # Pre-roll, untimed and before the W warm-up steps: the shader clock and the power controller take some
     # milliseconds to settle once the kernel starts running (the first ~10 ms run 10-15 % slower), and a short
     # --warmup would otherwise put that ramp into the timed region.  The timed region below is exactly K steps.
-    pre_end = time.perf_counter() + PRE_ROLL_SECONDS
-    while time.perf_counter() < pre_end:
-        for _ in range(16):
-            step()
-        torch.cuda.synchronize()
+    # The step count comes from the workload size, not from a clock: every rank must issue the same collectives.
+    pre_steps = max(4, min(8192, int(PRE_ROLL_SECONDS / (frames * ntr / 3.5e11))))
+    for i in range(pre_steps):
+        step()
+        if i % 64 == 63:
+            torch.cuda.synchronize()  # keep the host from running seconds ahead of the device
     for _ in range(args.warmup):
         step()
     fence()
