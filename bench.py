@@ -10,12 +10,14 @@ in HBM (generated there by the library's rg_synth kernel; include/rg_synth.h):
   N == 1   BASELINE configs[1]: one 10-minute 44.1 kHz stereo track (26 460 000 frames, 211.7 MB
            planar f32) -> per-track histogram, percentile, gain, peak.
   N  > 1   album mode, weak scaling: every rank owns one such 10-minute track per step; after the
-           per-rank kernels the 12 000-bin album histogram is all-reduced (sum) and the album peak
-           (max) over RCCL, then every rank runs the album percentile.  One rank per GPU, launched
+           per-rank kernels the [12 000-bin album histogram | album peak] packs of all ranks are
+           all-gathered over RCCL (one collective, on the stream of the batch) and folded on the
+           device (sum / max), then every rank runs the album percentile.  One rank per GPU, launched
            by torch.distributed.run.
 
-Timing: W warm-up steps, then exactly K steps between barrier + torch.cuda.synchronize() pairs;
-the time is the MAX over ranks; value = frames processed by all ranks / that time.
+Timing: an untimed pre-roll (0.25 s worth of steps, so that clock and power have settled), W warm-up
+steps, then exactly K steps between barrier + torch.cuda.synchronize() pairs; the time is the MAX
+over ranks; value = frames processed by all ranks / that time.
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (IIR+RMS+histogram),
 measured with HIP events on the stream it is launched on; `cpu_baseline` is the CPU oracle
 (a C restatement of the reference's sequential algorithm -- not the Rust binary, which cannot
