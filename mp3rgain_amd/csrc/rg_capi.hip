@@ -230,6 +230,7 @@ extern "C" void rg_destroy(rg_ctx *c) {
         S.h_desc.release();
         S.d_tm_rec.release();
         S.d_hist.release();
+        S.d_nonfinite.release();
         S.d_results.release();
         S.h_results.release();
         S.d_album_hist.release();

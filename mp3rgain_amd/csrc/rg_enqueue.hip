@@ -25,10 +25,10 @@ hipError_t rg_launch_track_results(const uint32_t *, const unsigned long long *,
 hipError_t rg_launch_album_merge(const uint32_t *, const unsigned long long *, uint32_t, uint32_t *, double *,
                                  hipStream_t);
 hipError_t rg_launch_tm_main(int fmt, int nch, const RgTmCoef *, const RgTmGeom *, const RgTmTrack *, uint32_t, uint32_t,
-                             double *, uint32_t, uint32_t *, uint64_t, hipStream_t);
+                             double *, uint32_t, uint32_t *, uint32_t *, uint64_t, hipStream_t);
 hipError_t rg_launch_tm_fix(int nch, const RgTmGeom *, const RgTmFixTables *, const RgTmTrack *, uint32_t, uint32_t,
-                            const double *, uint32_t, uint32_t *, unsigned long long *, uint32_t *, rg_track_result *,
-                            hipStream_t);
+                            const double *, uint32_t, uint32_t *, uint32_t *, unsigned long long *, uint32_t *,
+                            rg_track_result *, hipStream_t);
 }
 
 namespace {
@@ -304,6 +304,10 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
     uint32_t *const done_ptr = S.d_hist.p + n * (size_t)(RG_HISTOGRAM_SIZE + 2);
     RG_HIP(c, S.d_results.reserve(n));
     RG_HIP(c, S.h_results.reserve(n));
+    if (n > S.d_nonfinite.cap) {  // self-cleaning flags: zero once, when the buffer is (re)allocated
+        RG_HIP(c, S.d_nonfinite.reserve(n));
+        RG_HIP(c, hipMemsetAsync(S.d_nonfinite.p, 0, S.d_nonfinite.cap * sizeof(uint32_t), s));
+    }
 
     const unsigned char *base = (const unsigned char *)d_pcm_base;
     const bool use_tm = c->kernel_variant != 1;
@@ -441,13 +445,13 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
             rc = timing_begin(c, &e1);
             if (rc != RG_OK) return rc;
             RG_HIP(c, rg_launch_tm_main(gl.fmt, gl.nch, &gl.K, &gl.tb->geom, d_tm_tracks + gl.list_off,
-                                        (uint32_t)gl.list_n, gl.main_grid, S.d_tm_rec.p, gl.total_recs,
+                                        (uint32_t)gl.list_n, gl.main_grid, S.d_tm_rec.p, gl.total_recs, S.d_nonfinite.p,
                                         cleared ? nullptr : S.d_hist.p, (uint64_t)acc_words, s));
             if (gl.main_grid != 0) cleared = true;
             if (e1) RG_HIP(c, hipEventRecord(e1, s));
             RG_HIP(c, rg_launch_tm_fix(gl.nch, &gl.tb->geom, &gl.tb->fix, d_tm_tracks + gl.list_off,
-                                       (uint32_t)gl.list_n, gl.fix_grid, S.d_tm_rec.p, gl.total_recs, S.d_hist.p,
-                                       S.peak_ptr, done_ptr, S.d_results.p, s));
+                                       (uint32_t)gl.list_n, gl.fix_grid, S.d_tm_rec.p, gl.total_recs, S.d_nonfinite.p,
+                                       S.d_hist.p, S.peak_ptr, done_ptr, S.d_results.p, s));
         }
         if (n_k1) {
             hipEvent_t e1;

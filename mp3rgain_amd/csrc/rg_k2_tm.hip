@@ -347,7 +347,7 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
 template <int FMT>
 __global__ void __launch_bounds__(RG_TM_BLOCK_WIDE)
 rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restrict__ tracks, uint32_t n_tracks,
-                  double *__restrict__ rec, uint32_t total_recs, uint32_t lds_tables,
+                  double *__restrict__ rec, uint32_t total_recs, uint32_t *__restrict__ nonfinite, uint32_t lds_tables,
                   uint32_t *__restrict__ zero_words, uint64_t zero_count /* batch accumulators to clear, or nullptr */,
                   unsigned long long *__restrict__ dbg /* nullptr, or 6 words per wave: start, end, hw id, path, cycle counter start, end */) {
     typedef Fmt<FMT> F;
@@ -453,6 +453,13 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
         dbg[w + 3] = done ? 1ull : 0ull;
     }
 
+    // A sample that is not finite (NaN / Inf in float PCM) leaves the reference's filter state NaN for the rest of
+    // the track (src/replaygain.rs:586-616 has no reset): remember the first segment it happens in, the fix-up
+    // kernel turns every window from there on into a NaN window (bin 2000, as `NaN as i32` = 0 does)
+    {
+        const bool bad = active && !(fabs(st.A[0]) <= 1.7976931348623157e308);
+        if (__any(bad) && bad) atomicMax(&nonfinite[tr.track_index], 0xFFFFFFFFu - seg);
+    }
     // ---- segment record, structure-of-arrays: field f of channel c at ((c*RG_TM_REC + f) * total_recs + idx)
     if (active) {
         double *__restrict__ r = rec + (size_t)chan * RG_TM_REC * total_recs + ((size_t)tr.rec_base + seg);
@@ -496,7 +503,8 @@ __device__ __forceinline__ double tm_quad_half(GP Gm, const double (&sg)[RG_TM_D
 template <int NCH>
 __global__ void __launch_bounds__(RG_TM_BLOCK)
 rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__restrict__ tracks, uint32_t n_tracks,
-                 const double *__restrict__ rec, uint32_t total_recs, uint32_t *__restrict__ hist,
+                 const double *__restrict__ rec, uint32_t total_recs, uint32_t *__restrict__ nonfinite,
+                 uint32_t *__restrict__ hist,
                  unsigned long long *__restrict__ peak_bits, uint32_t *__restrict__ done_count,
                  rg_track_result *__restrict__ results,
                  unsigned long long *__restrict__ dbg /* nullptr, or 8 stage timestamps per block */) {
@@ -691,6 +699,9 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
 #pragma unroll
         for (int c = 0; c < NCH; ++c) S += 2.0 * (lin[c] + quad[c]);
     }
+    // windows at or after the first non-finite sample of the track are NaN windows (see the main kernel)
+    const uint32_t nf = nonfinite[tr.track_index];
+    if (nf != 0 && owner && (uint32_t)seg >= 0xFFFFFFFFu - nf) S = __longlong_as_double(0x7FF8000000000000ll);
     pieces[i] = owner ? S : 0.0;
     __syncthreads();
     if (wave == 0 && part_len != 0) {
@@ -766,6 +777,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
         TM_FIX_STAMP(6);
         const RgLoudness l = rg_block_loudness(hist + (size_t)tr.track_index * RG_HISTOGRAM_SIZE, pct_scan);
         if (i == 0) {
+            if (nf != 0) nonfinite[tr.track_index] = 0;  // every block of the track has read it: clean for the next batch
             const unsigned long long pb = atomicMax(&peak_bits[tr.track_index], 0ull);  // coherent read
             rg_store_track_result(results + tr.track_index, l, __longlong_as_double((long long)pb), tr.sample_rate,
                                   tr.file_type);
@@ -785,7 +797,7 @@ extern "C" void rg_tm_set_fix_debug_buffer(unsigned long long *d_buf) { g_tm_fix
 template <int FMT>
 static hipError_t launch_main_fmt(int nch, const RgTmCoef &K, const RgTmGeom &G, const RgTmTrack *d_tracks,
                                   uint32_t n_tracks, uint32_t grid, double *d_rec, uint32_t total_recs,
-                                  uint32_t *d_zero, uint64_t zero_count, hipStream_t s) {
+                                  uint32_t *d_nonfinite, uint32_t *d_zero, uint64_t zero_count, hipStream_t s) {
     // LDS: T12 (H10 x 12 doubles) + T2 ((L - H10) x 2 doubles) + one 4 KiB PCM tile per wave
     size_t lds = rg_tm_lds_bytes(G.L, G.H10, G.block);
     uint32_t lds_tables = lds <= RG_TM_LDS_BYTES ? 1u : 0u;
@@ -796,31 +808,32 @@ static hipError_t launch_main_fmt(int nch, const RgTmCoef &K, const RgTmGeom &G,
         attr_set = true;
     }
     hipLaunchKernelGGL((rg_tm_main_kernel<FMT>), dim3(grid, nch), dim3(G.block), lds, s, K, G, d_tracks, n_tracks,
-                       d_rec, total_recs, lds_tables, d_zero, zero_count, g_tm_debug);
+                       d_rec, total_recs, d_nonfinite, lds_tables, d_zero, zero_count, g_tm_debug);
     return hipGetLastError();
 }
 
 extern "C" hipError_t rg_launch_tm_main(int fmt, int nch, const RgTmCoef *K, const RgTmGeom *G,
                                         const RgTmTrack *d_tracks, uint32_t n_tracks, uint32_t grid, double *d_rec,
-                                        uint32_t total_recs, uint32_t *d_zero, uint64_t zero_count, hipStream_t s) {
+                                        uint32_t total_recs, uint32_t *d_nonfinite, uint32_t *d_zero, uint64_t zero_count,
+                                        hipStream_t s) {
     if (grid == 0) return hipSuccess;
     switch (fmt) {
-        case RG_FMT_F32_PLANAR: return launch_main_fmt<RG_FMT_F32_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_zero, zero_count, s);
-        case RG_FMT_S16_PLANAR: return launch_main_fmt<RG_FMT_S16_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_zero, zero_count, s);
-        default: return launch_main_fmt<RG_FMT_S32_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_zero, zero_count, s);
+        case RG_FMT_F32_PLANAR: return launch_main_fmt<RG_FMT_F32_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_nonfinite, d_zero, zero_count, s);
+        case RG_FMT_S16_PLANAR: return launch_main_fmt<RG_FMT_S16_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_nonfinite, d_zero, zero_count, s);
+        default: return launch_main_fmt<RG_FMT_S32_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_nonfinite, d_zero, zero_count, s);
     }
 }
 
 extern "C" hipError_t rg_launch_tm_fix(int nch, const RgTmGeom *G, const RgTmFixTables *FT, const RgTmTrack *d_tracks,
                                        uint32_t n_tracks, uint32_t grid, const double *d_rec, uint32_t total_recs,
-                                       uint32_t *d_hist, unsigned long long *d_peak_bits, uint32_t *d_done,
-                                       rg_track_result *d_results, hipStream_t s) {
+                                       uint32_t *d_nonfinite, uint32_t *d_hist, unsigned long long *d_peak_bits,
+                                       uint32_t *d_done, rg_track_result *d_results, hipStream_t s) {
     if (grid == 0) return hipSuccess;
     if (nch == 1)
         hipLaunchKernelGGL((rg_tm_fix_kernel<1>), dim3(grid), dim3(RG_TM_BLOCK), 0, s, *G, *FT, d_tracks, n_tracks, d_rec,
-                           total_recs, d_hist, d_peak_bits, d_done, d_results, g_tm_fix_debug);
+                           total_recs, d_nonfinite, d_hist, d_peak_bits, d_done, d_results, g_tm_fix_debug);
     else
         hipLaunchKernelGGL((rg_tm_fix_kernel<2>), dim3(grid), dim3(RG_TM_BLOCK), 0, s, *G, *FT, d_tracks, n_tracks, d_rec,
-                           total_recs, d_hist, d_peak_bits, d_done, d_results, g_tm_fix_debug);
+                           total_recs, d_nonfinite, d_hist, d_peak_bits, d_done, d_results, g_tm_fix_debug);
     return hipGetLastError();
 }

@@ -244,3 +244,38 @@ def test_device_synth_matches_host_and_device_resident_path(analyzer, oracle, ca
     aw, awh = oracle.album_from_hists([w[1] for w in wants], [w[0]["peak"] for w in wants])
     assert np.array_equal(ah, awh)
     assert alb.album_loudness_db == aw["album_loudness_db"] and alb.album_peak == aw["album_peak"]
+
+
+@pytest.mark.parametrize("where", ["start", "middle", "last_window", "both_channels"])
+@pytest.mark.parametrize("what", ["nan", "inf"])
+def test_non_finite_samples_poison_the_rest_of_the_track(_ctx, oracle, where, what):
+    """A NaN (or an Inf, which turns into NaN one subtraction later) leaves the reference's filter state NaN for the
+    rest of the track: every window from there on is a NaN window and lands in bin 2000 (`NaN as i32` = 0,
+    src/replaygain.rs:755-758); the peak ignores NaN (`f64::max`).  Variant 2 reproduces it through a per-track
+    first-bad-segment flag; a clean track in the same batch and the next batch on the same buffers are unaffected."""
+    import mp3rgain_amd as rg
+
+    an = _ctx
+    an.set_kernel(2)
+    for key in (1, 2, 3):
+        an.set_tuning(key, 0)
+    rate, n = 44100, 44100 * 4 + 1234
+    l, r = oracle.synth_f32(91, 0, rate, n).copy(), oracle.synth_f32(91, 1, rate, n).copy()
+    bad = np.float32(np.nan) if what == "nan" else np.float32(np.inf)
+    at = {"start": 0, "middle": 2205 * 37 + 1000, "last_window": n - 50, "both_channels": 2205 * 11 + 5}[where]
+    l[at] = bad
+    if where == "both_channels":
+        r[at + 3000] = -bad
+    clean_l, clean_r = oracle.synth_f32(92, 0, rate, n), oracle.synth_f32(92, 1, rate, n)
+    want, wh = oracle.analyze_pcm(l, r, rate)
+    cwant, cwh = oracle.analyze_pcm(clean_l, clean_r, rate)
+    for rep in range(10):  # every slot; the flag must be clean again afterwards
+        got, h = an.analyze_tracks([rg.PcmTrack([l, r], rate), rg.PcmTrack([clean_l, clean_r], rate)], return_histograms=True)
+        assert np.array_equal(h[0], wh), f"rep {rep}: bins differ at {np.nonzero(h[0] != wh)[0][:8]}"
+        assert got[0].loudness_db == want["loudness_db"]
+        assert got[0].peak == want["peak"] or (np.isinf(got[0].peak) and np.isinf(want["peak"]))
+        assert np.array_equal(h[1], cwh) and got[1].loudness_db == cwant["loudness_db"] and got[1].peak == cwant["peak"]
+        ok, hc = an.analyze_tracks([rg.PcmTrack([clean_l, clean_r], rate)], return_histograms=True)
+        assert np.array_equal(hc[0], cwh)
+    assert wh[2000] >= (n - at) // 2205  # the poisoned windows really are in bin 2000
+    an.set_kernel(0)
