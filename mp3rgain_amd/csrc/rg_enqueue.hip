@@ -318,7 +318,14 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
     for (size_t t = 0; t < n; ++t) {
         fill_common(c, tracks[t], base, (uint32_t)t, c->h_tracks[t]);
         const int ri = rg_rate_index(tracks[t].sample_rate);
-        if (use_tm && c->design[ri].stable) {
+        // Auto mode keeps variant 2 to the rates where its state representation is well conditioned.  At 64 and
+        // 96 kHz the Yule-Walker poles crowd z = 1: unit DF2T states reach the output with gains of 71 and 478
+        // (<= 9 at 48 kHz and below, rg_tm_design), so after an impulse or with a DC offset the moments cancel
+        // to ~1e-8 of the state energy and a nearly silent window can land a few bins off.  Variant 1 follows the
+        // reference's own evaluation order and is exact at every rate (0 of 4000 random tracks differ; variant 2:
+        // 14, all at these two rates), at 1/60 of the speed -- and no MP3 has these rates.
+        const bool tm_rate = c->kernel_variant == 2 || tracks[t].sample_rate <= 48000u;
+        if (use_tm && tm_rate && c->design[ri].stable) {
             const int nch = tracks[t].channels >= 2 ? 2 : 1;
             TmGroup *g = nullptr;
             for (auto &q : groups)
