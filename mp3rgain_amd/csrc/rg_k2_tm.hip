@@ -742,6 +742,10 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
             double total = 0.0;
             for (uint32_t q = 0; q < G.k; ++q) total += pieces[warm + i * G.k + q];
             if (NCH == 1) total *= 2.0;  // add_mono_sample feeds both sums (src/replaygain.rs:731-740)
+            // a sum of squares is never negative; A + 2 B.sigma + sigma'G sigma of a window whose true energy is
+            // far below the energy of the filter state (the high-passed tail of a DC offset, say) can come out a
+            // rounding error below zero, and log10 of that would be a NaN window.  (A NaN stays a NaN.)
+            if (total < 0.0) total = 0.0;
             const uint64_t rem = tr.frames - widx * G.W;
             const uint32_t n = rem < G.W ? (uint32_t)rem : G.W;
             bin = rg_window_bin(total, 0.0, n);
