@@ -357,3 +357,60 @@ def test_gpu_steps_feed_the_patcher(mg, copy_test_file):
     before = mg.analyze(path)
     assert mg.apply_gain_db(path, 4.3) == 40
     assert mg.analyze(path).max_gain == min(255, before.max_gain + steps)
+
+
+def test_mutated_files_agree_with_the_restatement(mg, mo):
+    """600 damaged variants of the fixture files -- bit flips, overwritten runs, truncations, junk prefixes, bogus ID3v2
+    sizes, synthetic MPEG-2 / 2.5 / mono / CRC headers spliced in -- through analyze and apply (clamped, wrapped, per
+    channel): the C++ code and the Python restatement agree on every byte, frame count and error."""
+    import random
+
+    rng = random.Random(4242)
+    bases = [(FIX / n).read_bytes() for n in FILES]
+    hdrs = [bytes([0xFF, 0xF3, 0x90, 0xC0]), bytes([0xFF, 0xE3, 0x54, 0x40]), bytes([0xFF, 0xFA, 0x92, 0x00]),
+            bytes([0xFF, 0xFB, 0xE4, 0x40]), bytes([0xFF, 0xF2, 0x18, 0xC4])]
+    agree_frames = 0
+    for i in range(600):
+        b = bytearray(rng.choice(bases))
+        for _ in range(rng.randint(0, 4)):
+            kind = rng.randint(0, 6)
+            pos = rng.randrange(0, max(1, len(b) - 8))
+            if kind == 0:
+                b[pos] ^= 1 << rng.randint(0, 7)
+            elif kind == 1:
+                n = rng.randint(1, 600)
+                b[pos:pos + n] = bytes(rng.getrandbits(8) for _ in range(min(n, len(b) - pos)))
+            elif kind == 2:
+                del b[rng.randrange(0, len(b)):]
+            elif kind == 3:
+                b[0:0] = bytes(rng.getrandbits(8) for _ in range(rng.randint(1, 300)))
+            elif kind == 4:
+                b[0:0] = b"ID3\x03\x00\x00" + bytes([rng.randint(0, 127) for _ in range(4)])
+            elif kind == 5:
+                b[pos:pos + 4] = rng.choice(hdrs)
+            else:
+                b[pos:pos + 2] = b"\xFF" + bytes([rng.choice([0xFB, 0xFA, 0xF3, 0xE3, 0xFF])])
+        data = bytes(b)
+        try:
+            want = mo.analyze(data)
+        except ValueError as ex:
+            with pytest.raises(mg.Mp3GainError, match=str(ex)):
+                mg.analyze_data(data)
+            continue
+        got = mg.analyze_data(data)
+        assert (got.frame_count, got.min_gain, got.max_gain, got.headroom_steps) == \
+            (want["frame_count"], want["min_gain"], want["max_gain"], want["headroom_steps"]), f"variant {i}"
+        assert got.avg_gain == want["avg_gain"] and got.mpeg_version == want["mpeg_version"] and got.channel_mode == want["channel_mode"]
+        agree_frames += got.frame_count
+        steps = rng.choice([1, -1, 3, -7, 100, -300, 255])
+        for wrap, channel in ((False, None), (True, None), (False, 0), (False, 1)):
+            ref = bytearray(data)
+            try:
+                n_ref = mo.apply_gain(ref, steps, wrap, channel)
+            except (IndexError, ValueError):
+                continue  # the restatement has no answer (a location past the end): nothing to compare
+            if channel is not None and want["channel_mode"] == "Mono":
+                continue  # channel gain on mono is an error at file level (lib.rs:757-759)
+            out, n = mg.apply_gain_data(data, steps, wrap=wrap, channel=None if channel is None else mg.Channel(channel))
+            assert (n, out) == (n_ref, bytes(ref)), f"variant {i} steps {steps} wrap {wrap} channel {channel}"
+    assert agree_frames > 5000
