@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION 1
+#define RG_ABI_VERSION 2
 #define RG_HISTOGRAM_SIZE 12000         /* HISTOGRAM_SIZE        src/replaygain.rs:630 */
 #define RG_HISTOGRAM_OFFSET 2000        /* HISTOGRAM_OFFSET      src/replaygain.rs:635 */
 #define RG_REPLAYGAIN_REFERENCE_DB 89.0 /* REPLAYGAIN_REFERENCE_DB src/replaygain.rs:37 */
@@ -80,7 +80,17 @@ typedef struct rg_track_result {
     int32_t gain_steps;
     uint32_t windows; /* number of 50 ms windows that landed in the histogram */
     uint32_t file_type;
+    uint32_t flags;   /* RG_TRACK_FLAG_* */
+    uint32_t reserved;
 } rg_track_result;
+/* the track held samples that are not finite (NaN / Inf): every window from the first one on is a NaN window */
+#define RG_TRACK_FLAG_NONFINITE 1u
+/* Variant 2 only: some window's energy is more than RG_TM_KAPPA times smaller than the energies it was
+ * assembled from (the high-passed tail of a large DC offset, say), so its bin may be a few 0.01 dB off.  The
+ * synchronous entry points (rg_analyze_pcm_batch, rg_analyze_album_pcm, rg_analyze_wav_batch and the file-level
+ * functions) then repeat the batch with the order-faithful kernel when the variant is 0 (auto) and return exact
+ * results with the flag cleared; callers of rg_enqueue_pcm_batch / rg_collect see the flag and decide. */
+#define RG_TRACK_FLAG_IMPRECISE 2u
 
 /* AlbumGainResult minus the per-track vector (src/replaygain.rs:79-95) */
 typedef struct rg_album_result {

@@ -48,6 +48,8 @@ class TrackResult(C.Structure):
         ("gain_steps", C.c_int32),
         ("windows", C.c_uint32),
         ("file_type", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 

@@ -231,6 +231,7 @@ extern "C" void rg_destroy(rg_ctx *c) {
         S.d_tm_rec.release();
         S.d_hist.release();
         S.d_nonfinite.release();
+        S.d_imprecise.release();
         S.d_results.release();
         S.h_results.release();
         S.d_album_hist.release();
@@ -560,6 +561,23 @@ extern "C" int rg_album_allreduce(rg_ctx *c, void *comm) {
 }
 
 // ================================ synchronous API ====================================================
+namespace {
+// Variant 2 marks tracks with a window it could not resolve reliably (RG_TRACK_FLAG_IMPRECISE).  In auto mode the
+// synchronous entry points then repeat the batch with the order-faithful kernel, which is exact and ~60x slower.
+bool needs_exact_pass(const rg_ctx *c, const rg_track_result *res, size_t n) {
+    if (c->kernel_variant != 0 || !res) return false;
+    for (size_t i = 0; i < n; ++i)
+        if (res[i].flags & RG_TRACK_FLAG_IMPRECISE) return true;
+    return false;
+}
+struct ExactPass {  // scoped switch to variant 1
+    rg_ctx *c;
+    int saved;
+    explicit ExactPass(rg_ctx *ctx) : c(ctx), saved(ctx->kernel_variant) { c->kernel_variant = 1; }
+    ~ExactPass() { c->kernel_variant = saved; }
+};
+}  // namespace
+
 extern "C" int rg_analyze_pcm_batch(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *pcm_base,
                                     size_t pcm_bytes, int on_device, rg_track_result *out, uint32_t *hist_out) {
     if (!c) return RG_ERR_INVALID_ARG;
@@ -567,6 +585,11 @@ extern "C" int rg_analyze_pcm_batch(rg_ctx *c, const rg_track_desc *tracks, size
     const void *d_base = nullptr;
     int rc = stage_pcm(c, pcm_base, pcm_bytes, on_device, &d_base);
     if (rc != RG_OK) return rc;
+    rc = rg_enqueue_impl(c, tracks, n, d_base, pcm_bytes, 0);
+    if (rc != RG_OK) return rc;
+    rc = rg_collect(c, out, hist_out);
+    if (rc != RG_OK || !needs_exact_pass(c, out, n)) return rc;
+    ExactPass exact(c);
     rc = rg_enqueue_impl(c, tracks, n, d_base, pcm_bytes, 0);
     if (rc != RG_OK) return rc;
     return rg_collect(c, out, hist_out);
@@ -582,8 +605,21 @@ extern "C" int rg_analyze_album_pcm(rg_ctx *c, const rg_track_desc *tracks, size
     if (rc != RG_OK) return rc;
     rc = rg_enqueue_impl(c, tracks, n, d_base, pcm_bytes, 1);
     if (rc != RG_OK) return rc;
-    rc = rg_collect(c, tracks_out, nullptr);
+    std::vector<rg_track_result> probe;
+    rg_track_result *res = tracks_out;
+    if (!res && n) {  // the flags are needed even when the caller does not want the per-track results
+        probe.resize(n);
+        res = probe.data();
+    }
+    rc = rg_collect(c, res, nullptr);
     if (rc != RG_OK) return rc;
+    if (needs_exact_pass(c, res, n)) {
+        ExactPass exact(c);
+        rc = rg_enqueue_impl(c, tracks, n, d_base, pcm_bytes, 1);
+        if (rc != RG_OK) return rc;
+        rc = rg_collect(c, tracks_out, nullptr);
+        if (rc != RG_OK) return rc;
+    }
     return rg_album_finish(c, album_out, album_hist_out);
 }
 

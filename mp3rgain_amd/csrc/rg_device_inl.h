@@ -115,7 +115,7 @@ static __device__ __forceinline__ int32_t rg_round_steps(double gain_db) {
 
 
 static __device__ __forceinline__ void rg_store_track_result(rg_track_result *out, const RgLoudness &l, double peak,
-                                                             uint32_t sample_rate, uint32_t file_type) {
+                                                             uint32_t sample_rate, uint32_t file_type, uint32_t flags = 0) {
     rg_track_result r;
     r.loudness_db = l.loudness_db;
     r.gain_db = RG_PINK_REF - l.loudness_db;
@@ -124,5 +124,7 @@ static __device__ __forceinline__ void rg_store_track_result(rg_track_result *ou
     r.gain_steps = rg_round_steps(r.gain_db);
     r.windows = (uint32_t)l.total;
     r.file_type = file_type;
+    r.flags = flags;
+    r.reserved = 0;
     *out = r;
 }

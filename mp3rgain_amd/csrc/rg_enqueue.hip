@@ -27,7 +27,7 @@ hipError_t rg_launch_album_merge(const uint32_t *, const unsigned long long *, u
 hipError_t rg_launch_tm_main(int fmt, int nch, const RgTmCoef *, const RgTmGeom *, const RgTmTrack *, uint32_t, uint32_t,
                              double *, uint32_t, uint32_t *, uint32_t *, uint64_t, hipStream_t);
 hipError_t rg_launch_tm_fix(int nch, const RgTmGeom *, const RgTmFixTables *, const RgTmTrack *, uint32_t, uint32_t,
-                            const double *, uint32_t, uint32_t *, uint32_t *, unsigned long long *, uint32_t *,
+                            const double *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *, uint32_t *,
                             rg_track_result *, hipStream_t);
 }
 
@@ -308,6 +308,10 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
         RG_HIP(c, S.d_nonfinite.reserve(n));
         RG_HIP(c, hipMemsetAsync(S.d_nonfinite.p, 0, S.d_nonfinite.cap * sizeof(uint32_t), s));
     }
+    if (n > S.d_imprecise.cap) {
+        RG_HIP(c, S.d_imprecise.reserve(n));
+        RG_HIP(c, hipMemsetAsync(S.d_imprecise.p, 0, S.d_imprecise.cap * sizeof(uint32_t), s));
+    }
 
     const unsigned char *base = (const unsigned char *)d_pcm_base;
     const bool use_tm = c->kernel_variant != 1;
@@ -458,7 +462,7 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
             if (e1) RG_HIP(c, hipEventRecord(e1, s));
             RG_HIP(c, rg_launch_tm_fix(gl.nch, &gl.tb->geom, &gl.tb->fix, d_tm_tracks + gl.list_off,
                                        (uint32_t)gl.list_n, gl.fix_grid, S.d_tm_rec.p, gl.total_recs, S.d_nonfinite.p,
-                                       S.d_hist.p, S.peak_ptr, done_ptr, S.d_results.p, s));
+                                       S.d_imprecise.p, S.d_hist.p, S.peak_ptr, done_ptr, S.d_results.p, s));
         }
         if (n_k1) {
             hipEvent_t e1;

@@ -311,12 +311,9 @@ extern "C" int rg_analyze_wav_batch(rg_ctx *c, const void *const *wav, const siz
     size_t arena_bytes = 0;
     int rc = stage_wavs(c, wav, wav_len, n, &descs, &arena_bytes);
     if (rc != RG_OK) return rc;
-    rc = rg_enqueue_impl(c, descs.data(), n, c->d_arena.p, arena_bytes, album ? 1 : 0);
-    if (rc != RG_OK) return rc;
-    rc = rg_collect(c, out, nullptr);
-    if (rc != RG_OK) return rc;
-    if (album) return rg_album_finish(c, album_out, nullptr);
-    return RG_OK;
+    // the planar arena is on the device: the rest is rg_analyze_pcm_batch / rg_analyze_album_pcm, exact pass included
+    if (album) return rg_analyze_album_pcm(c, descs.data(), n, c->d_arena.p, arena_bytes, 1, out, album_out, nullptr);
+    return rg_analyze_pcm_batch(c, descs.data(), n, c->d_arena.p, arena_bytes, 1, out, nullptr);
 }
 
 extern "C" int rg_analyze_track(rg_ctx *c, const char *path, int32_t track_index, rg_track_result *out) {

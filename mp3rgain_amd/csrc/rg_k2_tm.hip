@@ -504,7 +504,7 @@ template <int NCH>
 __global__ void __launch_bounds__(RG_TM_BLOCK)
 rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__restrict__ tracks, uint32_t n_tracks,
                  const double *__restrict__ rec, uint32_t total_recs, uint32_t *__restrict__ nonfinite,
-                 uint32_t *__restrict__ hist,
+                 uint32_t *__restrict__ imprecise, uint32_t *__restrict__ hist,
                  unsigned long long *__restrict__ peak_bits, uint32_t *__restrict__ done_count,
                  rg_track_result *__restrict__ results,
                  unsigned long long *__restrict__ dbg /* nullptr, or 8 stage timestamps per block */) {
@@ -519,6 +519,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     __shared__ double edge[RG_TM_BLOCK / 64][RG_TM_EDGE][NCH * RG_TM_DIM];
     __shared__ uint64_t pct_scan[RG_PCT_THREADS];
     __shared__ double pieces[RG_TM_BLOCK];
+    __shared__ double pieces_m[RG_TM_BLOCK];  // A + sigma'G sigma of the same segments: what the sum was assembled from
     __shared__ int bins[RG_TM_BLOCK];
     __shared__ int is_last;
     // the (at most one) segment of this block that the track ends in: its start state and length, for the
@@ -646,7 +647,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
         for (int j = 0; j < RG_TM_DIM; ++j) sgm[c][j] = from_below(w[c][j], 1, c * RG_TM_DIM + j);
 
     TM_FIX_STAMP(2);
-    double S = 0.0;
+    double S = 0.0, Mseg = 0.0;
     if (owner) {
         const uint64_t start = (uint64_t)seg * G.L;
         const uint64_t rem = tr.frames - start;
@@ -663,6 +664,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
             quad[c] = 0.0;
             pk = fmax(pk, r[(size_t)25 * total_recs]);
             S += r[0];
+            Mseg += r[0];
         }
         // full segments share one Gram matrix (LDS broadcast reads, one row at a time for all channels: the
         // scheduling fences keep the compiler from hoisting all 78 reads into registers).  The segment a
@@ -697,12 +699,16 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
             part_lane = i;
         }
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) S += 2.0 * (lin[c] + quad[c]);
+        for (int c = 0; c < NCH; ++c) {
+            S += 2.0 * (lin[c] + quad[c]);
+            Mseg += 2.0 * quad[c];
+        }
     }
     // windows at or after the first non-finite sample of the track are NaN windows (see the main kernel)
     const uint32_t nf = nonfinite[tr.track_index];
     if (nf != 0 && owner && (uint32_t)seg >= 0xFFFFFFFFu - nf) S = __longlong_as_double(0x7FF8000000000000ll);
     pieces[i] = owner ? S : 0.0;
+    pieces_m[i] = owner ? Mseg : 0.0;
     __syncthreads();
     if (wave == 0 && part_len != 0) {
         // term p of the packed upper triangle is G[p] s_j s_q (halved on the diagonal); two terms per lane
@@ -718,7 +724,10 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) quad += __shfl_xor(quad, off, 64);
-        if (lane == 0) pieces[part_lane] += 2.0 * quad;
+        if (lane == 0) {
+            pieces[part_lane] += 2.0 * quad;
+            pieces_m[part_lane] += 2.0 * quad;
+        }
     }
     // peak of the block's segments: wave max, then one atomic per wave (the bit pattern of a
     // non-negative double is ordered like the value)
@@ -736,22 +745,28 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     TM_FIX_STAMP(3);
     // ---- 50 ms windows: k consecutive segments each (finish_window, src/replaygain.rs:743-765) ----
     int bin = -1;
+    bool cancelled = false;
     if ((uint32_t)i < G.fix_windows) {
         const uint64_t widx = (uint64_t)b * G.fix_windows + i;
         if (widx < tr.n_windows) {
-            double total = 0.0;
-            for (uint32_t q = 0; q < G.k; ++q) total += pieces[warm + i * G.k + q];
+            double total = 0.0, mtot = 0.0;
+            for (uint32_t q = 0; q < G.k; ++q) {
+                total += pieces[warm + i * G.k + q];
+                mtot += pieces_m[warm + i * G.k + q];
+            }
             if (NCH == 1) total *= 2.0;  // add_mono_sample feeds both sums (src/replaygain.rs:731-740)
             // a sum of squares is never negative; A + 2 B.sigma + sigma'G sigma of a window whose true energy is
             // far below the energy of the filter state (the high-passed tail of a DC offset, say) can come out a
             // rounding error below zero, and log10 of that would be a NaN window.  (A NaN stays a NaN.)
             if (total < 0.0) total = 0.0;
+            if (mtot > RG_TM_KAPPA * total) cancelled = true;  // NaN compares false: a NaN window is not "imprecise"
             const uint64_t rem = tr.frames - widx * G.W;
             const uint32_t n = rem < G.W ? (uint32_t)rem : G.W;
             bin = rg_window_bin(total, 0.0, n);
         }
     }
     bins[i] = bin;
+    if (__any(cancelled) && lane == 0) tm_performed(atomicOr(&imprecise[tr.track_index], 1u));
     __syncthreads();
     // ---- LDS-side merge of equal bins, one global atomic per distinct bin of this block ----------
     if (bin >= 0) {
@@ -782,9 +797,11 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
         const RgLoudness l = rg_block_loudness(hist + (size_t)tr.track_index * RG_HISTOGRAM_SIZE, pct_scan);
         if (i == 0) {
             if (nf != 0) nonfinite[tr.track_index] = 0;  // every block of the track has read it: clean for the next batch
+            const uint32_t imp = atomicExch(&imprecise[tr.track_index], 0u);  // coherent read, and clean again
+            const uint32_t flags = (nf != 0 ? RG_TRACK_FLAG_NONFINITE : 0u) | (imp != 0 ? RG_TRACK_FLAG_IMPRECISE : 0u);
             const unsigned long long pb = atomicMax(&peak_bits[tr.track_index], 0ull);  // coherent read
             rg_store_track_result(results + tr.track_index, l, __longlong_as_double((long long)pb), tr.sample_rate,
-                                  tr.file_type);
+                                  tr.file_type, flags);
         }
         TM_FIX_STAMP(7);
     }
@@ -830,14 +847,15 @@ extern "C" hipError_t rg_launch_tm_main(int fmt, int nch, const RgTmCoef *K, con
 
 extern "C" hipError_t rg_launch_tm_fix(int nch, const RgTmGeom *G, const RgTmFixTables *FT, const RgTmTrack *d_tracks,
                                        uint32_t n_tracks, uint32_t grid, const double *d_rec, uint32_t total_recs,
-                                       uint32_t *d_nonfinite, uint32_t *d_hist, unsigned long long *d_peak_bits,
-                                       uint32_t *d_done, rg_track_result *d_results, hipStream_t s) {
+                                       uint32_t *d_nonfinite, uint32_t *d_imprecise, uint32_t *d_hist,
+                                       unsigned long long *d_peak_bits, uint32_t *d_done, rg_track_result *d_results,
+                                       hipStream_t s) {
     if (grid == 0) return hipSuccess;
     if (nch == 1)
         hipLaunchKernelGGL((rg_tm_fix_kernel<1>), dim3(grid), dim3(RG_TM_BLOCK), 0, s, *G, *FT, d_tracks, n_tracks, d_rec,
-                           total_recs, d_nonfinite, d_hist, d_peak_bits, d_done, d_results, g_tm_fix_debug);
+                           total_recs, d_nonfinite, d_imprecise, d_hist, d_peak_bits, d_done, d_results, g_tm_fix_debug);
     else
         hipLaunchKernelGGL((rg_tm_fix_kernel<2>), dim3(grid), dim3(RG_TM_BLOCK), 0, s, *G, *FT, d_tracks, n_tracks, d_rec,
-                           total_recs, d_nonfinite, d_hist, d_peak_bits, d_done, d_results, g_tm_fix_debug);
+                           total_recs, d_nonfinite, d_imprecise, d_hist, d_peak_bits, d_done, d_results, g_tm_fix_debug);
     return hipGetLastError();
 }

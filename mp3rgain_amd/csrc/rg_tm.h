@@ -32,6 +32,9 @@
 #define RG_TM_BLOCK_WIDE 768
 #define RG_TM_WAVE_TILE_BYTES 4096  // PCM staging tile of one wave: 64 rows x 16 frames x 4 B
 #define RG_TM_LDS_BYTES (160u * 1024u)
+// a window is flagged imprecise when the zero-state and transient energies it is assembled from exceed its own
+// energy by this factor (rounding then reaches ~1e-14 x KAPPA of the result: 1e-8 of a value, 4e-6 of a bin)
+#define RG_TM_KAPPA 1.0e6
 #define RG_TM_MAX_ROUNDS 4    // the doubling scan reaches 2^4 = 16 predecessors
 #define RG_TM_EDGE 16         // lanes of a wave whose scan values are visible to the next wave (>= 2^(MAX_ROUNDS-1), and 1 for the final shift)
 

@@ -54,6 +54,7 @@ class ReplayGainResult:
     sample_rate: int
     file_type: AudioFileType = AudioFileType.Mp3
     windows: int = 0
+    flags: int = 0  # RG_TRACK_FLAG_*: 1 = non-finite samples in the track, 2 = a window variant 2 could not resolve
 
     def gain_steps(self) -> int:
         return _capi.load().rg_gain_steps(self.gain_db)
@@ -386,7 +387,7 @@ class Analyzer:
 
 
 def _to_result(r: _capi.TrackResult, file_type: AudioFileType) -> ReplayGainResult:
-    return ReplayGainResult(r.loudness_db, r.gain_db, r.peak, r.sample_rate, AudioFileType(int(file_type)), r.windows)
+    return ReplayGainResult(r.loudness_db, r.gain_db, r.peak, r.sample_rate, AudioFileType(int(file_type)), r.windows, r.flags)
 
 
 _default: Optional[Analyzer] = None

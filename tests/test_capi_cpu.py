@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(capi):
     raw = C.CDLL(str(_capi.LIB_PATH))
     for name in declared:
         assert hasattr(raw, name), f"{name} not exported"
-    assert capi.rg_abi_version() == 1
+    assert capi.rg_abi_version() == 2
     assert capi.rg_is_available() == 1
 
 
@@ -36,7 +36,7 @@ def test_struct_layouts_match_the_header():
     from mp3rgain_amd import _capi
 
     assert C.sizeof(_capi.TrackDesc) == 24
-    assert C.sizeof(_capi.TrackResult) == 40
+    assert C.sizeof(_capi.TrackResult) == 48
     assert C.sizeof(_capi.AlbumResult) == 32
     assert C.sizeof(_capi.PeakResult) == 24
     assert C.sizeof(_capi.DeviceView) == 40

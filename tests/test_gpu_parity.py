@@ -275,6 +275,7 @@ def test_non_finite_samples_poison_the_rest_of_the_track(_ctx, oracle, where, wh
         assert got[0].loudness_db == want["loudness_db"]
         assert got[0].peak == want["peak"] or (np.isinf(got[0].peak) and np.isinf(want["peak"]))
         assert np.array_equal(h[1], cwh) and got[1].loudness_db == cwant["loudness_db"] and got[1].peak == cwant["peak"]
+        assert got[0].flags & 1 and not got[1].flags & 1  # RG_TRACK_FLAG_NONFINITE
         ok, hc = an.analyze_tracks([rg.PcmTrack([clean_l, clean_r], rate)], return_histograms=True)
         assert np.array_equal(hc[0], cwh)
     assert wh[2000] >= (n - at) // 2205  # the poisoned windows really are in bin 2000
@@ -417,7 +418,7 @@ def test_pathological_signals(_ctx, oracle):
     for key in (1, 2, 3):
         an.set_tuning(key, 0)
     cases = _pathological_cases(int(os.environ.get("RG_FUZZ_CASES", "240")))
-    inexact = 0
+    inexact = flagged = 0
     for lo in range(0, len(cases), 16):
         part = cases[lo:lo + 16]
         got, h = an.analyze_tracks([rg.PcmTrack(ch, rate) for rate, ch, _ in part], return_histograms=True)
@@ -428,8 +429,10 @@ def test_pathological_signals(_ctx, oracle):
             assert h[k][2000] == wh[2000], f"{where}: NaN windows"
             assert abs(got[k].loudness_db - want["loudness_db"]) <= DB_TOL, where
             assert int(h[k].sum()) == int(wh.sum()), where
+            flagged += 1 if got[k].flags & 2 else 0
             if not np.array_equal(h[k], wh):
                 inexact += 1
+                assert got[k].flags & 2, f"{where}: a displaced window in a track that is not flagged imprecise"
                 # every displaced window sits within 3 bins (0.03 dB) of its own: the running difference of the
                 # two histograms is never more than a couple of windows and is back at zero at most 3 bins later
                 run = np.cumsum(h[k].astype(np.int64) - wh.astype(np.int64))
@@ -438,4 +441,15 @@ def test_pathological_signals(_ctx, oracle):
                 assert np.abs(run).max() <= 2 and len(nz) <= 16 and longest <= 3, f"{where}: bins {np.nonzero(h[k] != wh)[0][:8]}"
                 assert got[k].loudness_db == want["loudness_db"], where
     assert inexact <= max(2, len(cases) // 100), f"{inexact} of {len(cases)} tracks with a displaced window"
+    assert flagged >= inexact
+    # auto mode: the synchronous entry point repeats a batch that has a flagged track with the order-faithful
+    # kernel, so every bin of every track is the oracle's, and no flag is left
     an.set_kernel(0)
+    for lo in range(0, len(cases), 16):
+        part = cases[lo:lo + 16]
+        got, h = an.analyze_tracks([rg.PcmTrack(ch, rate) for rate, ch, _ in part], return_histograms=True)
+        for k, (rate, ch, kinds) in enumerate(part):
+            want, wh = oracle.analyze_pcm(ch[0], ch[1] if len(ch) > 1 else None, rate)
+            assert np.array_equal(h[k], wh) and got[k].peak == want["peak"] and got[k].loudness_db == want["loudness_db"], \
+                f"auto mode, case {lo + k}: {rate} Hz, kinds {kinds}"
+            assert not got[k].flags & 2
