@@ -22,9 +22,9 @@
 // ---- kernel launchers (defined in the kernel translation units) --------------------------------
 extern "C" {
 hipError_t rg_launch_k1_halo(const RgTrackDev *, uint32_t, uint32_t, const RgCoefDev *, uint32_t *,
-                             unsigned long long *, hipStream_t);
+                             unsigned long long *, unsigned long long *, hipStream_t);
 hipError_t rg_launch_track_results(const uint32_t *, const unsigned long long *, const RgTrackDev *,
-                                   rg_track_result *, uint32_t, hipStream_t);
+                                   const unsigned long long *, rg_track_result *, uint32_t, hipStream_t);
 hipError_t rg_launch_album_merge(const uint32_t *, const unsigned long long *, uint32_t, uint32_t *, double *,
                                  hipStream_t);
 hipError_t rg_launch_album_result(const uint32_t *, const double *, rg_album_result *, hipStream_t);
@@ -232,6 +232,7 @@ extern "C" void rg_destroy(rg_ctx *c) {
         S.d_hist.release();
         S.d_nonfinite.release();
         S.d_imprecise.release();
+        S.d_k1_bad.release();
         S.d_results.release();
         S.h_results.release();
         S.d_album_hist.release();

@@ -20,12 +20,15 @@
 __global__ void __launch_bounds__(RG_PCT_THREADS)
 rg_track_result_kernel(const uint32_t *__restrict__ hist, const unsigned long long *__restrict__ peak_bits,
                        const RgTrackDev *__restrict__ list /* the tracks to finish, any subset */,
+                       const unsigned long long *__restrict__ first_bad /* variant 1: first non-finite frame, or ~0 */,
                        rg_track_result *__restrict__ out) {
     __shared__ uint64_t scan[RG_PCT_THREADS];
     const RgTrackDev tr = list[blockIdx.x];
     const uint32_t t = tr.track_index;
     const RgLoudness l = rg_block_loudness(hist + (size_t)t * RG_HISTOGRAM_SIZE, scan);
-    if (threadIdx.x == 0) rg_store_track_result(out + t, l, __longlong_as_double((long long)peak_bits[t]), tr.sample_rate, tr.file_type);
+    if (threadIdx.x == 0)
+        rg_store_track_result(out + t, l, __longlong_as_double((long long)peak_bits[t]), tr.sample_rate, tr.file_type,
+                              first_bad[t] != ~0ull ? RG_TRACK_FLAG_NONFINITE : 0u);
 }
 
 __global__ void __launch_bounds__(RG_PCT_THREADS)
@@ -147,11 +150,11 @@ rg_synth_fill_kernel(float *__restrict__ dst, uint64_t seed, uint32_t channel, u
 
 // ---- launch wrappers (plain C linkage so the host TU needs no kernel declarations) ---------------
 extern "C" hipError_t rg_launch_track_results(const uint32_t *d_hist, const unsigned long long *d_peak_bits,
-                                              const RgTrackDev *d_tracks,
+                                              const RgTrackDev *d_tracks, const unsigned long long *d_first_bad,
                                               rg_track_result *d_out, uint32_t n_tracks, hipStream_t s) {
     if (n_tracks == 0) return hipSuccess;
     hipLaunchKernelGGL(rg_track_result_kernel, dim3(n_tracks), dim3(RG_PCT_THREADS), 0, s, d_hist, d_peak_bits,
-                       d_tracks, d_out);
+                       d_tracks, d_first_bad, d_out);
     return hipGetLastError();
 }
 

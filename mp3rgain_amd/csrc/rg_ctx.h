@@ -86,6 +86,7 @@ struct RgSlot {
     std::vector<unsigned char> desc_shadow;  // what d_desc currently holds
     DevBuf<double> d_tm_rec;                 // segment records (rg_tm.h)
     DevBuf<uint32_t> d_hist;                 // [hist n*12000 | peak n*2 | done n] words
+    DevBuf<unsigned long long> d_k1_bad;     // variant 1: first non-finite frame per track (~0 = none), set per batch
     DevBuf<uint32_t> d_imprecise;            // per track: set by fix-up blocks that saw a cancelled window, cleared by the finisher
     DevBuf<uint32_t> d_nonfinite;            // per track: 0, or 0xFFFFFFFF - (first segment whose output is not finite);
                                              // zero between batches (the fix-up kernel's finisher resets what the main kernel set)

@@ -19,9 +19,9 @@
 
 extern "C" {
 hipError_t rg_launch_k1_halo(const RgTrackDev *, uint32_t, uint32_t, const RgCoefDev *, uint32_t *,
-                             unsigned long long *, hipStream_t);
+                             unsigned long long *, unsigned long long *, hipStream_t);
 hipError_t rg_launch_track_results(const uint32_t *, const unsigned long long *, const RgTrackDev *,
-                                   rg_track_result *, uint32_t, hipStream_t);
+                                   const unsigned long long *, rg_track_result *, uint32_t, hipStream_t);
 hipError_t rg_launch_album_merge(const uint32_t *, const unsigned long long *, uint32_t, uint32_t *, double *,
                                  hipStream_t);
 hipError_t rg_launch_tm_main(int fmt, int nch, const RgTmCoef *, const RgTmGeom *, const RgTmTrack *, uint32_t, uint32_t,
@@ -465,15 +465,17 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
                                        S.d_imprecise.p, S.d_hist.p, S.peak_ptr, done_ptr, S.d_results.p, s));
         }
         if (n_k1) {
+            RG_HIP(c, S.d_k1_bad.reserve(n));
+            RG_HIP(c, hipMemsetAsync(S.d_k1_bad.p, 0xFF, n * sizeof(unsigned long long), s));  // ~0 = all samples finite
             hipEvent_t e1;
             rc = timing_begin(c, &e1);
             if (rc != RG_OK) return rc;
             RG_HIP(c, rg_launch_k1_halo(d_k1_tracks, (uint32_t)n_k1, k1_items, c->d_coefs.p, S.d_hist.p,
-                                        S.peak_ptr, s));
+                                        S.peak_ptr, S.d_k1_bad.p, s));
             if (e1) RG_HIP(c, hipEventRecord(e1, s));
         }
         // tracks the fix-up kernel did not finish: variant 1's, and empty ones
-        RG_HIP(c, rg_launch_track_results(S.d_hist.p, S.peak_ptr, d_k1_tracks, S.d_results.p, (uint32_t)n_k1, s));
+        RG_HIP(c, rg_launch_track_results(S.d_hist.p, S.peak_ptr, d_k1_tracks, S.d_k1_bad.p, S.d_results.p, (uint32_t)n_k1, s));
     }
     if (album) {
         RG_HIP(c, rg_launch_album_merge(S.d_hist.p, S.peak_ptr, (uint32_t)n, S.d_album_hist.p,

@@ -79,10 +79,29 @@ __device__ __forceinline__ double load_input(const void *base, uint64_t i, uint3
 
 }  // namespace
 
+// A sample that is not finite (float PCM only) leaves the reference's filter state NaN for the rest of the track
+// (src/replaygain.rs:586-616 never resets it), so every window from that frame on is a NaN window.  A lane that
+// warms up from zero cannot know about a NaN before its halo: one streaming pass finds the first such frame of
+// every track (channels 0 and 1, the ones that are analysed) before the lanes run.
+__global__ void __launch_bounds__(256) rg_k1_first_nonfinite_kernel(const RgTrackDev *__restrict__ tracks,
+                                                                    unsigned long long *__restrict__ first_bad) {
+    const RgTrackDev tr = tracks[blockIdx.y];
+    if (tr.format != RG_FMT_F32_PLANAR) return;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long best = ~0ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tr.frames; i += stride) {
+        const float a = ((const float *)tr.ch0)[i];
+        const float b = tr.ch1 ? ((const float *)tr.ch1)[i] : 0.0f;
+        if (!(fabsf(a) <= 3.402823466e38f) || !(fabsf(b) <= 3.402823466e38f)) { best = i; break; }  // ascending per thread
+    }
+    if (best != ~0ull) atomicMin(&first_bad[tr.track_index], best);
+}
+
 __global__ void __launch_bounds__(256) rg_k1_halo_kernel(const RgTrackDev *__restrict__ tracks, uint32_t n_tracks,
                                                          uint32_t total_items, const RgCoefDev *__restrict__ coefs,
                                                          uint32_t *__restrict__ hist,
-                                                         unsigned long long *__restrict__ peak_bits) {
+                                                         unsigned long long *__restrict__ peak_bits,
+                                                         const unsigned long long *__restrict__ first_bad) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total_items) return;
 
@@ -119,6 +138,8 @@ __global__ void __launch_bounds__(256) rg_k1_halo_kernel(const RgTrackDev *__res
     double peak = 0.0, lsum = 0.0, rsum = 0.0;
     uint32_t n = 0;
     uint32_t *const h = hist + (size_t)tr.track_index * RG_HISTOGRAM_SIZE;
+    const uint64_t bad_from = first_bad[tr.track_index];  // ~0 when every sample is finite
+    const double qnan = __longlong_as_double(0x7FF8000000000000ll);
     for (uint64_t i = first; i < last; ++i) {
         const double lf = df1_process(fl, c, load_input(tr.ch0, i, fmt, mag));
         if (mag > peak) peak = mag;
@@ -133,12 +154,14 @@ __global__ void __launch_bounds__(256) rg_k1_halo_kernel(const RgTrackDev *__res
             rsum += sq;
         }
         if (++n >= W) {
+            if (i >= bad_from) lsum = qnan;  // the window holds, or follows, the first non-finite sample
             const int idx = rg_window_bin(lsum, rsum, n);
             if (idx >= 0) atomicAdd(&h[idx], 1u);
             lsum = 0.0; rsum = 0.0; n = 0;
         }
     }
     if (n > 0) {  // final partial window, src/replaygain.rs:907
+        if (last - 1 >= bad_from) lsum = qnan;
         const int idx = rg_window_bin(lsum, rsum, n);
         if (idx >= 0) atomicAdd(&h[idx], 1u);
     }
@@ -147,11 +170,13 @@ __global__ void __launch_bounds__(256) rg_k1_halo_kernel(const RgTrackDev *__res
 
 extern "C" hipError_t rg_launch_k1_halo(const RgTrackDev *d_tracks, uint32_t n_tracks, uint32_t total_items,
                                         const RgCoefDev *d_coefs, uint32_t *d_hist,
-                                        unsigned long long *d_peak_bits, hipStream_t stream) {
+                                        unsigned long long *d_peak_bits, unsigned long long *d_first_bad /* preset to ~0 */,
+                                        hipStream_t stream) {
     if (total_items == 0) return hipSuccess;
+    hipLaunchKernelGGL(rg_k1_first_nonfinite_kernel, dim3(512, n_tracks), dim3(256), 0, stream, d_tracks, d_first_bad);
     const uint32_t block = 64;  // one wave per workgroup: spreads a small item count over all CUs
     const uint32_t grid = (total_items + block - 1) / block;
     hipLaunchKernelGGL(rg_k1_halo_kernel, dim3(grid), dim3(block), 0, stream, d_tracks, n_tracks, total_items,
-                       d_coefs, d_hist, d_peak_bits);
+                       d_coefs, d_hist, d_peak_bits, d_first_bad);
     return hipGetLastError();
 }

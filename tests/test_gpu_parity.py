@@ -248,21 +248,25 @@ def test_device_synth_matches_host_and_device_resident_path(analyzer, oracle, ca
 
 @pytest.mark.parametrize("where", ["start", "middle", "last_window", "both_channels"])
 @pytest.mark.parametrize("what", ["nan", "inf"])
-def test_non_finite_samples_poison_the_rest_of_the_track(_ctx, oracle, where, what):
+@pytest.mark.parametrize("mode", ["variant2", "variant1", "auto_96k"])
+def test_non_finite_samples_poison_the_rest_of_the_track(_ctx, oracle, where, what, mode):
     """A NaN (or an Inf, which turns into NaN one subtraction later) leaves the reference's filter state NaN for the
     rest of the track: every window from there on is a NaN window and lands in bin 2000 (`NaN as i32` = 0,
     src/replaygain.rs:755-758); the peak ignores NaN (`f64::max`).  Variant 2 reproduces it through a per-track
-    first-bad-segment flag; a clean track in the same batch and the next batch on the same buffers are unaffected."""
+    first-bad-segment flag, variant 1 (also what auto mode uses at 96 kHz) through a pre-pass that finds the first
+    non-finite frame; a clean track in the same batch and the next batch on the same buffers are unaffected."""
     import mp3rgain_amd as rg
 
     an = _ctx
-    an.set_kernel(2)
+    an.set_kernel({"variant2": 2, "variant1": 1, "auto_96k": 0}[mode])
     for key in (1, 2, 3):
         an.set_tuning(key, 0)
-    rate, n = 44100, 44100 * 4 + 1234
+    rate = 96000 if mode == "auto_96k" else 44100
+    n = rate * 4 + 1234
     l, r = oracle.synth_f32(91, 0, rate, n).copy(), oracle.synth_f32(91, 1, rate, n).copy()
     bad = np.float32(np.nan) if what == "nan" else np.float32(np.inf)
-    at = {"start": 0, "middle": 2205 * 37 + 1000, "last_window": n - 50, "both_channels": 2205 * 11 + 5}[where]
+    W = rate // 20
+    at = {"start": 0, "middle": W * 37 + 1000, "last_window": n - 50, "both_channels": W * 11 + 5}[where]
     l[at] = bad
     if where == "both_channels":
         r[at + 3000] = -bad
@@ -278,7 +282,7 @@ def test_non_finite_samples_poison_the_rest_of_the_track(_ctx, oracle, where, wh
         assert got[0].flags & 1 and not got[1].flags & 1  # RG_TRACK_FLAG_NONFINITE
         ok, hc = an.analyze_tracks([rg.PcmTrack([clean_l, clean_r], rate)], return_histograms=True)
         assert np.array_equal(hc[0], cwh)
-    assert wh[2000] >= (n - at) // 2205  # the poisoned windows really are in bin 2000
+    assert wh[2000] >= (n - at) // W  # the poisoned windows really are in bin 2000
     an.set_kernel(0)
 
 
