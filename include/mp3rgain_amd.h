@@ -85,8 +85,8 @@ typedef struct rg_track_result {
 } rg_track_result;
 /* the track held samples that are not finite (NaN / Inf): every window from the first one on is a NaN window */
 #define RG_TRACK_FLAG_NONFINITE 1u
-/* Variant 2 only: some window's energy is more than RG_TM_KAPPA times smaller than the energies it was
- * assembled from (the high-passed tail of a large DC offset, say), so its bin may be a few 0.01 dB off.  The
+/* Variant 2 only: some window's energy is so much smaller than the energies it was assembled from (the high-passed
+ * tail of a large DC offset, say) that rounding may have moved it across a bin edge, a few 0.01 dB at most.  The
  * synchronous entry points (rg_analyze_pcm_batch, rg_analyze_album_pcm, rg_analyze_wav_batch and the file-level
  * functions) then repeat the batch with the order-faithful kernel when the variant is 0 (auto) and return exact
  * results with the flag cleared; callers of rg_enqueue_pcm_batch / rg_collect see the flag and decide. */

@@ -201,7 +201,7 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
     double best = 1e300;
     uint32_t bestL = 0;
     for (uint32_t L : cand) {
-        const uint32_t Hl = std::min(H10, L & ~3u);
+        const uint32_t Hl = H10 >= L ? L : H10;
         const uint32_t block = rg_tm_choose_block(L, Hl);
         double waves = 0;
         for (uint32_t id : g.ids) {

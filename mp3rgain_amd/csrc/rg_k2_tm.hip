@@ -277,7 +277,7 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
         auto piece = [&](const int p, const uint4 v) {
             const uint32_t f[4] = {v.x, v.y, v.z, v.w};
             const uint32_t n = n0 + 4u * p;
-            if (MODE == 1 || (MODE == 0 && n < H)) {  // all 12 transient moments live (H is a multiple of 4)
+            if (MODE == 1 || (MODE == 0 && n < H)) {  // all 12 transient moments live (H is a multiple of 4, or the whole segment)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     double row[12];
@@ -759,10 +759,15 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
             // far below the energy of the filter state (the high-passed tail of a DC offset, say) can come out a
             // rounding error below zero, and log10 of that would be a NaN window.  (A NaN stays a NaN.)
             if (total < 0.0) total = 0.0;
-            if (mtot > RG_TM_KAPPA * total) cancelled = true;  // NaN compares false: a NaN window is not "imprecise"
             const uint64_t rem = tr.frames - widx * G.W;
             const uint32_t n = rem < G.W ? (uint32_t)rem : G.W;
             bin = rg_window_bin(total, 0.0, n);
+            // could rounding have put this window into another bin?  (NaN compares false: a NaN window is exact)
+            if (mtot > 1.0e3 * total) {
+                const double e = RG_TM_CEPS * mtot;
+                const double lo = total - e;
+                cancelled = rg_window_bin(lo < 0.0 ? 0.0 : lo, 0.0, n) != rg_window_bin(total + e, 0.0, n);
+            }
         }
     }
     bins[i] = bin;

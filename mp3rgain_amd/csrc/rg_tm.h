@@ -32,9 +32,14 @@
 #define RG_TM_BLOCK_WIDE 768
 #define RG_TM_WAVE_TILE_BYTES 4096  // PCM staging tile of one wave: 64 rows x 16 frames x 4 B
 #define RG_TM_LDS_BYTES (160u * 1024u)
-// a window is flagged imprecise when the zero-state and transient energies it is assembled from exceed its own
-// energy by this factor (rounding then reaches ~1e-14 x KAPPA of the result: 1e-8 of a value, 4e-6 of a bin)
-#define RG_TM_KAPPA 1.0e6
+// Self-check of the fix-up kernel.  A window's energy S = A + 2 B.sigma + sigma'G sigma is assembled from
+// M = A + sigma'G sigma; rounding leaves an absolute error of about c * 2^-53 * M in S.  A window is flagged
+// imprecise when S - e and S + e, e = RG_TM_CEPS * M, do not fall into the same histogram bin (or one of them is
+// dropped and the other is not).  Measured over 9000 random and pathological tracks: the displaced windows sit at
+// M / S of 1e6 .. 1e8 and need e / M of 1e-14 .. 1e-12 to be explained; 1e-11 leaves an order of magnitude.
+#ifndef RG_TM_CEPS
+#define RG_TM_CEPS 1.0e-11
+#endif
 #define RG_TM_MAX_ROUNDS 4    // the doubling scan reaches 2^4 = 16 predecessors
 #define RG_TM_EDGE 16         // lanes of a wave whose scan values are visible to the next wave (>= 2^(MAX_ROUNDS-1), and 1 for the final shift)
 
