@@ -74,6 +74,7 @@ def main() -> int:
     ap.add_argument("--slots", type=int, default=0, help="pipeline slots of the library (0 = default)")
     ap.add_argument("--album", action="store_true", help="force the album path (collectives) even on one GPU")
     ap.add_argument("--cpu-reps", type=int, default=16, help="oracle repetitions for cpu_baseline (0 = skip)")
+    ap.add_argument("--pre-roll", type=float, default=PRE_ROLL_SECONDS, help="untimed pre-roll before the warm-up steps, seconds of work")
     args = ap.parse_args()
 
     import numpy as np
@@ -175,7 +176,7 @@ def main() -> int:
     # milliseconds to settle once the kernel starts running (the first ~10 ms run 10-15 % slower), and a short
     # --warmup would otherwise put that ramp into the timed region.  The timed region below is exactly K steps.
     # The step count comes from the workload size, not from a clock: every rank must issue the same collectives.
-    pre_steps = max(4, min(8192, int(PRE_ROLL_SECONDS / (frames * ntr / 3.5e11))))
+    pre_steps = max(4, min(8192, int(args.pre_roll / (frames * ntr / 3.5e11))))
     for i in range(pre_steps):
         step()
         if i % 64 == 63:

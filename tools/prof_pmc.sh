@@ -6,9 +6,13 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/$OUT
 cd $R
-run() { name=$1; shift; timeout 150 rocprofv3 "$@" -d $OUT/$name --output-format csv -- python bench.py --cpu-reps 0 $BENCH_ARGS > $OUT/$name.log 2>&1 || echo "$name failed/timeout"; }
+run() { name=$1; shift; timeout 150 rocprofv3 "$@" -d $OUT/$name --output-format csv -- python bench.py --cpu-reps 0 $BENCH_ARGS $EXTRA > $OUT/$name.log 2>&1 || echo "$name failed/timeout"; }
 BENCH_ARGS="$*"
+EXTRA=""
 run kt --kernel-trace --stats
+# the counter passes serialise the dispatches and write one row per dispatch and counter: a short pre-roll and 100
+# timed steps keep them small (the counters are per dispatch, they do not depend on how many there are)
+EXTRA="--pre-roll 0.01 --steps 100 --warmup 5"
 run pmc_sq1 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
 run pmc_sq2 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU
 run pmc_grbm --pmc GRBM_GUI_ACTIVE GRBM_COUNT

@@ -44,7 +44,7 @@ if len(sys.argv) > 2:
                 "correction": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B), WRITE_SIZE as reported",
                 "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0,
                 "algorithmic_bytes_per_launch": frames * 8,
-                "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --cpu-reps 0",
+                "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --cpu-reps 0 --pre-roll 0.01 --steps 100 --warmup 5",
                 "note": "PMC passes serialise the dispatches; the 211.7 MB input also fits the 256 MiB Infinity Cache, whose hits these fabric-side counters include",
             }
             json.dump(out, open(sys.argv[2], "w"), indent=1)
