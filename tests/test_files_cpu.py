@@ -73,3 +73,33 @@ def test_wav_parse_rejects_inconsistent_block_align():
 
 def test_wavinfo_layout():
     assert C.sizeof(_capi.WavInfo) == 32
+
+
+def test_wav_parse_survives_damage():
+    """2000 damaged WAV headers: never a crash, and whatever parses describes bytes that exist."""
+    import random
+
+    rng = random.Random(99)
+    bases = [wav_bytes([np.arange(50) % 7, np.arange(50) % 5], 44100, k, extensible=e) for k in ("u8", "s16", "s24", "f32") for e in (False, True)]
+    ok = 0
+    for _ in range(2000):
+        b = bytearray(rng.choice(bases))
+        for _ in range(rng.randint(1, 4)):
+            kind = rng.randint(0, 3)
+            pos = rng.randrange(0, len(b))
+            if kind == 0:
+                b[pos] = rng.getrandbits(8)
+            elif kind == 1:
+                struct.pack_into("<I", b, min(pos, len(b) - 4), rng.choice([0, 1, 0xFFFFFFFF, 0x7FFFFFFF, rng.getrandbits(32), rng.randrange(100)]))
+            elif kind == 2:
+                del b[pos:]
+            else:
+                b[pos:pos] = bytes(rng.getrandbits(8) for _ in range(rng.randint(1, 40)))
+        if len(b) == 0:
+            b = bytearray(b"\0")
+        rc, w = parse(bytes(b))
+        if rc == 0:
+            ok += 1
+            assert w.channels > 0 and w.block_align == w.channels * (w.bits_per_sample // 8)
+            assert w.data_offset + w.frames * w.block_align <= len(b)
+    assert 100 < ok < 2000
