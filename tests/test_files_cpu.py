@@ -86,10 +86,12 @@ def test_wav_parse_survives_damage():
         b = bytearray(rng.choice(bases))
         for _ in range(rng.randint(1, 4)):
             kind = rng.randint(0, 3)
+            if len(b) == 0:
+                break
             pos = rng.randrange(0, len(b))
             if kind == 0:
                 b[pos] = rng.getrandbits(8)
-            elif kind == 1:
+            elif kind == 1 and len(b) >= 4:
                 struct.pack_into("<I", b, min(pos, len(b) - 4), rng.choice([0, 1, 0xFFFFFFFF, 0x7FFFFFFF, rng.getrandbits(32), rng.randrange(100)]))
             elif kind == 2:
                 del b[pos:]
