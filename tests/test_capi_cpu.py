@@ -129,3 +129,21 @@ def test_product_does_not_reference_the_oracle():
     for p in list((ROOT / "mp3rgain_amd").rglob("*.py")) + list((ROOT / "mp3rgain_amd" / "csrc").glob("*")):
         if p.suffix in (".py", ".hip", ".cpp", ".h") or p.name == "Makefile":
             assert "oracle" not in p.read_text().lower().replace("no cpu", ""), p
+
+
+def test_tm_design_keeps_all_moments_when_the_segment_is_shorter_than_the_fast_decay(capi):
+    """rg_tm_design (host): H10 = frames for which all 12 transient moments are accumulated.  A multiple of 4 when it
+    ends inside the segment; the whole segment, trailing L & 3 frames included, when the fast block outlives it
+    (cutting at L & ~3 was a bug: L = 245 at 44.1 kHz, 150 at 24 kHz)."""
+    def h10(rate, L):
+        H, r, rf, res = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_double()
+        assert capi.rg_tm_design_info(rate, L, C.byref(H), C.byref(r), C.byref(rf), C.byref(res), None, None) == 0
+        return H.value, r.value, rf.value, res.value
+
+    assert h10(44100, 2205)[0] == 248 and h10(44100, 735)[0] == 248
+    assert h10(44100, 245)[0] == 245
+    assert capi.rg_tm_design_info(44100, 147, None, None, None, None, None, None) != 0  # would need more than 16 predecessors
+    assert h10(24000, 150)[0] == 150 and h10(24000, 1200)[0] == 320 and h10(24000, 300)[0] == 300
+    for rate, L in ((44100, 2205), (44100, 245), (48000, 2400), (8000, 400), (24000, 150)):
+        H, rounds, rounds_fast, resid = h10(rate, L)
+        assert H <= L and (H % 4 == 0 or H == L) and 1 <= rounds <= 4 and rounds_fast <= rounds and resid < 1e-15

@@ -2,7 +2,7 @@
 """Large differential fuzz of variant 2 against the CPU oracle (GPU box): random and pathological tracks from
 tests/test_gpu_parity.py with fresh seeds.  Reports, per set, how many tracks have a histogram bin that differs
 from the oracle's, how many carry RG_TRACK_FLAG_IMPRECISE, and -- the property that must hold -- how many differ
-WITHOUT carrying the flag.  Usage: python tools/fuzz_selfcheck.py [tracks_per_set] [first_seed]"""
+WITHOUT carrying the flag.  Usage: python tools/fuzz_selfcheck.py [tracks_per_set] [first_seed] [lane_target]"""
 import sys
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
@@ -20,8 +20,10 @@ from oracle import pyoracle as po  # noqa: E402
 
 per_set = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # tuning key 2: 0 = cost model, 1 = one segment per window, 1 << 40 = shortest segments
 an = rg.Analyzer(0)
 an.set_kernel(2)
+an.set_tuning(2, lanes)
 pool = ThreadPoolExecutor(16)
 bad_total = 0
 for name, gen in (("random", lambda n, s: T._random_cases(n, s)), ("pathological", lambda n, s: [c[:2] for c in T._pathological_cases(n, s)])):
