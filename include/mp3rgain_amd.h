@@ -88,7 +88,7 @@ typedef struct rg_track_result {
 /* Variant 2 only: some window's energy is so much smaller than the energies it was assembled from (the high-passed
  * tail of a large DC offset, say) that rounding may have moved it across a bin edge, a few 0.01 dB at most.  The
  * synchronous entry points (rg_analyze_pcm_batch, rg_analyze_album_pcm, rg_analyze_wav_batch and the file-level
- * functions) then repeat the batch with the order-faithful kernel when the variant is 0 (auto) and return exact
+ * functions) then repeat the batch, the flagged tracks on the order-faithful kernel, when the variant is 0 (auto) and return exact
  * results with the flag cleared; callers of rg_enqueue_pcm_batch / rg_collect see the flag and decide. */
 #define RG_TRACK_FLAG_IMPRECISE 2u
 

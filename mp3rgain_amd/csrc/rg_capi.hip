@@ -564,18 +564,21 @@ extern "C" int rg_album_allreduce(rg_ctx *c, void *comm) {
 // ================================ synchronous API ====================================================
 namespace {
 // Variant 2 marks tracks with a window it could not resolve reliably (RG_TRACK_FLAG_IMPRECISE).  In auto mode the
-// synchronous entry points then repeat the batch with the order-faithful kernel, which is exact and ~60x slower.
-bool needs_exact_pass(const rg_ctx *c, const rg_track_result *res, size_t n) {
+// synchronous entry points then repeat the batch with those tracks routed to the order-faithful kernel (exact,
+// ~60x slower) and everything else on the fast path again.
+bool needs_exact_pass(rg_ctx *c, const rg_track_result *res, size_t n) {
     if (c->kernel_variant != 0 || !res) return false;
+    bool any = false;
+    c->force_exact.assign(n, 0);
     for (size_t i = 0; i < n; ++i)
-        if (res[i].flags & RG_TRACK_FLAG_IMPRECISE) return true;
-    return false;
+        if (res[i].flags & RG_TRACK_FLAG_IMPRECISE) c->force_exact[i] = 1, any = true;
+    if (!any) c->force_exact.clear();
+    return any;
 }
-struct ExactPass {  // scoped switch to variant 1
+struct ExactPass {  // scope of the repeat: the per-track routing mask is dropped afterwards
     rg_ctx *c;
-    int saved;
-    explicit ExactPass(rg_ctx *ctx) : c(ctx), saved(ctx->kernel_variant) { c->kernel_variant = 1; }
-    ~ExactPass() { c->kernel_variant = saved; }
+    explicit ExactPass(rg_ctx *ctx) : c(ctx) {}
+    ~ExactPass() { c->force_exact.clear(); }
 };
 }  // namespace
 

@@ -457,3 +457,39 @@ def test_pathological_signals(_ctx, oracle):
             assert np.array_equal(h[k], wh) and got[k].peak == want["peak"] and got[k].loudness_db == want["loudness_db"], \
                 f"auto mode, case {lo + k}: {rate} Hz, kinds {kinds}"
             assert not got[k].flags & 2
+
+
+def test_exact_repeat_touches_only_the_flagged_tracks(_ctx, oracle):
+    """One pathological track in a batch of clean ones: the synchronous call returns the oracle's bins for all of them,
+    and only the flagged track went to the order-faithful kernel (the others keep variant 2's timing: the whole call
+    stays far below what variant 1 would need for the batch)."""
+    import time
+
+    import mp3rgain_amd as rg
+
+    an = _ctx
+    an.set_kernel(0)
+    for key in (1, 2, 3):
+        an.set_tuning(key, 0)
+    rate, n = 44100, 44100 * 120
+    clean = [[oracle.synth_f32(500 + t, c, rate, n) for c in range(2)] for t in range(6)]
+    rng = np.random.default_rng(8)  # a whisper of noise riding on a near-full-scale DC offset: every window cancels
+    dc = [(s * 0.9 + 3e-5 * rng.standard_normal(44100 * 3)).astype(np.float32) for s in (1.0, -1.0)]
+    tracks = [rg.PcmTrack(ch, rate) for ch in clean[:3]] + [rg.PcmTrack(dc, rate)] + [rg.PcmTrack(ch, rate) for ch in clean[3:]]
+    an.set_kernel(2)
+    forced, _ = an.analyze_tracks(tracks, return_histograms=True)
+    assert [bool(g.flags & 2) for g in forced] == [False, False, False, True, False, False, False]
+    an.set_kernel(0)
+    an.analyze_tracks(tracks)  # warm
+    t0 = time.perf_counter()
+    got, h = an.analyze_tracks(tracks, return_histograms=True)
+    dt_auto = time.perf_counter() - t0
+    an.set_kernel(1)
+    t0 = time.perf_counter()
+    an.analyze_tracks(tracks)
+    dt_v1 = time.perf_counter() - t0
+    an.set_kernel(0)
+    for g, hh, tr in zip(got, h, tracks):
+        want, wh = oracle.analyze_pcm(tr.channels[0], tr.channels[1], rate)
+        assert np.array_equal(hh, wh) and g.loudness_db == want["loudness_db"] and not g.flags & 2
+    assert dt_auto < dt_v1  # six 2-minute tracks on variant 1 cost far more than the H2D copy both calls share
