@@ -15,8 +15,22 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 
+#include <type_traits>
+
 #include "rg_device.h"
 #include "rg_device_inl.h"
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, 10>)
+#define RG_K1_ELEVEN(f)                                                                                       \
+    do {                                                                                                      \
+        f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{});   \
+        f(std::integral_constant<int, 3>{});                                                                             \
+        __builtin_amdgcn_sched_barrier(0); /* keeps the loads of later frames from being hoisted all the way up */      \
+        f(std::integral_constant<int, 4>{}); f(std::integral_constant<int, 5>{}); f(std::integral_constant<int, 6>{});   \
+        f(std::integral_constant<int, 7>{});                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        f(std::integral_constant<int, 8>{}); f(std::integral_constant<int, 9>{}); f(std::integral_constant<int, 10>{}); \
+    } while (0)
 
 namespace {
 
@@ -44,6 +58,40 @@ __device__ __forceinline__ double df1_process(Df1State &f, const RgCoefDev &c, d
     }
     const double y = (1e-10 + c.yb[0] * f.yx[0]) + acc;
     f.yy[0] = y;
+
+    f.bx[2] = f.bx[1]; f.bx[1] = f.bx[0];
+    f.by[2] = f.by[1]; f.by[1] = f.by[0];
+    f.bx[0] = y;
+    double acc2 = 0.0;
+#pragma unroll
+    for (int i = 1; i < 3; ++i) {
+        double t = c.bb[i] * f.bx[i] - c.ba[i] * f.by[i];
+        acc2 = acc2 + t;
+    }
+    const double z = (1e-10 + c.bb[0] * f.bx[0]) + acc2;
+    f.by[0] = z;
+    return z;
+}
+
+// The same step with the Yule-Walker histories rotated instead of shifted.  K = 0..10 counts the frames since the
+// histories were last in their natural order; the shift of frame K would move x_buf[i-1] to x_buf[i], so after it
+// the value the reference holds in x_buf[i] / y_buf[i] lives in physical slot (i - K - 1) mod 11 without having
+// been moved, and the new sample goes to slot (10 - K).  The twenty moves of the shift disappear when eleven
+// consecutive frames are unrolled with K = 0..10 -- and after the eleventh the histories are in natural order again.  Same products, same subtraction,
+// same fold order: bit-identical to df1_process.
+template <int K>
+__device__ __forceinline__ double df1_process_rot(Df1State &f, const RgCoefDev &c, double s) {
+    constexpr int P0 = (10 - K) % 11;
+    f.yx[P0] = s;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 1; i < 11; ++i) {
+        const int p = (i - K - 1 + 22) % 11;
+        double t = c.yb[i] * f.yx[p] - c.ya[i] * f.yy[p];
+        acc = acc + t;
+    }
+    const double y = (1e-10 + c.yb[0] * f.yx[P0]) + acc;
+    f.yy[P0] = y;
 
     f.bx[2] = f.bx[1]; f.bx[1] = f.bx[0];
     f.by[2] = f.by[1]; f.by[1] = f.by[0];
@@ -130,9 +178,20 @@ __global__ void __launch_bounds__(256) rg_k1_halo_kernel(const RgTrackDev *__res
     df1_reset(fr);
     double mag;
 
-    for (uint64_t i = warm; i < first; ++i) {
-        (void)df1_process(fl, c, load_input(tr.ch0, i, fmt, mag));
-        if (stereo) (void)df1_process(fr, c, load_input(tr.ch1, i, fmt, mag));
+    {
+        uint64_t i = warm;
+        for (; i + 11 <= first; i += 11) {  // eleven frames per turn: rotated histories, no shifts
+            auto step = [&](auto k) {
+                constexpr int K = decltype(k)::value;
+                (void)df1_process_rot<K>(fl, c, load_input(tr.ch0, i + K, fmt, mag));
+                if (stereo) (void)df1_process_rot<K>(fr, c, load_input(tr.ch1, i + K, fmt, mag));
+            };
+            RG_K1_ELEVEN(step);
+        }
+        for (; i < first; ++i) {
+            (void)df1_process(fl, c, load_input(tr.ch0, i, fmt, mag));
+            if (stereo) (void)df1_process(fr, c, load_input(tr.ch1, i, fmt, mag));
+        }
     }
 
     double peak = 0.0, lsum = 0.0, rsum = 0.0;
@@ -140,11 +199,16 @@ __global__ void __launch_bounds__(256) rg_k1_halo_kernel(const RgTrackDev *__res
     uint32_t *const h = hist + (size_t)tr.track_index * RG_HISTOGRAM_SIZE;
     const uint64_t bad_from = first_bad[tr.track_index];  // ~0 when every sample is finite
     const double qnan = __longlong_as_double(0x7FF8000000000000ll);
-    for (uint64_t i = first; i < last; ++i) {
-        const double lf = df1_process(fl, c, load_input(tr.ch0, i, fmt, mag));
+    // one frame of the segment; ROT >= 0 selects the rotated step of that phase, -1 the shifting one
+    auto frame = [&](const uint64_t i, auto rot) {
+        constexpr int ROT = decltype(rot)::value;
+        double lf, rf = 0.0;
+        if constexpr (ROT >= 0) lf = df1_process_rot<ROT>(fl, c, load_input(tr.ch0, i, fmt, mag));
+        else lf = df1_process(fl, c, load_input(tr.ch0, i, fmt, mag));
         if (mag > peak) peak = mag;
         if (stereo) {
-            const double rf = df1_process(fr, c, load_input(tr.ch1, i, fmt, mag));
+            if constexpr (ROT >= 0) rf = df1_process_rot<ROT>(fr, c, load_input(tr.ch1, i, fmt, mag));
+            else rf = df1_process(fr, c, load_input(tr.ch1, i, fmt, mag));
             if (mag > peak) peak = mag;
             lsum += lf * lf;
             rsum += rf * rf;
@@ -159,6 +223,14 @@ __global__ void __launch_bounds__(256) rg_k1_halo_kernel(const RgTrackDev *__res
             if (idx >= 0) atomicAdd(&h[idx], 1u);
             lsum = 0.0; rsum = 0.0; n = 0;
         }
+    };
+    {
+        uint64_t i = first;
+        for (; i + 11 <= last; i += 11) {
+            auto step = [&](auto k) { frame(i + decltype(k)::value, k); };
+            RG_K1_ELEVEN(step);
+        }
+        for (; i < last; ++i) frame(i, std::integral_constant<int, -1>{});
     }
     if (n > 0) {  // final partial window, src/replaygain.rs:907
         if (last - 1 >= bad_from) lsum = qnan;
