@@ -565,7 +565,7 @@ extern "C" int rg_album_allreduce(rg_ctx *c, void *comm) {
 namespace {
 // Variant 2 marks tracks with a window it could not resolve reliably (RG_TRACK_FLAG_IMPRECISE).  In auto mode the
 // synchronous entry points then repeat the batch with those tracks routed to the order-faithful kernel (exact,
-// ~60x slower) and everything else on the fast path again.
+// ~20x slower) and everything else on the fast path again.
 bool needs_exact_pass(rg_ctx *c, const rg_track_result *res, size_t n) {
     if (c->kernel_variant != 0 || !res) return false;
     bool any = false;

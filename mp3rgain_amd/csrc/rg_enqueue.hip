@@ -327,7 +327,7 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
         // (<= 9 at 48 kHz and below, rg_tm_design), so after an impulse or with a DC offset the moments cancel
         // to ~1e-8 of the state energy and a nearly silent window can land a few bins off.  Variant 1 follows the
         // reference's own evaluation order and is exact at every rate (0 of 4000 random tracks differ; variant 2:
-        // 14, all at these two rates), at 1/60 of the speed -- and no MP3 has these rates.
+        // 14, all at these two rates), at 1/20 of the speed -- and no MP3 has these rates.
         const bool tm_rate = (c->kernel_variant == 2 || tracks[t].sample_rate <= 48000u) &&
                              !(c->force_exact.size() == n && c->force_exact[t]);
         if (use_tm && tm_rate && c->design[ri].stable) {
