@@ -75,6 +75,9 @@ bool box_at(const uint8_t *d, size_t len, size_t pos, Box *b) {
         b->size = s;
         b->hdr = 8;
     }
+    // a size smaller than its own header cannot be walked (the reference's `size - header_size` underflows
+    // there, src/mp4meta.rs:90-96: a panic in debug builds, a wrapped length in release): treated as "no box"
+    if (b->size != 0 && b->size < b->hdr) return false;
     return true;
 }
 
@@ -282,7 +285,7 @@ int update(const uint8_t *d, size_t len, const rg_mp4_rg_tags *tags, Bytes *out)
     r.reserve(len + 1024);
     if (L.has_ilst) {  // replace the ilst in place
         const size_t ist = L.ilst.pos, isz = (size_t)L.ilst.size;
-        if (ist + isz > len || L.ilst.pos + L.ilst.hdr + L.ilst.content() > len) return fail(RG_MP4_ERR_ARG, "ilst box runs past the end of the file");
+        if (isz < L.ilst.hdr || isz > len - ist) return fail(RG_MP4_ERR_ARG, "ilst box runs past the end of the file");
         const Bytes ilst = build_ilst(tags, d + L.ilst.pos + L.ilst.hdr, (size_t)L.ilst.content());
         const int64_t diff = (int64_t)ilst.size() - (int64_t)isz;
         r.insert(r.end(), d, d + ist);

@@ -51,8 +51,11 @@ def header(data: bytes, pos: int) -> Optional[Tuple[int, bytes, int]]:
     if size == 1:
         if pos + 16 > len(data):
             return None
-        return struct.unpack_from(">Q", data, pos + 8)[0], typ, 16
-    return size, typ, 8
+        size = struct.unpack_from(">Q", data, pos + 8)[0]
+        # a box smaller than its own header: the reference's `size - header_size` (:90-96) underflows
+        # (panic in debug, wrapped length in release); the restatement and the library call it "no box"
+        return None if 0 < size < 16 else (size, typ, 16)
+    return None if 0 < size < 8 else (size, typ, 8)
 
 
 def content_size(size: int, hdr: int) -> int:                  # :90-96

@@ -28,7 +28,9 @@ def test_library_exports_every_declared_symbol(capi):
     raw = C.CDLL(str(_capi.LIB_PATH))
     for name in declared:
         assert hasattr(raw, name), f"{name} not exported"
-    assert capi.rg_abi_version() == 2
+    import __graft_entry__
+
+    assert capi.rg_abi_version() == __graft_entry__.header_abi_version()
     assert capi.rg_is_available() == 1
 
 
@@ -147,3 +149,10 @@ def test_tm_design_keeps_all_moments_when_the_segment_is_shorter_than_the_fast_d
     for rate, L in ((44100, 2205), (44100, 245), (48000, 2400), (8000, 400), (24000, 150)):
         H, rounds, rounds_fast, resid = h10(rate, L)
         assert H <= L and (H % 4 == 0 or H == L) and 1 <= rounds <= 4 and rounds_fast <= rounds and resid < 1e-15
+
+
+def test_graft_entry_build_succeeds():
+    """The driver's "does it build" check: make (a no-op when up to date), import, ABI agreement with the header."""
+    import __graft_entry__
+
+    __graft_entry__.build()

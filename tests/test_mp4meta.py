@@ -289,6 +289,43 @@ def test_damaged_files_do_not_crash():
     assert agreed > len(cases) // 3
 
 
+@pytest.mark.parametrize("container", [b"moov", b"udta", b"meta", b"ilst"])
+@pytest.mark.parametrize("size", [2, 3, 7])
+def test_container_box_smaller_than_its_header(container, size):
+    """A 32-bit size of 2..7 on moov / udta / meta / ilst made `size - header` wrap to ~2^64 and the ilst walk
+    read past the buffer (round-1 advisor finding, reproduced under ASan).  Now such a box does not exist:
+    the library answers like the restatement, and never copies foreign bytes into the output."""
+    base, _ = make_mp4(old_rg={"replaygain_track_gain": "+1.00 dB"})
+    i = base.find(container) - 4
+    d = bytearray(base)
+    struct.pack_into(">I", d, i, size)
+    d = bytes(d)
+    tags, otags = tags_pair((1.5, 0.75), (-2.0, 0.5))
+    try:
+        want = O.update(d, otags)
+    except ValueError:
+        want = None
+    try:
+        got = M.update_mp4_metadata(d, tags)
+    except M.Mp4MetaError:
+        got = None
+    assert got == want
+    M.read_replaygain_tags_data(d)  # must simply not crash
+    # extended-size form: size field 1, 64-bit size below 16
+    d2 = bytearray(base)
+    d2[i:i + 8] = struct.pack(">I4s", 1, container)
+    d2[i + 8:i + 16] = struct.pack(">Q", size + 8)
+    try:
+        want2 = O.update(bytes(d2), otags)
+    except ValueError:
+        want2 = None
+    try:
+        got2 = M.update_mp4_metadata(bytes(d2), tags)
+    except M.Mp4MetaError:
+        got2 = None
+    assert got2 == want2
+
+
 def test_library_exports_every_declared_symbol():
     """include/mp3rgain_amd_mp4.h, the ctypes binding and the shared library agree on the entry points."""
     import ctypes as C
