@@ -18,11 +18,27 @@ import numpy as np
 from . import _capi
 
 
-def shard_indices(n_tracks: int, world: int, rank: int) -> List[int]:
-    """Tracks of the album that `rank` analyses (round robin keeps shards balanced for like-sized tracks)."""
+def shard_indices(n_tracks: int, world: int, rank: int, frames: Optional[Sequence[int]] = None) -> List[int]:
+    """Tracks of the album that `rank` analyses, in ascending order.
+
+    Without `frames`: round robin (rank r owns r, r + world, ...), which is balanced for like-sized tracks and is
+    the split BASELINE configs[3] names.  With `frames` (one length per track): balanced by cumulative frames --
+    longest track first, each to the rank with the least work so far (ties: the lower rank), so that a few long
+    tracks in an album of short ones do not make one GPU the straggler.  Deterministic: every rank computes the
+    same partition from the same list."""
     if not (0 <= rank < world):
         raise ValueError("rank out of range")
-    return list(range(rank, n_tracks, world))
+    if frames is None:
+        return list(range(rank, n_tracks, world))
+    if len(frames) != n_tracks:
+        raise ValueError("frames must hold one length per track")
+    load = [0] * world
+    owner = [0] * n_tracks
+    for t in sorted(range(n_tracks), key=lambda i: (-int(frames[i]), i)):
+        r = min(range(world), key=lambda q: (load[q], q))
+        owner[t] = r
+        load[r] += int(frames[t])
+    return [t for t in range(n_tracks) if owner[t] == rank]
 
 
 def allreduce_album(hist_i32, peak_f64, group=None, even_if_alone: bool = False) -> None:
@@ -69,7 +85,7 @@ def album_result_from_hist(hist_u32: np.ndarray, peak: float) -> dict:
             "album_gain_steps": lib.rg_gain_steps(gain), "windows": int(h.sum(dtype=np.uint64))}
 
 
-def gather_track_results(local: Sequence, n_tracks: int, group=None) -> Optional[list]:
+def gather_track_results(local: Sequence, n_tracks: int, group=None, frames: Optional[Sequence[int]] = None) -> Optional[list]:
     """Per-track results back in input order (track_results.push order, src/replaygain.rs:1061):
     every rank contributes the results of shard_indices(n_tracks, world, rank); all ranks get the list."""
     import torch.distributed as dist
@@ -81,6 +97,6 @@ def gather_track_results(local: Sequence, n_tracks: int, group=None) -> Optional
     dist.all_gather_object(buckets, list(local), group=group)
     out = [None] * n_tracks
     for r in range(world):
-        for k, t in enumerate(shard_indices(n_tracks, world, r)):
+        for k, t in enumerate(shard_indices(n_tracks, world, r, frames)):
             out[t] = buckets[r][k]
     return out

@@ -1,25 +1,36 @@
 #!/bin/bash
-# usage: tools/prof_pmc.sh <outdir> <bench args...>   (run on the GPU box through gpurun)
+# usage: tools/prof_pmc.sh <tag> <frames_per_launch> <bench args...>     (run on the GPU box through gpurun)
+#   e.g. tools/prof_pmc.sh cfg2 7938000000                      (bench.py's default workload, configs[2])
+#        tools/prof_pmc.sh cfg1 26460000 --tracks-per-rank 1 --minutes 10
+# Writes raw rocprofv3 output under gpurun_out/prof_<tag>/ and the summaries that are committed under profiles/:
+#   r02_<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the bench command
+#   r02_<tag>_span.json          per-kernel span / concurrency derived from the raw kernel trace
+#   r02_pmc_<tag>.json           per-launch PMC means of the dominant kernel (read by bench.py)
+#   r02_<tag>_pmc_summary.txt    every counter, every kernel
 # Each counter group is its own rocprofv3 run (no trace domains combined with --pmc), each under a timeout.
-OUT=$1; shift
-cd /tmp && export TMPDIR=/tmp
+TAG=$1; FRAMES=$2; shift 2
 R=${GRAFT_REPO_ROOT:-/root/repo}
-mkdir -p $R/$OUT
+OUT=gpurun_out/prof_$TAG
+cd /tmp && export TMPDIR=/tmp
+mkdir -p $R/$OUT $R/profiles
 cd $R
-run() { name=$1; shift; timeout 150 rocprofv3 "$@" -d $OUT/$name --output-format csv -- python bench.py --cpu-reps 0 $BENCH_ARGS $EXTRA > $OUT/$name.log 2>&1 || echo "$name failed/timeout"; }
 BENCH_ARGS="$*"
-EXTRA=""
+run() { name=$1; shift; timeout ${PROF_TIMEOUT:-400} rocprofv3 "$@" -d $OUT/$name --output-format csv -- python bench.py --cpu-seconds 0 --no-configs1 $BENCH_ARGS $EXTRA > $OUT/$name.log 2>&1 || echo "$name failed/timeout"; }
+EXTRA="${KT_EXTRA:-}"
 run kt --kernel-trace --stats
-# the counter passes serialise the dispatches and write one row per dispatch and counter: a short pre-roll and 100
+# the counter passes serialise the dispatches and write one row per dispatch and counter: a short pre-roll and few
 # timed steps keep them small (the counters are per dispatch, they do not depend on how many there are)
-EXTRA="--pre-roll 0.01 --steps 100 --warmup 5"
-run pmc_sq1 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
-run pmc_sq2 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU
-run pmc_grbm --pmc GRBM_GUI_ACTIVE GRBM_COUNT
+EXTRA="${PMC_EXTRA:---pre-roll 0.01 --steps 6 --warmup 1}"
 run pmc_fetch --pmc FETCH_SIZE
 run pmc_write --pmc WRITE_SIZE
+run pmc_sq1 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
+run pmc_f64 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32
+if [ -z "$PMC_SHORT" ]; then
+run pmc_sq2 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU
+run pmc_grbm --pmc GRBM_GUI_ACTIVE GRBM_COUNT
 run pmc_tcc --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
-run pmc_lat --pmc SQ_INST_LEVEL_SMEM SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_BUSY_CU_CYCLES
-run pmc_sqc --pmc SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_REQ SQC_TC_STALL
 run pmc_lds --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT
-find $OUT -name "*.csv" | head -40
+run pmc_lat --pmc SQ_INST_LEVEL_SMEM SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_BUSY_CU_CYCLES
+fi
+python tools/prof_summary.py $OUT $TAG $FRAMES "$BENCH_ARGS" > profiles/r02_${TAG}_pmc_summary.txt 2>&1
+tail -5 profiles/r02_${TAG}_pmc_summary.txt

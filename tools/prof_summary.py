@@ -1,19 +1,68 @@
 #!/usr/bin/env python3
-"""Summarise a tools/prof_pmc.sh output directory: per-kernel average duration and PMC counters."""
+"""Summarise a tools/prof_pmc.sh output directory and write the files that are committed under profiles/.
+
+    prof_summary.py <rawdir> <tag> <frames_per_launch> "<bench args>"
+
+  profiles/r02_<tag>_kernel_stats.csv  copy of rocprofv3's kernel_stats.csv
+  profiles/r02_<tag>_span.json         per kernel: launches, sum of durations, first-start-to-last-end span, concurrency
+                                       (from the raw kernel trace: the stats file's average alone says nothing about
+                                       throughput when launches of consecutive batches overlap)
+  profiles/r02_pmc_<tag>.json          per-launch PMC means of the dominant kernel; bench.py reads it
+"""
 import csv
 import glob
+import json
+import os
+import shutil
 import sys
 from collections import defaultdict
 
-d = sys.argv[1]
+d, tag, frames, bench_args = sys.argv[1], sys.argv[2], int(sys.argv[3]), (sys.argv[4] if len(sys.argv) > 4 else "")
+prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+MAIN = "rg_tm_main_kernel"
+
 for f in glob.glob(f"{d}/kt/*/*kernel_stats.csv"):
+    shutil.copy(f, os.path.join(prof, f"r02_{tag}_kernel_stats.csv"))
     print("== kernel stats (rocprofv3 --kernel-trace --stats)")
     for r in csv.DictReader(open(f)):
         print(f"  {r['Name'][:60]:60s} calls {r['Calls']:>5s} avg_ns {float(r['AverageNs']):12.1f} pct {r['Percentage']}")
+
+# ---- span / concurrency per kernel from the raw trace ------------------------------------------------------
+spans = {}
+for f in glob.glob(f"{d}/kt/*/*kernel_trace.csv"):
+    per = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        per[r["Kernel_Name"].split("(")[0].replace("void ", "")].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    for k, iv in per.items():
+        if "rg_" not in k:
+            continue
+        iv.sort()
+        # the timed region's launches: drop the pre-roll / warm-up by keeping the last 60 % of the launches
+        keep = iv[int(len(iv) * 0.4):] if len(iv) >= 10 else iv
+        tot = sum(e - s for s, e in keep)
+        span = max(e for _, e in keep) - min(s for s, _ in keep)
+        spans[k] = {"launches_all": len(iv), "launches_counted": len(keep), "sum_duration_ms": tot / 1e6,
+                    "avg_duration_ms": tot / 1e6 / len(keep), "span_ms": span / 1e6,
+                    "concurrency": tot / span if span else 1.0, "span_per_launch_ms": span / 1e6 / len(keep)}
+if spans:
+    m = next((v for k, v in spans.items() if MAIN in k), None)
+    doc = {"command": f"rocprofv3 --kernel-trace --stats -- python bench.py --cpu-seconds 0 --no-configs1 {bench_args}".strip(),
+           "frames_per_launch": frames, "kernels": spans,
+           "note": "launches_counted = the last 60 % of each kernel's launches (pre-roll and warm-up dropped); "
+                   "span = first start to last end of those; concurrency = sum of durations / span"}
+    if m:
+        doc["dominant_kernel"] = {"name": MAIN, "algorithmic_bytes_per_launch": 8 * frames,
+                                  "achieved_GBps_span": 8 * frames / (m["span_per_launch_ms"] * 1e-3) / 1e9,
+                                  "hbm_frac_span": 8 * frames / (m["span_per_launch_ms"] * 1e-3) / 8e12,
+                                  "achieved_GBps_avg_duration": 8 * frames / (m["avg_duration_ms"] * 1e-3) / 1e9,
+                                  "fp64_algorithmic_tflops_span": 108 * frames / (m["span_per_launch_ms"] * 1e-3) / 1e12}
+    json.dump(doc, open(os.path.join(prof, f"r02_{tag}_span.json"), "w"), indent=1)
+    print("== span", json.dumps(doc.get("dominant_kernel")))
+
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(f"{d}/pmc_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"][:44]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")[:44]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("== PMC (mean per dispatch)")
 for k, cs in acc.items():
     if "rg_" not in k:
@@ -22,30 +71,27 @@ for k, cs in acc.items():
     for c, v in sorted(cs.items()):
         print(f"      {c:28s} {sum(v)/len(v):16.1f}  (n={len(v)})")
 
-# ---- profiles/pmc_traffic.json: HBM bytes per launch of the dominant kernel (read by bench.py) -------------
-# MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB-units of 1024 B as reported; on gfx950 FETCH_SIZE
-# tallies 128-byte requests at 64 B, hence the x2; each counter comes from its own --pmc pass.
-if len(sys.argv) > 2:
-    import json
-
-    main = [k for k in acc if "rg_tm_main_kernel" in k or "rg_halo" in k]
-    if main:
-        k = main[0]
-        f, w = acc[k].get("FETCH_SIZE", []), acc[k].get("WRITE_SIZE", [])
-        if f and w:
-            fk, wk = sum(f) / len(f), sum(w) / len(w)
-            frames = int(sys.argv[3]) if len(sys.argv) > 3 else 26460000
-            out = {
-                "kernel": "rg_tm_main_kernel",
-                "frames_per_launch": frames,
-                "fetch_size_kib_reported": fk,
-                "write_size_kib_reported": wk,
-                "dispatches_averaged": [len(f), len(w)],
-                "correction": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B), WRITE_SIZE as reported",
-                "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0,
-                "algorithmic_bytes_per_launch": frames * 8,
-                "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --cpu-reps 0 --pre-roll 0.01 --steps 100 --warmup 5",
-                "note": "PMC passes serialise the dispatches; the 211.7 MB input also fits the 256 MiB Infinity Cache, whose hits these fabric-side counters include",
-            }
-            json.dump(out, open(sys.argv[2], "w"), indent=1)
-            print("wrote", sys.argv[2])
+# ---- profiles/r02_pmc_<tag>.json ---------------------------------------------------------------------------
+# MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE tallies the 128-byte
+# requests of a wide coalesced streaming read at 64 B, hence the x2; each counter comes from its own --pmc pass.
+main = [k for k in acc if MAIN in k]
+if main:
+    cs = acc[main[0]]
+    mean = lambda name: (sum(cs[name]) / len(cs[name])) if cs.get(name) else None  # noqa: E731
+    fk, wk = mean("FETCH_SIZE"), mean("WRITE_SIZE")
+    out = {"kernel": MAIN, "workload_tag": tag, "frames_per_launch": frames,
+           "algorithmic_bytes_per_launch": frames * 8,
+           "fetch_size_kib_reported": fk, "write_size_kib_reported": wk,
+           "correction": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B), WRITE_SIZE as reported",
+           "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0 if fk is not None and wk is not None else None,
+           "valu_insts_per_launch": mean("SQ_INSTS_VALU"),
+           "fma_f64_insts_per_launch": mean("SQ_INSTS_VALU_FMA_F64"),
+           "add_f64_insts_per_launch": mean("SQ_INSTS_VALU_ADD_F64"),
+           "mul_f64_insts_per_launch": mean("SQ_INSTS_VALU_MUL_F64"),
+           "cvt_insts_per_launch": mean("SQ_INSTS_VALU_CVT"),
+           "waves_per_launch": mean("SQ_WAVES"),
+           "dispatches_averaged": {k: len(v) for k, v in cs.items() if k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64")},
+           "command": f"rocprofv3 --pmc <one group per pass> -- python bench.py --cpu-seconds 0 --no-configs1 {bench_args} --pre-roll 0.01 --steps 6 --warmup 1".replace("  ", " "),
+           "note": "PMC passes serialise the dispatches: these describe one launch alone"}
+    json.dump(out, open(os.path.join(prof, f"r02_pmc_{tag}.json"), "w"), indent=1)
+    print("wrote", f"profiles/r02_pmc_{tag}.json")
