@@ -90,7 +90,8 @@ def pmc_for(tag: str, frames_per_launch: int):
     return pm if pm.get("frames_per_launch") == frames_per_launch else None
 
 
-def roofline_block(frames_per_launch: int, k_ms_sum: float, k_launches: int, k_span_ms: float, tag: str) -> dict:
+def roofline_block(frames_per_launch: int, k_ms_sum: float, k_launches: int, k_span_ms: float, tag: str,
+                   algo_bytes: int = 0, algo_flop: int = 0, launches_per_step: int = 1) -> dict:
     """Both bounds for the dominant kernel.
 
     Consecutive batches run in separate pipeline slots, so several launches can be in flight at once:
@@ -102,10 +103,12 @@ def roofline_block(frames_per_launch: int, k_ms_sum: float, k_launches: int, k_s
     k_ms = k_ms_sum / max(1, k_launches)
     conc = k_ms_sum / k_span_ms if k_span_ms > 0 else 1.0
     span_s = k_span_ms * 1e-3
-    algo_bytes = ALGO_BYTES_PER_FRAME * frames_per_launch
-    algo_flop = ALGO_FLOP_PER_FRAME * frames_per_launch
-    gbps = algo_bytes * k_launches / span_s / 1e9 if span_s > 0 else 0.0
-    tflops = algo_flop * k_launches / span_s / 1e12 if span_s > 0 else 0.0
+    # per step (= per launch for a uniform batch; a mixed batch splits into launches_per_step launch groups)
+    algo_bytes = algo_bytes or ALGO_BYTES_PER_FRAME * frames_per_launch
+    algo_flop = algo_flop or ALGO_FLOP_PER_FRAME * frames_per_launch
+    k_steps = k_launches / launches_per_step
+    gbps = algo_bytes * k_steps / span_s / 1e9 if span_s > 0 else 0.0
+    tflops = algo_flop * k_steps / span_s / 1e12 if span_s > 0 else 0.0
     pm = pmc_for(tag, frames_per_launch)
     traffic = pm["hbm_bytes_per_launch"] if pm else None
     fp64 = {"achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
@@ -118,9 +121,9 @@ def roofline_block(frames_per_launch: int, k_ms_sum: float, k_launches: int, k_s
         if fma:
             ex["fma_f64_wave_insts_per_launch"] = fma
             ex["fma_f64_per_channel_sample"] = fma * 64.0 / (2.0 * frames_per_launch)
-            ex["tflops"] = 2.0 * 64.0 * fma * k_launches / span_s / 1e12 if span_s > 0 else 0.0
+            ex["tflops"] = 2.0 * 64.0 * fma * k_steps / span_s / 1e12 if span_s > 0 else 0.0
         else:  # no FP64-specific counter: every VALU instruction priced as an FMA (upper bound on the flops)
-            ex["tflops_upper_bound"] = 2.0 * 64.0 * pm["valu_insts_per_launch"] * k_launches / span_s / 1e12 if span_s > 0 else 0.0
+            ex["tflops_upper_bound"] = 2.0 * 64.0 * pm["valu_insts_per_launch"] * k_steps / span_s / 1e12 if span_s > 0 else 0.0
         ex["valu_per_channel_sample"] = pm["valu_insts_per_launch"] * 64.0 / (2.0 * frames_per_launch)
         fp64["executed"] = ex
     return {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
@@ -129,8 +132,9 @@ def roofline_block(frames_per_launch: int, k_ms_sum: float, k_launches: int, k_s
             "fp64": fp64,
             "kernel": "rg_tm_main_kernel", "kernel_ms": k_ms, "kernel_launches": int(k_launches),
             "kernel_concurrency": conc, "kernel_span_ms": k_span_ms,
-            "achieved_one_launch_alone": algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
-            "algorithmic_bytes_per_launch": algo_bytes}
+            "launch_groups_per_step": launches_per_step,
+            "achieved_one_launch_alone": algo_bytes / launches_per_step / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
+            "algorithmic_bytes_per_launch": algo_bytes // launches_per_step}
 
 
 def main() -> int:
@@ -146,6 +150,9 @@ def main() -> int:
     ap.add_argument("--total-tracks", type=int, default=0, help="album size for --scaling strong (default: --tracks-per-rank)")
     ap.add_argument("--tm-segment", type=int, default=0, help="force variant 2 segment length (tuning)")
     ap.add_argument("--slots", type=int, default=0, help="pipeline slots of the library (0 = default)")
+    ap.add_argument("--mixed", action="store_true",
+                    help="BASELINE configs[4]'s PCM side instead: half the tracks at 44.1 kHz, half at 48 kHz, every 10th mono, "
+                         "every 20th with full-scale (clipped) peaks")
     ap.add_argument("--album", action="store_true", help="force the album path (collectives) even on one GPU")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU time budget of each cpu_baseline leg (0 = skip baseline and parity)")
     ap.add_argument("--parity-tracks", type=int, default=16, help="tracks of the batch whose full histogram is compared with the oracle")
@@ -200,23 +207,39 @@ def main() -> int:
     # context's own pipeline streams (rg_batch_stream), which costs no cross-stream event per step.
 
     # ---- synthetic PCM straight into HBM ---------------------------------------------------
-    def make_batch(n_tracks: int, n_frames: int, seeds):
-        t_pcm = torch.empty((max(1, n_tracks), 2, n_frames), dtype=torch.float32, device="cuda")
+    def make_batch(specs):
+        """specs: [(seed, rate, channels, frames)] -> (arena tensor, descriptors, bytes)"""
+        n_tracks = len(specs)
+        total = sum(ch * fr for _, _, ch, fr in specs)
+        t_pcm = torch.empty(max(1, total), dtype=torch.float32, device="cuda")
         t_descs = (_capi.TrackDesc * max(1, n_tracks))()
-        for t in range(n_tracks):
-            for c in range(2):
-                an.synth_fill_device(t_pcm[t, c].data_ptr(), seeds[t], c, RATE, 0, n_frames)
-            t_descs[t].offset_bytes = t * 2 * n_frames * 4
-            t_descs[t].frames = n_frames
-            t_descs[t].sample_rate = RATE
-            t_descs[t].channels = 2
+        off = 0
+        for t, (seed, rate, ch, fr) in enumerate(specs):
+            for c in range(ch):
+                an.synth_fill_device(t_pcm[off + c * fr:].data_ptr(), seed, c, rate, 0, fr)
+            t_descs[t].offset_bytes = off * 4
+            t_descs[t].frames = fr
+            t_descs[t].sample_rate = rate
+            t_descs[t].channels = ch
             t_descs[t].format = _capi.FMT_F32_PLANAR
+            off += ch * fr
         torch.cuda.synchronize()
-        return t_pcm, t_descs
+        return t_pcm, t_descs, total * 4
 
-    seeds = [0x5EED0000 + g for g in mine]
-    pcm, descs = make_batch(ntr, frames, seeds)
-    pcm_bytes = pcm.numel() * 4
+    HOT = 1 << 40  # RG_SYNTH_HOT_BIT: boosted and hard-clipped, peak >= 1.0 (the -k rule's input)
+    if args.mixed:
+        specs = []
+        for k, g in enumerate(mine):
+            rate = RATE if k < (ntr + 1) // 2 else 48000
+            specs.append((0x5EED0000 + g + (HOT if g % 20 == 7 else 0), rate, 1 if g % 10 == 9 else 2,
+                          int(round(args.minutes * 60 * rate))))
+    else:
+        specs = [(0x5EED0000 + g, RATE, 2, frames) for g in mine]
+    seeds = [sp[0] for sp in specs]
+    pcm, descs, pcm_bytes = make_batch(specs)
+    batch_frames = sum(sp[3] for sp in specs)                    # frames this rank analyses per step
+    batch_algo_bytes = sum(4 * sp[2] * sp[3] for sp in specs)    # f32, each channel read once
+    batch_algo_flop = sum(54 * sp[2] * sp[3] for sp in specs)    # 27 FMA per channel-sample
 
     album = world > 1 or args.album
     # The album exchange (LoudnessHistogram::accumulate / album_peak.max across ranks, replaygain.rs:1056-1059) is
@@ -285,7 +308,7 @@ def main() -> int:
         an.timing_enable(False)
         return dt_, ks, kl, ksp
 
-    dt, k1_ms_sum, k1_launches, k1_span_ms = timed(step, args.steps, args.warmup, frames * max(1, ntr))
+    dt, k1_ms_sum, k1_launches, k1_span_ms = timed(step, args.steps, args.warmup, max(1, batch_frames))
 
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -298,18 +321,26 @@ def main() -> int:
     n_imprecise = sum(1 for r in res if r.flags & 2)
     n_nonfinite = sum(1 for r in res if r.flags & 1)
 
-    total_frames = frames * total_tracks * args.steps  # every rank's tracks, every step
+    if dist is not None:  # every rank's tracks, every step
+        tf = torch.tensor([batch_frames], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tf)
+        total_frames = int(tf.item()) * args.steps
+    else:
+        total_frames = batch_frames * args.steps
     value = total_frames / dt
-    tag = workload_tag(ntr, frames, album)
-    roof = roofline_block(frames * ntr, k1_ms_sum, k1_launches, k1_span_ms, tag)
+    tag = "cfg5" if args.mixed and ntr == 1000 and args.minutes == 3.0 else workload_tag(ntr, frames, album)
+    # a mixed batch is several launch groups (rate x channel count) per step: the per-launch figures are per group
+    groups = len({(sp[1], sp[2]) for sp in specs}) or 1
+    roof = roofline_block(batch_frames, k1_ms_sum, k1_launches, k1_span_ms, tag, algo_bytes=batch_algo_bytes,
+                          algo_flop=batch_algo_flop, launches_per_step=groups)
 
     # ---- secondary workload on one GPU: configs[1], one 10-minute track (fits the Infinity Cache) ----------
     configs1 = None
-    if world == 1 and not args.no_configs1 and not album:
-        pcm1, descs1 = make_batch(1, FRAMES_10MIN, [0x5EED0000])
+    if world == 1 and not args.no_configs1 and not album and not args.mixed:
+        pcm1, descs1, bytes1 = make_batch([(0x5EED0000, RATE, 2, FRAMES_10MIN)])
 
         def step1():
-            an.enqueue_device(descs1, 1, pcm1.data_ptr(), pcm1.numel() * 4, album=False)
+            an.enqueue_device(descs1, 1, pcm1.data_ptr(), bytes1, album=False)
 
         d1, s1, l1, sp1 = timed(step1, args.configs1_steps, 20, FRAMES_10MIN)
         r1 = an.collect(1)
@@ -336,22 +367,32 @@ def main() -> int:
             peaks_equal = True
             same_input = True
             want0 = None
-            for t in range(npar):
-                l = po.synth_f32(seeds[t], 0, RATE, frames)
-                r = po.synth_f32(seeds[t], 1, RATE, frames)
-                if t == 0:
-                    host = pcm[0].cpu().numpy()
-                    same_input = bool(np.array_equal(host[0], l) and np.array_equal(host[1], r))
-                want, want_hist = po.analyze_pcm(l, r, RATE)
-                if t == 0:
-                    want0, l0, r0 = want, l, r
+            # in a mixed batch the compared tracks are spread over it, so that every launch group is covered
+            if args.mixed:
+                pick = {(k * ntr) // npar for k in range(npar)}
+                pick |= {next((i for i in range(ntr) if specs[i][2] == 1), 0), next((i for i in range(ntr) if specs[i][0] & HOT), 0)}
+                pick |= {next((i for i in range(ntr - 1, -1, -1) if specs[i][2] == 1), 0)}  # a mono track of the second rate
+                pick = sorted(pick)
+            else:
+                pick = list(range(npar))
+            for n_done, t in enumerate(pick):
+                seed_t, rate_t, ch_t, fr_t = specs[t]
+                l = po.synth_f32(seed_t, 0, rate_t, fr_t)
+                r = po.synth_f32(seed_t, 1, rate_t, fr_t) if ch_t == 2 else None
+                if n_done == 0:
+                    off0 = descs[t].offset_bytes // 4
+                    host = pcm[off0:off0 + ch_t * fr_t].cpu().numpy().reshape(ch_t, fr_t)
+                    same_input = bool(np.array_equal(host[0], l) and (r is None or np.array_equal(host[1], r)))
+                want, want_hist = po.analyze_pcm(l, r, rate_t)
+                if n_done == 0:
+                    want0, l0, r0, rate0, fr0, t0_ = want, l, r, rate_t, fr_t, t
                 diff_bins += int(np.count_nonzero(hists[t] != want_hist))
                 max_db = max(max_db, abs(res[t].loudness_db - want["loudness_db"]))
                 peaks_equal = peaks_equal and res[t].peak == want["peak"]
-            parity = {"tracks_compared": npar, "same_input_bits": same_input, "differing_histogram_bins": diff_bins,
+            parity = {"tracks_compared": len(pick), "same_input_bits": same_input, "differing_histogram_bins": diff_bins,
                       "max_abs_db_delta": max_db, "peaks_equal": peaks_equal,
-                      "loudness_db_gpu": res[0].loudness_db, "loudness_db_oracle": want0["loudness_db"],
-                      "db_delta": res[0].loudness_db - want0["loudness_db"],
+                      "loudness_db_gpu": res[t0_].loudness_db, "loudness_db_oracle": want0["loudness_db"],
+                      "db_delta": res[t0_].loudness_db - want0["loudness_db"],
                       "tracks_flagged_imprecise": n_imprecise, "tracks_flagged_nonfinite": n_nonfinite,
                       "tracks_in_batch": ntr,
                       "note": "async enqueue/collect path: a flagged track may have windows off by <= 3 bins (0.03 dB); "
@@ -360,7 +401,7 @@ def main() -> int:
             c0 = time.perf_counter()
             reps = 0
             while True:
-                po.analyze_pcm(l0, r0, RATE)
+                po.analyze_pcm(l0, r0, rate0)
                 reps += 1
                 if time.perf_counter() - c0 >= args.cpu_seconds:
                     break
@@ -373,15 +414,19 @@ def main() -> int:
             per_thread = max(1, int(reps * min(1.0, 4.0 / max(cdt, 1e-9))))  # about 4 s per thread
             m0 = time.perf_counter()
             with ThreadPoolExecutor(nthr) as pool:  # ctypes releases the GIL inside the C call
-                list(pool.map(lambda _: [po.analyze_pcm(l0, r0, RATE) for _ in range(per_thread)], range(nthr)))
+                list(pool.map(lambda _: [po.analyze_pcm(l0, r0, rate0) for _ in range(per_thread)], range(nthr)))
             mdt = time.perf_counter() - m0
-            cpu = {"value": frames * reps / cdt, "unit": "stereo samples/s", "cores": 1, "kind": "port",
-                   "sample": f"track 0 of the batch ({frames} stereo frames @44.1 kHz) x{reps} = {cdt:.1f} s, "
+            cpu = {"value": fr0 * reps / cdt, "unit": "stereo samples/s", "cores": 1, "kind": "port",
+                   "sample": f"track {t0_} of the batch ({fr0} stereo frames @{rate0 / 1000:g} kHz) x{reps} = {cdt:.1f} s, "
                              f"oracle/rg_oracle.c (C restatement of replaygain.rs, not the Rust binary), 1 thread, "
                              f"host has {os.cpu_count()} cores, {_usable_cores()} usable by this process",
-                   "all_cores": {"value": frames * per_thread * nthr / mdt, "cores": nthr,
+                   "all_cores": {"value": fr0 * per_thread * nthr / mdt, "cores": nthr,
                                  "sample": f"the same track x{per_thread} on each of {nthr} threads (tracks as the parallel unit)"}}
-        if world == 1 and not album:
+        if args.mixed:
+            wl = (f"configs[4], PCM side: {ntr} synthetic {args.minutes:g}-min tracks per GPU, half 44.1 kHz and half 48 kHz, every 10th mono, "
+                  f"every 20th clipped at full scale (peak >= 1.0), {pcm_bytes / 1e9:.1f} GB planar f32 resident in HBM; "
+                  f"{groups} launch groups per step (AAC/M4A decode itself is not part of this line)")
+        elif world == 1 and not album:
             wl = (f"configs[2]: batch of {ntr} synthetic {frames / RATE / 60:g}-min 44.1 kHz stereo tracks, per-track gain (-r), "
                   f"{pcm_bytes / 1e9:.1f} GB planar f32 resident in HBM" if tag == "cfg2"
                   else f"track mode: {ntr} x {frames / RATE / 60:g}-min 44.1 kHz stereo track(s), {pcm_bytes / 1e9:.2f} GB resident in HBM")
