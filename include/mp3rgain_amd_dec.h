@@ -1,0 +1,64 @@
+/* mp3rgain_amd_dec.h -- C ABI of the PCM decode row: MPEG-1 / MPEG-2 / MPEG-2.5
+ * Layer III bitstream -> planar f32 PCM, the form `process_audio_buffer` consumes (src/replaygain.rs:953-1029).
+ *
+ * What it replaces in the reference (citations are file:line under /root/reference):
+ *   symphonia::default::get_probe().format(...)      src/replaygain.rs:815-822   container probe: ID3v2 skip, frame sync,
+ *                                                                                 Xing/Info/VBRI header frame not decoded
+ *   track.codec_params.{sample_rate, channels}       src/replaygain.rs:855-858   rg_mp3_stream_info
+ *   format.next_packet() / decoder.decode(&packet)   src/replaygain.rs:881-900   the frame loop: a frame that cannot be
+ *                                                                                 decoded is skipped (DecodeError -> continue),
+ *                                                                                 the end of the data ends the track
+ * The decoder crate (symphonia 0.5.5, Cargo.lock:230-311) is not part of the reference tree; this is an independent
+ * implementation of ISO/IEC 11172-3 / 13818-3 Layer III with the same packet semantics: every audio frame yields
+ * 1152 (MPEG-1) or 576 (MPEG-2 / 2.5) frames of PCM per channel, FormatOptions::default() => no gapless trimming
+ * (encoder delay and padding are decoded and analysed like everything else), f32 samples nominally in [-1, 1].
+ *
+ * Host code, no GPU needed.  Plain C types only.
+ */
+#ifndef MP3RGAIN_AMD_DEC_H
+#define MP3RGAIN_AMD_DEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rg_mp3dec_status {
+    RG_MP3DEC_OK = 0,
+    RG_MP3DEC_ERR_ARG = -1,
+    RG_MP3DEC_ERR_NO_AUDIO = -2, /* no Layer III frame found: the reference's "Failed to probe format" */
+    RG_MP3DEC_ERR_CAPACITY = -3  /* output buffers too small (frames needed are reported in the info) */
+} rg_mp3dec_status;
+
+typedef struct rg_mp3_stream_info {
+    uint32_t sample_rate;     /* of the first audio frame; frames at another rate are skipped            */
+    uint32_t channels;        /* 1 or 2, of the first audio frame                                        */
+    uint64_t frames;          /* PCM frames per channel: scan = upper bound, decode = what was produced  */
+    uint32_t audio_frames;    /* Layer III frames found (scan) / decoded (decode)                        */
+    uint32_t skipped_frames;  /* frames that could not be decoded and were dropped (bit reservoir underflow,
+                                 invalid side info): DecodeError -> continue, src/replaygain.rs:896-899   */
+    uint32_t info_frame;      /* 1: a Xing / Info / VBRI header frame was found and not decoded (lib.rs:388-408 skips it too) */
+    uint32_t id3v2_bytes;     /* size of the ID3v2 tag skipped at the start                              */
+    uint32_t mpeg_version;    /* 1, 2, or 25 (MPEG-2.5)                                                  */
+    uint32_t samples_per_frame; /* 1152 or 576                                                           */
+    uint64_t first_frame_offset;
+    uint32_t junk_bytes;      /* bytes skipped while resynchronising                                     */
+    uint32_t reserved;
+} rg_mp3_stream_info;
+
+/* Header-level scan (no decoding): stream parameters and an upper bound of the PCM length. */
+int rg_mp3_scan(const void *data, size_t len, rg_mp3_stream_info *out);
+
+/* Decode a whole stream.  ch0 / ch1: planar outputs of `capacity` frames each (ch1 may be NULL for a mono stream).
+ * On RG_MP3DEC_OK out->frames holds the number of frames written per channel. */
+int rg_mp3_decode_f32(const void *data, size_t len, float *ch0, float *ch1, uint64_t capacity, rg_mp3_stream_info *out);
+
+/* Text of the last error of the calling thread ("" if none). */
+const char *rg_mp3dec_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MP3RGAIN_AMD_DEC_H */
