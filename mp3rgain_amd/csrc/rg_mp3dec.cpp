@@ -122,7 +122,7 @@ size_t find_sync(const uint8_t *d, size_t len, size_t pos, Header *h, bool need_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// bit reader over a byte buffer (caller guarantees 8 readable bytes past the end)
+// bit reader over a byte buffer (caller guarantees 64 readable bytes past the end)
 // ---------------------------------------------------------------------------------------------------------------
 struct Bits {
     const uint8_t *p;
@@ -283,7 +283,9 @@ struct SideInfo {
 };
 
 bool parse_side_info(const uint8_t *p, const Header &h, const Tables &T, SideInfo *si) {
-    Bits b{p, 0, (size_t)h.side_bytes * 8};
+    uint8_t padded[32 + 8] = {0};  // the bit reader looks up to 3 bytes ahead; the frame may end with the side information
+    memcpy(padded, p, (size_t)h.side_bytes);
+    Bits b{padded, 0, (size_t)h.side_bytes * 8};
     const int nch = h.channels, ngr = h.lsf ? 1 : 2;
     memset(si, 0, sizeof *si);
     if (!h.lsf) {
@@ -447,7 +449,8 @@ void read_scalefactors_lsf(Bits &b, Granule &g, bool intensity_right, ChannelSta
         for (int q = 0; q < n; ++q, ++i) {
             const int v = (int)b.get(slen[k]);
             sf[i] = v;
-            cs.illegal[i] = (uint8_t)(intensity_right && v == (1 << slen[k]) - 1 ? 1 : 0);
+            // a partition without bits transmits position 0 for its bands, which is a legal position (equal gains)
+            cs.illegal[i] = (uint8_t)(intensity_right && slen[k] > 0 && v == (1 << slen[k]) - 1 ? 1 : 0);
         }
     }
     for (; i < 40; ++i) { sf[i] = 0; cs.illegal[i] = 0; }
@@ -757,7 +760,7 @@ bool decode_frame(Decoder &D, const uint8_t *f, const Header &h, const Tables &T
     if (ok) {
         const size_t begin = have - (size_t)si.main_data_begin;
         const size_t total = D.reservoir.size() - begin;
-        std::vector<uint8_t> buf(total + 8, 0);
+        std::vector<uint8_t> buf(total + 64, 0);  // scalefactor / linbits reads may run a few bytes past a granule that lies about its length
         memcpy(buf.data(), D.reservoir.data() + begin, total);
         Bits b{buf.data(), 0, total * 8};
         const int ngr = h.lsf ? 1 : 2;

@@ -92,8 +92,9 @@ def main():
         pcm, info = decode(data, rate)
         assert info["rate"] == rate
         # that build's MP3 decoder is ffmpeg's fixed-point one: every sample is a multiple of 2^-15
-        q = np.round(pcm.astype(np.float64) * 32768.0)
-        assert np.abs(q / 32768.0 - pcm).max() < 1e-6, "not 16-bit quantised?"
+        p64 = pcm.astype(np.float64)
+        q = np.round(np.where(p64 > 0, p64 * 32767.0, p64 * 32768.0))  # Chromium's int16 -> float: /32767 above zero, /32768 below
+        assert np.abs(np.where(q > 0, q / 32767.0, q / 32768.0) - p64).max() < 1e-6, "not 16-bit quantised?"
         np.save(out / (Path(f).stem + ".ffmpeg.npy"), np.clip(q, -32768, 32767).astype(np.int16))
         print(f, info, "peak", float(np.abs(pcm).max()))
 
