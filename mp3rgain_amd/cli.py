@@ -214,6 +214,15 @@ _FILE_KEYS = ("file", "status", "frames", "mpeg_version", "channel_mode", "min_g
               "max_amplitude", "error", "warning", "dry_run")
 
 
+def _is_riff_wave(file) -> bool:
+    try:
+        with open(file, "rb") as f:
+            head = f.read(12)
+    except OSError:
+        return False
+    return len(head) == 12 and head[:4] == b"RIFF" and head[8:] == b"WAVE"
+
+
 def _file_result(file: Path, **kw) -> dict:
     d = {"file": str(file)}
     for k in _FILE_KEYS[1:]:
@@ -784,6 +793,13 @@ class Cli:
                 self.p(f"  v {name} ({'track+album tags' if album is not None else 'tags'} written, {rg.gain_db:+.1f} dB)")
             return _file_result(file, status="success", loudness_db=rg.loudness_db, peak=rg.peak, gain_applied_steps=rg.gain_steps(),
                                 gain_applied_db=rg.gain_db, warning=warning)
+        if _is_riff_wave(file):
+            # The reference cannot get here (its probe knows no WAV); this library analyses WAV, but PCM has no global_gain
+            # fields: the frame scanner would take false syncs in the samples for frames and rewrite audio bytes.
+            msg = "RIFF/WAVE input is analysed only: lossless gain applies to MPEG Layer III frames"
+            if self.talk:
+                self.e(f"  x {name} - {msg}")
+            return _file_result(file, status="error", error=msg)
         fn = mp3gain.apply_gain_with_undo_wrap if o.wrap_gain else mp3gain.apply_gain_with_undo
         try:
             frames = self._with_temp_file(file, lambda f: fn(f, actual))

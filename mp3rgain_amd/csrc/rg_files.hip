@@ -2,21 +2,28 @@
 // analyze_album / find_peak_amplitude on files, as the reference's public functions take them
 // (src/replaygain.rs:929-941, 1033-1074, 1140-1249).
 //
-// The reference gets PCM from a third-party decoder (symphonia) that is not part of this repo's scope and
-// cannot be restated offline.  What is accepted here instead:
-//   * RIFF/WAVE files (integer PCM 8/16/24/32 bit, IEEE float 32 bit, plain or WAVE_FORMAT_EXTENSIBLE);
-//   * any other file through an external decoder command that writes a WAV stream to stdout
-//     (rg_set_decoder_command, e.g. "ffmpeg -v error -i {} -f wav -c:a pcm_f32le -").
-// The interleaved bytes are copied to HBM as they are and turned into the planar arena of the analysis by a
-// device kernel; everything after that is the same path as rg_analyze_pcm_batch.
+// The reference gets PCM from symphonia (src/replaygain.rs:807-904).  Here a file is, by content:
+//   * an MPEG-1/2/2.5 Layer III stream (optionally behind an ID3v2 tag): decoded by the library's own decoder
+//     (rg_mp3dec.cpp, include/mp3rgain_amd_dec.h) into planar f32 that goes to HBM as it is -- the files of an
+//     album are decoded on all host cores at once;
+//   * a RIFF/WAVE file (integer PCM 8/16/24/32 bit, IEEE float 32 bit, plain or WAVE_FORMAT_EXTENSIBLE): the
+//     interleaved bytes are copied to HBM and turned into the planar arena by a device kernel;
+//   * anything else (M4A/AAC: no AAC decoder is built yet) through an external decoder command that writes a WAV
+//     stream to stdout (rg_set_decoder_command, e.g. "ffmpeg -v error -i {} -f wav -c:a pcm_f32le -").
+// Everything after the arena is the same path as rg_analyze_pcm_batch.
 #include <errno.h>
+#include <sched.h>
 #include <stdio.h>
 #include <string.h>
 
 #include <string>
 #include <vector>
 
+#include <atomic>
+#include <thread>
+
 #include "../../include/mp3rgain_amd.h"
+#include "../../include/mp3rgain_amd_dec.h"
 #include "../../include/mp3rgain_amd_mp4.h"
 #include "rg_ctx.h"
 
@@ -184,6 +191,15 @@ struct WavItem {
     uint64_t src_len;
 };
 
+// One input of the file layer after loading: either the bytes of a WAV stream, or planar f32 PCM from the MP3 decoder
+struct LoadedAudio {
+    std::vector<uint8_t> wav;
+    std::vector<float> planar;  // [channels][frames]
+    uint32_t sample_rate = 0, channels = 0;
+    uint64_t frames = 0;
+    bool decoded = false;       // planar is valid
+};
+
 size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // parse, copy to HBM, de-interleave: on return `descs` describe the planar arena c->d_arena
@@ -232,6 +248,67 @@ int stage_wavs(rg_ctx *c, const void *const *wav, const size_t *wav_len, size_t 
     return RG_OK;
 }
 
+// the same for loaded files: WAV items take the de-interleave route, decoded MP3 items are planar f32 already and go
+// straight into the arena
+int stage_loaded(rg_ctx *c, const std::vector<LoadedAudio> &in, std::vector<rg_track_desc> *descs, size_t *arena_bytes) {
+    const size_t n = in.size();
+    std::vector<WavItem> items(n);
+    size_t src_total = 0, dst_total = 0;
+    descs->assign(n ? n : 1, rg_track_desc{});
+    for (size_t i = 0; i < n; ++i) {
+        rg_track_desc &d = (*descs)[i];
+        d.offset_bytes = dst_total;
+        if (in[i].decoded) {
+            d.frames = in[i].frames;
+            d.sample_rate = in[i].sample_rate;
+            d.channels = (uint16_t)in[i].channels;
+            d.format = RG_FMT_F32_PLANAR;
+            dst_total = align16(dst_total + (size_t)in[i].frames * in[i].channels * sizeof(float));
+            continue;
+        }
+        WavItem &it = items[i];
+        it.bytes = in[i].wav.data();
+        if (rg_wav_parse(in[i].wav.data(), in[i].wav.size(), &it.info) != RG_OK)
+            return rg_set_err(c, RG_ERR_FORMAT, "input %zu is not a RIFF/WAVE stream", i);
+        it.kind = wav_kind(it.info);
+        if (it.kind < 0)
+            return rg_set_err(c, RG_ERR_FORMAT, "input %zu: unsupported WAV sample format (tag %u, %u bits)", i,
+                              it.info.sample_format, it.info.bits_per_sample);
+        it.src_off = src_total;
+        it.src_len = it.info.frames * it.info.block_align;
+        src_total = align16(src_total + it.src_len);
+        d.frames = it.info.frames;
+        d.sample_rate = it.info.sample_rate;
+        d.channels = it.info.channels;
+        d.format = planar_format(it.kind);
+        dst_total = align16(dst_total + (size_t)it.info.frames * it.info.channels * rg_bytes_per_sample(d.format));
+    }
+    int rc = rg_bind_device(c);
+    if (rc != RG_OK) return rc;
+    for (int s = 0; s < c->n_slots; ++s) RG_HIP(c, hipStreamSynchronize(c->slots[s].stream));
+    RG_HIP(c, c->d_wav.reserve(src_total ? src_total : 16));
+    RG_HIP(c, c->d_arena.reserve(dst_total ? dst_total : 16));
+    hipStream_t fs = c->user_attached ? c->user_stream : c->slot().stream;
+    for (size_t i = 0; i < n; ++i) {
+        unsigned char *dst = c->d_arena.p + (*descs)[i].offset_bytes;
+        if (in[i].decoded) {
+            const size_t bytes = (size_t)in[i].frames * in[i].channels * sizeof(float);
+            if (bytes) RG_HIP(c, hipMemcpyAsync(dst, in[i].planar.data(), bytes, hipMemcpyHostToDevice, fs));
+            continue;
+        }
+        const WavItem &it = items[i];
+        if (it.src_len == 0) continue;
+        RG_HIP(c, hipMemcpyAsync(c->d_wav.p + it.src_off, it.bytes + it.info.data_offset, it.src_len, hipMemcpyHostToDevice, fs));
+        RG_HIP(c, launch_deinterleave(it.kind, c->d_wav.p + it.src_off, dst, it.info.frames, it.info.channels, fs));
+    }
+    // the host buffers are the caller's locals: the copies must have left them before this returns
+    RG_HIP(c, hipStreamSynchronize(fs));
+    if (!c->user_attached) RG_HIP(c, hipEventRecord(c->user_ev, fs));
+    c->user_dirty = true;
+    *arena_bytes = dst_total;
+    return RG_OK;
+}
+
 bool read_all(FILE *f, std::vector<uint8_t> *out) {
     uint8_t chunk[1 << 16];
     size_t n;
@@ -248,38 +325,98 @@ std::string shell_quote(const char *s) {
     return q + "'";
 }
 
-// bytes of a WAV stream for `path`: the file itself when it is RIFF/WAVE, else the decoder command's stdout
-int load_wav_for(rg_ctx *c, const char *path, std::vector<uint8_t> *out) {
-    if (!path) return rg_set_err(c, RG_ERR_INVALID_ARG, "null path");
+// Load one file (no device work; safe to call from several threads at once as long as `err` is per call).
+// RIFF/WAVE: the bytes; MPEG Layer III: decoded planar f32; anything else: the decoder command's stdout.
+int load_audio_for(const std::string &decoder_cmd, const char *path, LoadedAudio *out, std::string *err) {
+    char msg[1024];
+    auto fail = [&](int code, const char *fmt, const char *a, int b = 0) {
+        snprintf(msg, sizeof msg, fmt, a, b);
+        *err = msg;
+        return code;
+    };
+    if (!path) return fail(RG_ERR_INVALID_ARG, "null path%s", "");
     FILE *f = fopen(path, "rb");
-    if (!f) return rg_set_err(c, RG_ERR_IO, "Failed to open: %s", path);  // src/replaygain.rs:804-805
-    uint8_t head[12];
-    const size_t got = fread(head, 1, sizeof head, f);
-    const bool riff = got == 12 && memcmp(head, "RIFF", 4) == 0 && memcmp(head + 8, "WAVE", 4) == 0;
-    if (riff) {
-        out->assign(head, head + got);
-        const bool ok = read_all(f, out);
-        fclose(f);
-        if (!ok) return rg_set_err(c, RG_ERR_IO, "Failed to read: %s", path);
+    if (!f) return fail(RG_ERR_IO, "Failed to open: %s", path);  // src/replaygain.rs:804-805
+    std::vector<uint8_t> bytes;
+    const bool ok = read_all(f, &bytes);
+    fclose(f);
+    if (!ok) return fail(RG_ERR_IO, "Failed to read: %s", path);
+    if (bytes.size() >= 12 && memcmp(bytes.data(), "RIFF", 4) == 0 && memcmp(bytes.data() + 8, "WAVE", 4) == 0) {
+        out->wav.swap(bytes);
         return RG_OK;
     }
-    fclose(f);
-    if (c->decoder_cmd.empty())  // src/replaygain.rs:815-822: the probe knows no such format
-        return rg_set_err(c, RG_ERR_FORMAT,
-                          "Failed to probe format: %s (not RIFF/WAVE, and no decoder command is set: rg_set_decoder_command)", path);
-    std::string cmd = c->decoder_cmd;
+    const bool mp4 = bytes.size() >= 8 && memcmp(bytes.data() + 4, "ftyp", 4) == 0;
+    if (!mp4) {
+        // the probe (src/replaygain.rs:815-822) and the packet loop (:881-904) for an MPEG audio stream
+        rg_mp3_stream_info si;
+        if (rg_mp3_scan(bytes.data(), bytes.size(), &si) == RG_MP3DEC_OK && si.audio_frames > 0) {
+            out->planar.assign((size_t)si.frames * si.channels, 0.0f);
+            rg_mp3_stream_info di;
+            const int rc = rg_mp3_decode_f32(bytes.data(), bytes.size(), out->planar.data(),
+                                             si.channels == 2 ? out->planar.data() + si.frames : nullptr, si.frames, &di);
+            if (rc != RG_MP3DEC_OK) return fail(RG_ERR_FORMAT, "Failed to decode: %s", path);
+            if (si.channels == 2 && di.frames != si.frames)  // dropped frames shortened the track: close the gap between the planes
+                memmove(out->planar.data() + di.frames, out->planar.data() + si.frames, sizeof(float) * (size_t)di.frames);
+            out->sample_rate = di.sample_rate;
+            out->channels = di.channels;
+            out->frames = di.frames;
+            out->decoded = true;
+            return RG_OK;
+        }
+    }
+    if (decoder_cmd.empty())  // src/replaygain.rs:815-822: the probe knows no such format
+        return fail(RG_ERR_FORMAT, mp4 ? "Failed to probe format: %s (MP4/AAC: no AAC decoder is built; set a decoder command: rg_set_decoder_command)"
+                                       : "Failed to probe format: %s (neither MPEG Layer III nor RIFF/WAVE, and no decoder command is set: rg_set_decoder_command)",
+                    path);
+    std::string cmd = decoder_cmd;
     const std::string q = shell_quote(path);
     size_t at = cmd.find("{}");
     if (at == std::string::npos) cmd += " " + q;
     else
         for (; at != std::string::npos; at = cmd.find("{}", at + q.size())) cmd.replace(at, 2, q);
     FILE *p = popen(cmd.c_str(), "r");
-    if (!p) return rg_set_err(c, RG_ERR_IO, "Failed to run decoder: %s", strerror(errno));
-    out->clear();
-    const bool ok = read_all(p, out);
+    if (!p) return fail(RG_ERR_IO, "Failed to run decoder: %s", strerror(errno));
+    out->wav.clear();
+    const bool rd = read_all(p, &out->wav);
     const int status = pclose(p);
-    if (!ok || status != 0 || out->empty())
-        return rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s (decoder command exited with status %d)", path, status);
+    if (!rd || status != 0 || out->wav.empty())
+        return fail(RG_ERR_FORMAT, "Failed to probe format: %s (decoder command exited with status %d)", path, status);
+    return RG_OK;
+}
+
+int load_one(rg_ctx *c, const char *path, LoadedAudio *out) {
+    std::string err;
+    const int rc = load_audio_for(c->decoder_cmd, path, out, &err);
+    if (rc != RG_OK) return rg_set_err(c, rc, "%s", err.c_str());
+    return RG_OK;
+}
+
+// The files of an album, decoded on the host's cores (decode is by far the longest stage of a real run: one core turns
+// about 200 s of stereo audio into PCM per second, the GPU analyses 8 million).  Errors keep the reference's order: the
+// first failing file in input order is the one reported (src/replaygain.rs:1055).
+int load_many(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedAudio> *out) {
+    out->assign(n, LoadedAudio());
+    std::vector<int> rcs(n, RG_OK);
+    std::vector<std::string> errs(n);
+    unsigned workers = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) workers = (unsigned)CPU_COUNT(&set);
+    if (workers < 1) workers = 1;
+    if (workers > n) workers = (unsigned)n;
+    std::atomic<size_t> next{0};
+    const std::string cmd = c->decoder_cmd;
+    auto work = [&]() {
+        for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) rcs[i] = load_audio_for(cmd, paths[i], &(*out)[i], &errs[i]);
+    };
+    if (workers <= 1) {
+        work();
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned w = 0; w < workers; ++w) pool.emplace_back(work);
+        for (auto &t : pool) t.join();
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (rcs[i] != RG_OK) return rg_set_err(c, rcs[i], "%s", errs[i].c_str());
     return RG_OK;
 }
 
@@ -318,15 +455,17 @@ extern "C" int rg_analyze_wav_batch(rg_ctx *c, const void *const *wav, const siz
 
 extern "C" int rg_analyze_track(rg_ctx *c, const char *path, int32_t track_index, rg_track_result *out) {
     if (!c || !out) return RG_ERR_INVALID_ARG;
-    std::vector<uint8_t> bytes;
-    int rc = load_wav_for(c, path, &bytes);
+    std::vector<LoadedAudio> in(1);
+    int rc = load_one(c, path, &in[0]);
     if (rc != RG_OK) return rc;
     rc = check_track_index(c, track_index);
     if (rc != RG_OK) return rc;
-    const void *p = bytes.data();
-    const size_t len = bytes.size();
-    rc = rg_analyze_wav_batch(c, &p, &len, 1, 0, out, nullptr);
+    std::vector<rg_track_desc> descs;
+    size_t arena_bytes = 0;
+    rc = stage_loaded(c, in, &descs, &arena_bytes);
     if (rc == RG_ERR_FORMAT) return rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s", path);  // src/replaygain.rs:815-822
+    if (rc != RG_OK) return rc;
+    rc = rg_analyze_pcm_batch(c, descs.data(), 1, c->d_arena.p, arena_bytes, 1, out, nullptr);
     if (rc != RG_OK) return rc;
     out->file_type = file_type_of(path);
     return RG_OK;
@@ -336,22 +475,22 @@ extern "C" int rg_analyze_track(rg_ctx *c, const char *path, int32_t track_index
 extern "C" int rg_analyze_album(rg_ctx *c, const char *const *paths, size_t n, int32_t track_index, rg_track_result *tracks_out,
                                 rg_album_result *album_out) {
     if (!c || (n && (!paths || !tracks_out)) || !album_out) return RG_ERR_INVALID_ARG;
-    std::vector<std::vector<uint8_t>> bytes(n);
-    std::vector<const void *> ptrs(n);
-    std::vector<size_t> lens(n);
-    for (size_t i = 0; i < n; ++i) {
-        int rc = load_wav_for(c, paths[i], &bytes[i]);
-        if (rc != RG_OK) return rc;
+    std::vector<LoadedAudio> in;
+    int rc = load_many(c, paths, n, &in);
+    if (rc != RG_OK) return rc;
+    if (n) {
         rc = check_track_index(c, track_index);
         if (rc != RG_OK) return rc;
-        ptrs[i] = bytes[i].data();
-        lens[i] = bytes[i].size();
     }
-    int rc = rg_analyze_wav_batch(c, ptrs.data(), lens.data(), n, 1, tracks_out, album_out);
+    std::vector<rg_track_desc> descs;
+    size_t arena_bytes = 0;
+    rc = stage_loaded(c, in, &descs, &arena_bytes);
     if (rc == RG_ERR_FORMAT) {  // "input i ..." -> the reference's text with the file's name
         size_t i = 0;
         if (sscanf(c->err.c_str(), "input %zu", &i) == 1 && i < n) return rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s", paths[i]);
     }
+    if (rc != RG_OK) return rc;
+    rc = rg_analyze_album_pcm(c, descs.data(), n, c->d_arena.p, arena_bytes, 1, tracks_out, album_out, nullptr);
     if (rc != RG_OK) return rc;
     for (size_t i = 0; i < n; ++i) tracks_out[i].file_type = file_type_of(paths[i]);
     return RG_OK;
@@ -360,14 +499,12 @@ extern "C" int rg_analyze_album(rg_ctx *c, const char *const *paths, size_t n, i
 // find_peak_amplitude (src/replaygain.rs:1140-1249): max |x| over ALL channels, no loudness analysis
 extern "C" int rg_find_peak_amplitude(rg_ctx *c, const char *path, rg_peak_result *out) {
     if (!c || !out) return RG_ERR_INVALID_ARG;
-    std::vector<uint8_t> bytes;
-    int rc = load_wav_for(c, path, &bytes);
+    std::vector<LoadedAudio> in(1);
+    int rc = load_one(c, path, &in[0]);
     if (rc != RG_OK) return rc;
-    const void *p = bytes.data();
-    const size_t len = bytes.size();
     std::vector<rg_track_desc> descs;
     size_t arena_bytes = 0;
-    rc = stage_wavs(c, &p, &len, 1, &descs, &arena_bytes);
+    rc = stage_loaded(c, in, &descs, &arena_bytes);
     if (rc == RG_ERR_FORMAT) return rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s", path);
     if (rc != RG_OK) return rc;
     // the arena was produced on the stream rg_find_peak_pcm uses, so no further ordering is needed

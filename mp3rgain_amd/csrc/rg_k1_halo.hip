@@ -132,9 +132,11 @@ __device__ __forceinline__ double load_input(const void *base, uint64_t i, uint3
 // warms up from zero cannot know about a NaN before its halo: one streaming pass finds the first such frame of
 // every track (channels 0 and 1, the ones that are analysed) before the lanes run.
 __global__ void __launch_bounds__(256) rg_k1_first_nonfinite_kernel(const RgTrackDev *__restrict__ tracks,
-                                                                    unsigned long long *__restrict__ first_bad) {
-    const RgTrackDev tr = tracks[blockIdx.y];
-    if (tr.format != RG_FMT_F32_PLANAR) return;
+                                                                    unsigned long long *__restrict__ first_bad, uint32_t n_tracks) {
+  // gridDim.y is capped at 65535: a block row walks the tracks t, t + gridDim.y, ...
+  for (uint32_t t = blockIdx.y; t < n_tracks; t += gridDim.y) {
+    const RgTrackDev tr = tracks[t];
+    if (tr.format != RG_FMT_F32_PLANAR) continue;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     unsigned long long best = ~0ull;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tr.frames; i += stride) {
@@ -143,6 +145,7 @@ __global__ void __launch_bounds__(256) rg_k1_first_nonfinite_kernel(const RgTrac
         if (!(fabsf(a) <= 3.402823466e38f) || !(fabsf(b) <= 3.402823466e38f)) { best = i; break; }  // ascending per thread
     }
     if (best != ~0ull) atomicMin(&first_bad[tr.track_index], best);
+  }
 }
 
 __global__ void __launch_bounds__(256) rg_k1_halo_kernel(const RgTrackDev *__restrict__ tracks, uint32_t n_tracks,
@@ -245,7 +248,8 @@ extern "C" hipError_t rg_launch_k1_halo(const RgTrackDev *d_tracks, uint32_t n_t
                                         unsigned long long *d_peak_bits, unsigned long long *d_first_bad /* preset to ~0 */,
                                         hipStream_t stream) {
     if (total_items == 0) return hipSuccess;
-    hipLaunchKernelGGL(rg_k1_first_nonfinite_kernel, dim3(512, n_tracks), dim3(256), 0, stream, d_tracks, d_first_bad);
+    hipLaunchKernelGGL(rg_k1_first_nonfinite_kernel, dim3(512, n_tracks < 65535u ? n_tracks : 65535u), dim3(256), 0, stream, d_tracks,
+                       d_first_bad, n_tracks);
     const uint32_t block = 64;  // one wave per workgroup: spreads a small item count over all CUs
     const uint32_t grid = (total_items + block - 1) / block;
     hipLaunchKernelGGL(rg_k1_halo_kernel, dim3(grid), dim3(block), 0, stream, d_tracks, n_tracks, total_items,

@@ -1,7 +1,8 @@
 """Command-line façade on the GPU box: -r, -a, -e, -x and the beets TSV line run the analysis through the C ABI.
-MP3 fixtures (byte copies of the reference's) are paired with a stand-in decoder that emits a known WAV stream,
-so every printed number is checked against the CPU oracle on the same samples, and the gain that -r / -a apply
-to the MP3 is checked in the file's global_gain fields."""
+The MP3 files are the reference's fixtures (byte copies, some with their level moved by the lossless gain patcher so
+that quiet / loud / clipping cases exist); the library decodes them itself (rg_mp3dec.cpp), and every printed number
+is checked against the CPU oracle run on the same decoder's PCM, the applied gain in the file's global_gain fields.
+Only the M4A case still goes through a stand-in decoder command: no AAC decoder is built."""
 import io
 import json
 import math
@@ -31,6 +32,17 @@ sys.stdout.buffer.write(wav_bytes(ch, 44100, 'f32', streamed=True))
 """
 
 
+# level shifts, in 1.5 dB steps, that turn the fixture (a 440 Hz sine at about -21 dBFS) into the named case
+SHIFT = {"quiet.mp3": -12, "loud.mp3": 22}
+
+
+def decoded_mp3(path):
+    from mp3rgain_amd import mp3dec
+
+    pcm, _ = mp3dec.decode(Path(path).read_bytes())
+    return [pcm[c] for c in range(pcm.shape[0])]
+
+
 def decoded(name: str):
     import zlib
 
@@ -52,16 +64,22 @@ def box(tmp_path, _ctx):
         return rc, out.getvalue(), err.getvalue()
 
     def mp3(name, src="test_joint_stereo.mp3"):
+        from mp3rgain_amd import mp3gain
+
         p = tmp_path / name
         shutil.copyfile(FIX / src, p)
+        if name in SHIFT:
+            mp3gain.apply_gain(p, SHIFT[name])
         return p
 
     return run, mp3, tmp_path
 
 
-def want_for(oracle, name):
-    ch = decoded(name)
-    return oracle.analyze_pcm(ch[0], ch[1], 44100)[0], oracle.analyze_pcm(ch[0], ch[1], 44100)[1]
+def want_for(oracle, f):
+    """oracle result for a file: MP3s through the library's decoder, the M4A stand-in through its decoder script"""
+    ch = decoded_mp3(f) if str(f).endswith(".mp3") else decoded(Path(f).name)
+    res, hist = oracle.analyze_pcm(ch[0], ch[1] if len(ch) > 1 else None, 44100)
+    return res, hist
 
 
 def test_track_gain_applies_to_mp3(box, oracle):
@@ -69,9 +87,10 @@ def test_track_gain_applies_to_mp3(box, oracle):
 
     run, mp3, _ = box
     f = mp3("quiet.mp3")
-    w, _ = want_for(oracle, "quiet.mp3")
+    w, _ = want_for(oracle, f)
     steps = w["gain_steps"]
     assert steps > 0
+    b = mp3gain.analyze(f)
     rc, out, err = run("-r", f)
     assert (rc, err) == (0, "")
     assert out == ("mp3rgain Analyzing and applying track gain to 1 file(s)\n  Target: 89 dB (ReplayGain 1.0)\n\n"
@@ -79,11 +98,14 @@ def test_track_gain_applies_to_mp3(box, oracle):
                    f"      Loudness: {w['loudness_db']:.1f} dB, Gain: {w['gain_db']:+.1f} dB ({steps} steps), Peak: {w['peak']:.4f}\n"
                    f"  v quiet.mp3 (40 frames, {steps * 1.5:+.1f} dB)\n")  # src/main.rs:1223-1238, 1956-1969, 2139-2147
     a = mp3gain.analyze(f)
-    assert (a.min_gain, a.max_gain) == (min(110 + steps, 255), min(210 + steps, 255))
+    assert (a.min_gain, a.max_gain) == (min(b.min_gain + steps, 255), min(b.max_gain + steps, 255))
     assert mp3gain.read_ape_tag_value(f, "MP3GAIN_UNDO") == f"{steps:+04d},{steps:+04d},N"
+    # the analysis of the patched file moves by exactly the applied gain (the decoder reads global_gain)
+    w2, _ = want_for(oracle, f)
+    assert abs((w2["loudness_db"] - w["loudness_db"]) - steps * 1.5) <= 0.02
     # undo brings the audio bytes back
     rc, out, _ = run("-u", f)
-    assert "(40 frames restored)" in out and mp3gain.analyze(f).max_gain == 210
+    assert "(40 frames restored)" in out and mp3gain.analyze(f).max_gain == b.max_gain
 
 
 def test_track_gain_modifier_dry_run_json_and_clipping(box, oracle):
@@ -91,12 +113,13 @@ def test_track_gain_modifier_dry_run_json_and_clipping(box, oracle):
 
     run, mp3, _ = box
     f = mp3("quiet.mp3")
-    w, _ = want_for(oracle, "quiet.mp3")
+    w, _ = want_for(oracle, f)
+    b = mp3gain.analyze(f)
     rc, out, _ = run("-n", "-e", "-m", "-2", f)  # -e = track gain only (src/main.rs:527-530)
     s = w["gain_steps"]
     assert f"({s} steps + -2 = {s - 2}), Peak:" in out and "  Gain modifier: -2 steps\n" in out
     assert f"  ~ [DRY RUN] quiet.mp3 (would apply {(s - 2) * 1.5:+.1f} dB, {s - 2} steps)\n" in out
-    assert mp3gain.analyze(f).max_gain == 210
+    assert mp3gain.analyze(f).max_gain == b.max_gain
     rc, out, err = run("-o", "json", "-r", "-n", f)
     d = json.loads(out)
     r = d["files"][0]
@@ -111,10 +134,11 @@ def test_track_gain_modifier_dry_run_json_and_clipping(box, oracle):
     else:
         assert err == ""
     loud = mp3("loud.mp3")
-    wl, _ = want_for(oracle, "loud.mp3")
-    assert wl["gain_steps"] < 0 and wl["peak"] == 1.0
+    wl, _ = want_for(oracle, loud)
+    assert wl["gain_steps"] < 0 and wl["peak"] > 1.0  # a float decode is not clipped: the peak says by how much it would be
+    bl = mp3gain.analyze(loud)
     rc, out, err = run("-r", loud)
-    assert err == "" and mp3gain.analyze(loud).max_gain == 210 + wl["gain_steps"]
+    assert err == "" and mp3gain.analyze(loud).max_gain == bl.max_gain + wl["gain_steps"]
 
 
 def test_album_gain(box, oracle):
@@ -123,7 +147,7 @@ def test_album_gain(box, oracle):
     run, mp3, _ = box
     names = ["one.mp3", "quiet.mp3", "three.mp3"]
     files = [mp3(n, s) for n, s in zip(names, ("test_joint_stereo.mp3", "test_vbr.mp3", "test_joint_stereo.mp3"))]
-    per = [want_for(oracle, n) for n in names]
+    per = [want_for(oracle, f) for f in files]
     alb, _ = oracle.album_from_hists([h for _, h in per], [w["peak"] for w, _ in per])
     steps = round(alb["album_gain_db"] / 1.5)
     before = [mp3gain.analyze(f).max_gain for f in files]
@@ -149,7 +173,7 @@ def test_album_gain(box, oracle):
 def test_beets_tsv_and_max_amplitude(box, oracle):
     run, mp3, tmp = box
     f = mp3("one.mp3")
-    w, _ = want_for(oracle, "one.mp3")
+    w, _ = want_for(oracle, f)
     rc, out, err = run("-o", "-s", "s", "-k", "-d", "0", f)  # what beets runs
     assert (rc, err) == (0, "")
     lines = out.splitlines()
@@ -189,7 +213,7 @@ def test_m4a_gets_tags_only(box, oracle):
     f = tmp / "quiet.m4a"
     data, _ = make_mp4()
     f.write_bytes(data)
-    w, _ = want_for(oracle, "quiet.m4a")
+    w, _ = want_for(oracle, f)
     rc, out, err = run("-r", "-c", f)
     assert (rc, err) == (0, "")
     assert out.endswith(f"  v quiet.m4a (tags written, {w['gain_db']:+.1f} dB)\n")  # src/main.rs:2204-2212
