@@ -149,6 +149,7 @@ def main() -> int:
                     help="weak: --tracks-per-rank on every GPU; strong: --total-tracks sharded over the GPUs by cumulative frames")
     ap.add_argument("--total-tracks", type=int, default=0, help="album size for --scaling strong (default: --tracks-per-rank)")
     ap.add_argument("--tm-segment", type=int, default=0, help="force variant 2 segment length (tuning)")
+    ap.add_argument("--tm-windows", type=int, default=0, help="most windows per lane of variant 2 (tuning; 0 = library default, 1 = one)")
     ap.add_argument("--slots", type=int, default=0, help="pipeline slots of the library (0 = default)")
     ap.add_argument("--mixed", action="store_true",
                     help="BASELINE configs[4]'s PCM side instead: half the tracks at 44.1 kHz, half at 48 kHz, every 10th mono, "
@@ -203,6 +204,8 @@ def main() -> int:
         an.set_tuning(1, args.tm_segment)
     if args.slots:
         an.set_tuning(3, args.slots)
+    if args.tm_windows:
+        an.set_tuning(4, args.tm_windows)
     # No caller stream is attached: every batch, its album tail and the collective in between run on the
     # context's own pipeline streams (rg_batch_stream), which costs no cross-stream event per step.
 

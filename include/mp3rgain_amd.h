@@ -171,7 +171,9 @@ int rg_set_kernel(rg_ctx *ctx, int variant);
  * the 50 ms window), key 2 = number of segments (lanes) variant 2 aims for when it picks one,
  * key 3 = number of pipeline slots (1..8, default 8): buffer sets that consecutive enqueues rotate through, spread
  * over min(slots, 4) HIP streams so that batches overlap on the GPU; rg_collect / rg_album_finish always refer to
- * the most recent enqueue */
+ * the most recent enqueue,
+ * key 4 = most windows one lane of variant 2 may run in a row (multi-window segments; 0 = chosen from the batch size, up
+ * to 16; 1 = never more than one) */
 int rg_set_tuning(rg_ctx *ctx, int key, int64_t value);
 /* diagnostic (host only): variant 2's design for one rate and segment length.  T_out: [L][12],
  * gram_last_out: [78]; either may be NULL.  RG_ERR_INVALID_ARG when no design exists. */

@@ -229,6 +229,7 @@ extern "C" void rg_destroy(rg_ctx *c) {
         S.d_desc.release();
         S.h_desc.release();
         S.d_tm_rec.release();
+        S.d_tm_win.release();
         S.d_hist.release();
         S.d_nonfinite.release();
         S.d_imprecise.release();
@@ -286,6 +287,7 @@ extern "C" int rg_set_tuning(rg_ctx *c, int key, int64_t value) {
     switch (key) {
         case RG_TUNE_TM_SEGMENT: c->tune_tm_segment = (uint32_t)value; return RG_OK;
         case RG_TUNE_TM_TARGET_LANES: c->tune_tm_target_lanes = (uint64_t)value; return RG_OK;
+        case RG_TUNE_TM_WINDOWS: c->tune_tm_windows = (uint32_t)(value > 255 ? 255 : value); return RG_OK;
         case RG_TUNE_PIPELINE_SLOTS: {
             if (sync_all(c) != RG_OK) return RG_ERR_DEVICE;
             c->n_slots = value == 0 ? RG_DEFAULT_SLOTS : (value > RG_MAX_SLOTS ? RG_MAX_SLOTS : (int)value);

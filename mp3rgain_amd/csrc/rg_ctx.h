@@ -62,7 +62,7 @@ struct RgTmDeviceTables {
     RgTmFixTables fix{};
 };
 
-enum { RG_TUNE_TM_SEGMENT = 1, RG_TUNE_TM_TARGET_LANES = 2, RG_TUNE_PIPELINE_SLOTS = 3 };
+enum { RG_TUNE_TM_SEGMENT = 1, RG_TUNE_TM_TARGET_LANES = 2, RG_TUNE_PIPELINE_SLOTS = 3, RG_TUNE_TM_WINDOWS = 4 };
 
 #define RG_MAX_SLOTS 8
 #define RG_SLOT_STREAMS 4   // HIP streams the slots are spread over (the runtime has 4 hardware queues by default)
@@ -85,6 +85,7 @@ struct RgSlot {
     PinnedBuf<unsigned char> h_desc;
     std::vector<unsigned char> desc_shadow;  // what d_desc currently holds
     DevBuf<double> d_tm_rec;                 // segment records (rg_tm.h)
+    DevBuf<double> d_tm_win;                 // per-window energies of multi-window segments: [channels][windows of the group]
     DevBuf<uint32_t> d_hist;                 // [hist n*12000 | peak n*2 | done n] words
     DevBuf<unsigned long long> d_k1_bad;     // variant 1: first non-finite frame per track (~0 = none), set per batch
     DevBuf<uint32_t> d_imprecise;            // per track: set by fix-up blocks that saw a cancelled window, cleared by the finisher
@@ -109,6 +110,7 @@ struct rg_ctx {
     std::string err;
     int kernel_variant = 0;      // 0 auto (= 2), 1 halo/reference-order kernel, 2 transient-moment kernels
     uint32_t tune_tm_segment = 0;          // 0 = choose from the workload
+    uint32_t tune_tm_windows = 0;          // windows per segment: 0 = choose from the workload, 1 = never more than one
     uint64_t tune_tm_target_lanes = 0;     // 0 = cost model
     int n_slots = RG_DEFAULT_SLOTS;
 
@@ -124,7 +126,7 @@ struct rg_ctx {
 
     RgRateDesign design[RG_NUM_RATES];
     DevBuf<RgCoefDev> d_coefs;
-    std::map<uint32_t, RgTmDeviceTables *> tm_tables;  // key = rate_idx << 16 | L, shared by all slots (read only)
+    std::map<uint32_t, RgTmDeviceTables *> tm_tables;  // key = rate_idx << 24 | m << 16 | L, shared by all slots (read only)
 
     // host scratch for building one batch's descriptors
     std::vector<RgTrackDev> h_tracks, h_k1_tracks;

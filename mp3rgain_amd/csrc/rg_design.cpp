@@ -131,10 +131,11 @@ ld maxabs(const ld *A, int n) {
 
 }  // namespace
 
-void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out) {
+void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out, uint32_t m) {
     *out = RgTmDesign();
     const uint32_t W = (uint32_t)(((uint64_t)rc.sample_rate * 50u) / 1000u);
-    if (L == 0 || W % L != 0) return;
+    if (L == 0 || W % L != 0 || m == 0 || (m > 1 && L != W)) return;
+    out->m = m;
     RgRateDesign rd;
     rg_design_rate(rc, &rd);
     if (!rd.stable) return;
@@ -242,7 +243,11 @@ void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out) {
     ld PY[100], PB[4];
     for (int i = 0; i < 100; ++i) PY[i] = (i / 10 == i % 10) ? 1.0L : 0.0L;
     PB[0] = PB[3] = 1.0L; PB[1] = PB[2] = 0.0L;
-    for (uint32_t n = 0; n < L; ++n) { matmul_ld(10, PY, Fy, PY); matmul_ld(2, PB, Fb, PB); }
+    for (uint64_t n = 0; n < (uint64_t)L * m; ++n) {  // one segment = L * m frames
+        matmul_ld(10, PY, Fy, PY);
+        matmul_ld(2, PB, Fb, PB);
+        if (maxabs(PY, 100) < 1e-40L && maxabs(PB, 4) < 1e-40L) break;  // nothing left to multiply (and no denormal crawl)
+    }
     uint32_t rounds = 0, rounds_fast = 0;
     bool fast_done = false;
     for (int r = 0; r <= RG_TM_MAX_ROUNDS; ++r) {

@@ -20,7 +20,7 @@ void rg_design_rate(const rg_rate_coeffs &rc, RgRateDesign *out);
 #include <vector>
 
 struct RgTmDesign {
-    uint32_t L = 0, W = 0;
+    uint32_t L = 0, W = 0, m = 1;
     uint32_t H10 = 0;         // multiple of 4, <= L rounded down to a multiple of 4 (or == that bound)
     uint32_t rounds = 0;      // doubling rounds for the slow (Butter) block
     uint32_t rounds_fast = 0; // rounds after which the fast (Yule) block's power is below 1e-18
@@ -34,6 +34,7 @@ struct RgTmDesign {
     bool ok = false;
 };
 
-// L must divide W = rate*50/1000.  Returns ok=false for an unstable row or when no truncation
+// L must divide W = rate*50/1000; m = windows per segment (m > 1 needs L == W): the segment stride is L * m frames,
+// which is what the state transition Phi spans.  Returns ok=false for an unstable row or when no truncation
 // with <= RG_TM_MAX_ROUNDS doubling rounds reaches 1e-18.
-void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out);
+void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out, uint32_t m = 1);

@@ -25,10 +25,10 @@ hipError_t rg_launch_track_results(const uint32_t *, const unsigned long long *,
 hipError_t rg_launch_album_merge(const uint32_t *, const unsigned long long *, uint32_t, uint32_t *, double *,
                                  hipStream_t);
 hipError_t rg_launch_tm_main(int fmt, int nch, const RgTmCoef *, const RgTmGeom *, const RgTmTrack *, uint32_t, uint32_t,
-                             double *, uint32_t, uint32_t *, uint32_t *, uint64_t, hipStream_t);
+                             double *, uint32_t, double *, uint32_t, uint32_t *, uint32_t *, uint64_t, hipStream_t);
 hipError_t rg_launch_tm_fix(int nch, const RgTmGeom *, const RgTmFixTables *, const RgTmTrack *, uint32_t, uint32_t,
-                            const double *, uint32_t, uint32_t *, uint32_t *, uint32_t *, unsigned long long *, uint32_t *,
-                            rg_track_result *, hipStream_t);
+                            const double *, uint32_t, const double *, uint32_t, uint32_t *, uint32_t *, uint32_t *,
+                            unsigned long long *, uint32_t *, rg_track_result *, hipStream_t);
 }
 
 namespace {
@@ -110,15 +110,15 @@ int finish_k1_list(rg_ctx *c, RgTrackDev *list, size_t n, uint32_t *total_items)
 }
 
 // ---- variant 2 tables --------------------------------------------------------------------------
-int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out) {
-    const uint32_t key = ((uint32_t)rate_idx << 16) | L;
+int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out, uint32_t m = 1) {
+    const uint32_t key = ((uint32_t)rate_idx << 24) | (m << 16) | L;
     auto it = c->tm_tables.find(key);
     if (it != c->tm_tables.end()) {
         *out = it->second;
         return it->second->design.ok ? RG_OK : RG_ERR_INVALID_ARG;
     }
     RgTmDeviceTables *tb = new RgTmDeviceTables();
-    rg_tm_design(RG_RATE_TABLE[rate_idx], L, &tb->design);
+    rg_tm_design(RG_RATE_TABLE[rate_idx], L, &tb->design, m);
     c->tm_tables[key] = tb;
     *out = tb;
     const RgTmDesign &D = tb->design;
@@ -151,7 +151,11 @@ int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out) {
     g.warm = 1u << D.rounds;
     g.fix_windows = (RG_TM_BLOCK - g.warm) / g.k;
     g.block = rg_tm_choose_block(D.L, D.H10);
-    g.pad_ = 0;
+    g.m = m;
+    if (m > 1 && rg_tm_lds_bytes(D.L, D.H10, g.block) > RG_TM_LDS_BYTES) {  // multi-window segments run on the LDS path only
+        tb->design.ok = false;
+        return RG_ERR_INVALID_ARG;
+    }
     g.T = tb->d_blob + oT;
     g.Tlds = tb->d_blob + oL;
     tb->fix.Gp = tb->d_blob + oG;
@@ -177,20 +181,32 @@ int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out) {
 // Consecutive batches overlap across the context's pipeline slots, so `waves` counts n_slots batches.
 int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, RgTmDeviceTables **out) {
     const uint32_t W = rg_window_samples(RG_RATE_TABLE[g.rate_idx].sample_rate);
-    if (c->tune_tm_segment && W % c->tune_tm_segment == 0 &&
-        get_tm_tables(c, g.rate_idx, c->tune_tm_segment, out) == RG_OK)
-        return RG_OK;
-    std::vector<uint32_t> cand;
+    if (c->tune_tm_segment && W % c->tune_tm_segment == 0) {
+        const uint32_t m = c->tune_tm_segment == W && c->tune_tm_windows > 1 ? c->tune_tm_windows : 1;
+        if (get_tm_tables(c, g.rate_idx, c->tune_tm_segment, out, m) == RG_OK) return RG_OK;
+    }
+    // candidates: (L, 1) for every divisor L of the window, and (W, m) -- a lane runs m whole windows and pays for the
+    // transient moments in the first one only (rg_tm.h)
+    struct Cand { uint32_t L, m; };
+    std::vector<Cand> cand;
     for (uint32_t d = 1; d <= W; ++d)
-        if (W % d == 0 && (d >= kMinSegment || d == W)) cand.push_back(d);
-    if (c->tune_tm_target_lanes) {  // explicit lane target: largest L reaching it, else the smallest L
-        for (size_t i = cand.size(); i-- > 0;) {
-            uint64_t lanes = 0;
-            for (uint32_t id : g.ids) lanes += (tracks[id].frames + cand[i] - 1) / cand[i];
-            if (lanes >= c->tune_tm_target_lanes && get_tm_tables(c, g.rate_idx, cand[i], out) == RG_OK) return RG_OK;
-        }
+        if (W % d == 0 && (d >= kMinSegment || d == W)) cand.push_back(Cand{d, 1});
+    if (c->tune_tm_windows != 1) {
+        static const uint32_t ms[] = {2, 3, 4, 6, 8, 12, 16};
+        for (uint32_t m : ms)
+            if (c->tune_tm_windows == 0 || m <= c->tune_tm_windows) cand.push_back(Cand{W, m});
+    }
+    auto lanes_of = [&](const Cand &q) {
+        uint64_t lanes = 0;
+        const uint64_t stride = (uint64_t)q.L * q.m;
+        for (uint32_t id : g.ids) lanes += (tracks[id].frames + stride - 1) / stride;
+        return lanes;
+    };
+    if (c->tune_tm_target_lanes) {  // explicit lane target: the longest segment reaching it, else the shortest
+        for (size_t i = cand.size(); i-- > 0;)
+            if (lanes_of(cand[i]) >= c->tune_tm_target_lanes && get_tm_tables(c, g.rate_idx, cand[i].L, out, cand[i].m) == RG_OK) return RG_OK;
         for (size_t i = 0; i < cand.size(); ++i)
-            if (get_tm_tables(c, g.rate_idx, cand[i], out) == RG_OK) return RG_OK;
+            if (get_tm_tables(c, g.rate_idx, cand[i].L, out, cand[i].m) == RG_OK) return RG_OK;
         return rg_set_err(c, RG_ERR_INVALID_ARG, "no admissible segment length for %u Hz",
                           RG_RATE_TABLE[g.rate_idx].sample_rate);
     }
@@ -198,22 +214,31 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
     RgTmDeviceTables *full = nullptr;
     uint32_t H10 = W;
     if (get_tm_tables(c, g.rate_idx, W, &full) == RG_OK) H10 = full->design.H10;
+    // Cost model.  Per lane: 28 VALU slots per frame (27 FMA + convert), + 2 per frame of the first window (slow pair of
+    // moments), + 10 for its first H10 frames (fast block), + a fixed part (prologue, record, the fix-up kernel's share:
+    // one 208-byte record per channel read back plus ~400 FMAs; measured 2.4 ms per 10.8 M segments beside 24 ms of main)
+    //   waves(L, m) = sum over tracks and channels of ceil(nseg / block) * block / 64
+    //   time        ~ ceil(waves / 1024) * cost   when everything is resident at once,
+    //                 (waves / 1024 + 1) * cost   otherwise (many rounds, one extra for the ragged tail)
+    // Consecutive batches overlap across the context's pipeline slots, so `waves` counts the batches in flight.
     double best = 1e300;
-    uint32_t bestL = 0;
-    for (uint32_t L : cand) {
+    size_t best_i = 0;
+    std::vector<double> score(cand.size(), 1e300);
+    for (size_t i = 0; i < cand.size(); ++i) {
+        const uint32_t L = cand[i].L, m = cand[i].m;
         const uint32_t Hl = H10 >= L ? L : H10;
         const uint32_t block = rg_tm_choose_block(L, Hl);
+        const uint64_t stride = (uint64_t)L * m;
         double waves = 0;
         for (uint32_t id : g.ids) {
-            const uint64_t nseg = (tracks[id].frames + L - 1) / L;
+            const uint64_t nseg = (tracks[id].frames + stride - 1) / stride;
             waves += (double)((nseg + block - 1) / block) * (block / 64) * g.nch;
         }
         waves *= c->n_slots < RG_SLOT_STREAMS ? c->n_slots : RG_SLOT_STREAMS;  // batches in flight = streams
-        // per segment: the main kernel's prologue/record write, and the fix-up kernel's share (one 208-byte
-        // record per channel read back plus ~400 FMAs; measured 2.4 ms per 10.8 M segments beside 24 ms of main)
-        const double cost = (double)L * 30.0 + (double)std::min(L, H10) * 10.0 + 1500.0 + 1500.0;
+        const double cost = (double)stride * 28.0 + (double)L * 2.0 + (double)std::min(L, H10) * 10.0 + 1500.0 + 1500.0 + 60.0 * (m - 1);
         // residency: the LDS image of the response tables + one 4 KiB tile per wave bound the blocks per CU
         const double lds = (double)rg_tm_lds_bytes(L, Hl, block);
+        if (m > 1 && lds > (double)RG_TM_LDS_BYTES) continue;
         // waves per SIMD that can be resident: three narrow blocks, or one wide block, per CU
         const double blocks_cu = block == RG_TM_BLOCK ? std::max(1.0, std::min(3.0, floor((double)RG_TM_LDS_BYTES / lds))) : 3.0;
         const double cap = 1024.0 * blocks_cu;
@@ -222,16 +247,17 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
         const double wps = std::min(blocks_cu, std::max(1.0, waves / 1024.0));
         const double eff = wps >= 3.0 ? 1.0 : (wps >= 2.0 ? 1.09 + (3.0 - wps) * 0.0 : 1.28 - (wps - 1.0) * 0.19);
         // tables that do not fit a CU's LDS (160 KiB) send the whole launch down the generic path
-        const double tm = rounds * cost * eff * (lds > (double)RG_TM_LDS_BYTES ? 8.0 : 1.0);
-        if (tm < best) { best = tm; bestL = L; }
+        // rounds * cost covers every lane of the batch whatever the segment stride is, so candidates compare on it directly
+        score[i] = rounds * cost * eff * (lds > (double)RG_TM_LDS_BYTES ? 8.0 : 1.0);
+        if (score[i] < best) { best = score[i]; best_i = i; }
     }
-    // walk outwards from the best candidate until one designs (tiny L can need too many scan rounds)
-    std::sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) {
-        const uint32_t da = a > bestL ? a - bestL : bestL - a, db = b > bestL ? b - bestL : bestL - b;
-        return da < db;
-    });
-    for (uint32_t L : cand)
-        if (get_tm_tables(c, g.rate_idx, L, out) == RG_OK) return RG_OK;
+    // try the candidates from the best score on (tiny L can need too many scan rounds)
+    std::vector<size_t> order(cand.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return score[a] < score[b]; });
+    (void)best_i;
+    for (size_t i : order)
+        if (get_tm_tables(c, g.rate_idx, cand[i].L, out, cand[i].m) == RG_OK) return RG_OK;
     return rg_set_err(c, RG_ERR_INVALID_ARG, "no admissible segment length for %u Hz",
                       RG_RATE_TABLE[g.rate_idx].sample_rate);
 }
@@ -354,12 +380,12 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
         RgTmDeviceTables *tb;
         RgTmCoef K;
         size_t list_off, list_n;
-        uint32_t main_grid, fix_grid, total_recs;
+        uint32_t main_grid, fix_grid, total_recs, total_windows;
         int fmt, nch;
     };
     std::vector<GroupLaunch> launches;
     size_t tm_off = 0;
-    size_t max_rec_doubles = 0;
+    size_t max_rec_doubles = 0, max_win_doubles = 0;
     for (const TmGroup &g : groups) {
         GroupLaunch gl{};
         rc = choose_tm_tables(c, g, tracks, &gl.tb);
@@ -376,7 +402,8 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
         gl.nch = g.nch;
         gl.list_off = tm_off;
         gl.list_n = g.ids.size();
-        uint64_t recs = 0, mb = 0, fb = 0;
+        uint64_t recs = 0, mb = 0, fb = 0, wins = 0;
+        const uint64_t seg_stride = (uint64_t)geo.L * geo.m;
         const uint32_t NB = geo.fix_windows * geo.k;
         const uint32_t geom_block = geo.block;
         for (uint32_t id : g.ids) {
@@ -385,7 +412,7 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
             o.ch0 = cd.ch0;
             o.ch1 = cd.ch1;
             o.frames = cd.frames;
-            o.nseg = (uint32_t)((cd.frames + geo.L - 1) / geo.L);
+            o.nseg = (uint32_t)((cd.frames + seg_stride - 1) / seg_stride);
             o.n_windows = cd.n_windows;
             o.rec_base = (uint32_t)recs;
             o.main_block_base = (uint32_t)mb;
@@ -394,7 +421,8 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
             o.fix_blocks = (o.nseg + NB - 1) / NB;
             o.sample_rate = cd.sample_rate;
             o.file_type = cd.file_type;
-            o.pad_ = 0;
+            o.win_base = (uint32_t)wins;
+            wins += cd.n_windows;
             if (o.fix_blocks == 0) {  // empty track: no block will finish it, the result kernel does
                 c->h_k1_tracks[n_k1] = cd;
                 c->h_k1_tracks[n_k1].n_segments = 0;
@@ -404,16 +432,19 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
             recs += o.nseg;
             mb += (o.nseg + geom_block - 1) / geom_block;
             fb += (o.nseg + NB - 1) / NB;
-            if (recs > 0x7FFFFFFFull || mb > 0x7FFFFFFFull || fb > 0x7FFFFFFFull)
+            if (recs > 0x7FFFFFFFull || mb > 0x7FFFFFFFull || fb > 0x7FFFFFFFull || wins > 0x7FFFFFFFull)
                 return rg_set_err(c, RG_ERR_INVALID_ARG, "batch too large");
         }
         gl.total_recs = (uint32_t)recs;
+        gl.total_windows = (uint32_t)wins;
+        if (geo.m > 1) max_win_doubles = std::max(max_win_doubles, (size_t)wins * g.nch);
         gl.main_grid = (uint32_t)mb;
         gl.fix_grid = (uint32_t)fb;
         max_rec_doubles = std::max(max_rec_doubles, (size_t)recs * RG_TM_REC * g.nch);
         launches.push_back(gl);
     }
     RG_HIP(c, S.d_tm_rec.reserve(max_rec_doubles ? max_rec_doubles : 1));
+    if (max_win_doubles) RG_HIP(c, S.d_tm_win.reserve(max_win_doubles));
 
     S.n_enqueued = n;
     S.album_ready = false;
@@ -457,13 +488,13 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
             rc = timing_begin(c, &e1);
             if (rc != RG_OK) return rc;
             RG_HIP(c, rg_launch_tm_main(gl.fmt, gl.nch, &gl.K, &gl.tb->geom, d_tm_tracks + gl.list_off,
-                                        (uint32_t)gl.list_n, gl.main_grid, S.d_tm_rec.p, gl.total_recs, S.d_nonfinite.p,
-                                        cleared ? nullptr : S.d_hist.p, (uint64_t)acc_words, s));
+                                        (uint32_t)gl.list_n, gl.main_grid, S.d_tm_rec.p, gl.total_recs, S.d_tm_win.p,
+                                        gl.total_windows, S.d_nonfinite.p, cleared ? nullptr : S.d_hist.p, (uint64_t)acc_words, s));
             if (gl.main_grid != 0) cleared = true;
             if (e1) RG_HIP(c, hipEventRecord(e1, s));
             RG_HIP(c, rg_launch_tm_fix(gl.nch, &gl.tb->geom, &gl.tb->fix, d_tm_tracks + gl.list_off,
-                                       (uint32_t)gl.list_n, gl.fix_grid, S.d_tm_rec.p, gl.total_recs, S.d_nonfinite.p,
-                                       S.d_imprecise.p, S.d_hist.p, S.peak_ptr, done_ptr, S.d_results.p, s));
+                                       (uint32_t)gl.list_n, gl.fix_grid, S.d_tm_rec.p, gl.total_recs, S.d_tm_win.p,
+                                       gl.total_windows, S.d_nonfinite.p, S.d_imprecise.p, S.d_hist.p, S.peak_ptr, done_ptr, S.d_results.p, s));
         }
         if (n_k1) {
             RG_HIP(c, S.d_k1_bad.reserve(n));

@@ -151,7 +151,8 @@ typedef short __attribute__((ext_vector_type(4), aligned(2))) rg_s16x4u;     // 
 //   G4  t_0, t_1, A, B_j                                   (need z, issued 10 slots earlier)
 template <int FMT, int NX, bool MASK>
 __device__ __forceinline__ void tm_frame(TmLane<1> &st, const uint32_t wbits, typename Fmt<FMT>::peak_t &pk,
-                                         const double (&tr)[NX], const RgTmCoef &K, const uint32_t n, const uint32_t len) {
+                                         const double *__restrict__ tr /* NX values; unused when NX == 0 */, const RgTmCoef &K,
+                                         const uint32_t n, const uint32_t len) {
     double (&s)[10] = st.s[0];
     double (&t)[2] = st.t[0];
     const double x = Fmt<FMT>::cvt_word(wbits, pk);  // also tracks the peak; frames past the end were staged as zeros
@@ -194,11 +195,16 @@ __device__ __forceinline__ void tm_load_row(double (&dst)[NX], const double *__r
 // Per wave, no block barrier: the global loads of tile t+1 are issued when tile t has just been
 // written to the wave's LDS tile and stay in flight during tile t's arithmetic; inside a tile the
 // next 4-frame piece is read from LDS while the current one computes.
-template <int FMT, bool TAIL>
+//
+// MOM = the transient moments B are accumulated (the first window of a segment); without it the tile loop is the
+// cascade and the energy alone (windows 2..m of a multi-window segment: no table reads at all).
+// A row is L frames; row r of the wave starts at frame (wave_seg0 + r) * seg_stride + row_off of the channel.
+template <int FMT, bool TAIL, bool MOM>
 __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::peak_t &pk, const RgTmCoef &K, const uint32_t L,
                                              const uint32_t H,
                                              const __attribute__((address_space(1))) typename Fmt<FMT>::elem *chp,
-                                             const uint64_t frames, const uint32_t wave_seg0, const uint32_t len,
+                                             const uint64_t frames, const uint32_t wave_seg0, const uint64_t seg_stride,
+                                             const uint64_t row_off, const uint32_t len,
                                              const double *__restrict__ T12, const double *__restrict__ T2,
                                              char *const wtile /* RG_TM_WAVE_TILE_BYTES */) {
     typedef Fmt<FMT> F;
@@ -212,7 +218,7 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
     for (int q = 0; q < 4; ++q) {
         const int row = 16 * q + lrow;
         const int piece = lslot ^ ((row >> 2) & 3);
-        const uint64_t row0 = (uint64_t)(wave_seg0 + row) * L;
+        const uint64_t row0 = (uint64_t)(wave_seg0 + row) * seg_stride + row_off;
         lfirst[q] = row0 + 4u * piece;
         llen[q] = L;
         if (TAIL) llen[q] = row0 >= frames ? 0u : (frames - row0 < L ? (uint32_t)(frames - row0) : L);
@@ -265,7 +271,8 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
     auto read_piece = [&](int p) -> uint4 { return *reinterpret_cast<const uint4 *>(rrow + 16 * (p ^ rswz)); };
 
     // One tile.  MODE 1: every piece of the tile lies below H (all 12 moments live); MODE 2: every piece lies at or
-    // past H (slow pair only); MODE 0: decided per piece (the one tile H falls into, and the last tile of a row).
+    // past H (slow pair only); MODE 0: decided per piece (the one tile H falls into, and the last tile of a row);
+    // MODE 3: no moments, whole tile; MODE 4: no moments, the ragged last tile.
     // Whole-tile modes keep the piece loop on a single path: with both frame bodies behind a branch inside one
     // loop the register allocator reconciles the rotated filter state with 15 v_mov_b64 per piece on one of them.
     auto run_tile = [&](const uint32_t tile, auto mode) {
@@ -273,11 +280,14 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
         store_tile();                                // tile `tile` -> LDS (every read of the previous tile is behind us)
         if (tile + 1 < ntiles) load_tile(tile + 1);  // in flight during this tile's arithmetic
         const uint32_t n0 = tile * RG_TM_TILE;
-        const int np = MODE != 0 ? 4 : (L - n0 >= RG_TM_TILE ? 4 : (int)((L - n0) >> 2));  // full 4-frame pieces in this tile
+        const int np = (MODE != 0 && MODE != 4) ? 4 : (L - n0 >= RG_TM_TILE ? 4 : (int)((L - n0) >> 2));  // full 4-frame pieces in this tile
         auto piece = [&](const int p, const uint4 v) {
             const uint32_t f[4] = {v.x, v.y, v.z, v.w};
             const uint32_t n = n0 + 4u * p;
-            if (MODE == 1 || (MODE == 0 && n < H)) {  // all 12 transient moments live (H is a multiple of 4, or the whole segment)
+            if (MODE == 3 || MODE == 4) {  // cascade and energy only
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tm_frame<FMT, 0, TAIL>(st, f[u], pk, nullptr, K, n + u, len);
+            } else if (MODE == 1 || (MODE == 0 && n < H)) {  // all 12 transient moments live (H is a multiple of 4, or the whole segment)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     double row[12];
@@ -295,7 +305,7 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
                 }
             }
         };
-        if constexpr (MODE != 0) {
+        if constexpr (MODE != 0 && MODE != 4) {
             // whole-tile modes: the four pieces are unrolled (no loop counter, no copy of the prefetched piece)
             uint4 v[4];
             v[0] = read_piece(0);
@@ -314,12 +324,14 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
                 v = vn;
             }
         }
-        if (MODE == 0 && tile + 1 == ntiles) {
+        if ((MODE == 0 || MODE == 4) && tile + 1 == ntiles) {
             // L & 3 trailing frames, in this (the last) tile
             for (uint32_t n = L & ~3u; n < L; ++n) {
                 const uint32_t o = n - n0;
                 const uint32_t f = *reinterpret_cast<const uint32_t *>(rrow + 16 * ((int)(o >> 2) ^ rswz) + 4 * (o & 3));
-                if (n < H) {
+                if (MODE == 4) {
+                    tm_frame<FMT, 0, TAIL>(st, f, pk, nullptr, K, n, len);
+                } else if (n < H) {
                     double row[12];
                     tm_load_row<12>(row, T12 + (size_t)n * 12);
                     tm_frame<FMT, 12, TAIL>(st, f, pk, row, K, n, len);
@@ -333,21 +345,31 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
     typedef std::integral_constant<int, 0> Mixed;
     typedef std::integral_constant<int, 1> All12;
     typedef std::integral_constant<int, 2> All2;
+    typedef std::integral_constant<int, 3> None;
+    typedef std::integral_constant<int, 4> NoneRagged;
 
     load_tile(0);
     const uint32_t full_tiles = L / RG_TM_TILE;                         // tiles with four whole pieces
-    const uint32_t t12 = (H / RG_TM_TILE) < full_tiles ? H / RG_TM_TILE : full_tiles;  // tiles entirely below H
     uint32_t tile = 0;
+    if constexpr (!MOM) {
+        for (; tile < full_tiles; ++tile) run_tile(tile, None{});
+        for (; tile < ntiles; ++tile) run_tile(tile, NoneRagged{});
+        return;
+    }
+    const uint32_t t12 = (H / RG_TM_TILE) < full_tiles ? H / RG_TM_TILE : full_tiles;  // tiles entirely below H
     for (; tile < t12; ++tile) run_tile(tile, All12{});
     if (tile < ntiles && (tile * RG_TM_TILE < H || tile >= full_tiles)) { run_tile(tile, Mixed{}); ++tile; }  // the tile H falls into
     for (; tile < full_tiles; ++tile) run_tile(tile, All2{});
     for (; tile < ntiles; ++tile) run_tile(tile, Mixed{});              // the ragged last tile
 }
 
-template <int FMT>
+// MULTI = multi-window segments (G.m > 1); a separate instantiation, so that the one-window kernel's register
+// allocation is not disturbed by the window loop
+template <int FMT, bool MULTI>
 __global__ void __launch_bounds__(RG_TM_BLOCK_WIDE)
 rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restrict__ tracks, uint32_t n_tracks,
-                  double *__restrict__ rec, uint32_t total_recs, uint32_t *__restrict__ nonfinite, uint32_t lds_tables,
+                  double *__restrict__ rec, uint32_t total_recs, double *__restrict__ win_energy /* [channels][total_windows], m > 1 */,
+                  uint32_t total_windows, uint32_t *__restrict__ nonfinite, uint32_t lds_tables,
                   uint32_t *__restrict__ zero_words, uint64_t zero_count /* batch accumulators to clear, or nullptr */,
                   unsigned long long *__restrict__ dbg /* nullptr, or 6 words per wave: start, end, hw id, path, cycle counter start, end */) {
     typedef Fmt<FMT> F;
@@ -370,9 +392,11 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
     const uint32_t seg = (blockIdx.x - tr.main_block_base) * blockDim.x + threadIdx.x;
     const uint32_t L = G.L;
     const uint32_t H = G.H10;
+    const uint32_t m = MULTI ? G.m : 1u;            // windows per segment (L == W when m > 1)
+    const uint64_t seg_stride = (uint64_t)L * m;
     const bool active = seg < tr.nseg;
-    const uint64_t start = (uint64_t)seg * L;
-    uint32_t len = 0;
+    const uint64_t start = (uint64_t)seg * seg_stride;
+    uint32_t len = 0;                               // valid frames of the first window (the moment zone)
     if (active) {
         const uint64_t rem = tr.frames - start;
         len = rem < L ? (uint32_t)rem : L;
@@ -388,6 +412,16 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
 #pragma unroll
     for (int j = 0; j < RG_TM_DIM; ++j) st.B[0][j] = 0.0;
     typename F::peak_t pk = 0;
+    // segment record, structure-of-arrays: field f of channel c at ((c*RG_TM_REC + f) * total_recs + idx)
+    // (the address is formed where it is used: a pointer held across the frame loops costs two VGPRs there)
+    auto rec_ptr = [&]() -> double * { return rec + (size_t)chan * RG_TM_REC * total_recs + ((size_t)tr.rec_base + (active ? seg : 0)); };
+    // A sample that is not finite (NaN / Inf in float PCM) leaves the reference's filter state NaN for the rest of
+    // the track (src/replaygain.rs:586-616 has no reset): remember the first unit (segment, or window of a multi-window
+    // segment) it happens in; every window from there on becomes a NaN window (bin 2000, as `NaN as i32` = 0 does)
+    auto note_nonfinite = [&](const double energy, const uint32_t unit, const bool counts) {
+        const bool bad = counts && !(fabs(energy) <= 1.7976931348623157e308);
+        if (__any(bad) && bad) atomicMax(&nonfinite[tr.track_index], 0xFFFFFFFFu - unit);
+    };
 
     bool done = false;
     {
@@ -419,14 +453,44 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
             // of the channel go through the element-wise staging of the TAIL variant too
             const bool plain = len == L && start + ((L + 3u) & ~3u) <= tr.frames;
             if (__all(plain))
-                tm_fast_path<FMT, false>(st, pk, K, L, H, chp, tr.frames, wave_seg0, len, T12, T2, wtile);
+                tm_fast_path<FMT, false, true>(st, pk, K, L, H, chp, tr.frames, wave_seg0, seg_stride, 0, len, T12, T2, wtile);
             else if (__any(len != 0))
-                tm_fast_path<FMT, true>(st, pk, K, L, H, chp, tr.frames, wave_seg0, len, T12, T2, wtile);
+                tm_fast_path<FMT, true, true>(st, pk, K, L, H, chp, tr.frames, wave_seg0, seg_stride, 0, len, T12, T2, wtile);
+            if constexpr (MULTI) {
+                // ---- windows 2..m of the segment: the start state's transient is gone (|Phi| < 1e-15 per window,
+                // rg_design.cpp), what is left is the running cascade and one energy per window.  The moments of the
+                // first window are final: they leave the registers now.
+                note_nonfinite(st.A[0], seg * m, active);
+                if (active) {
+                    double *__restrict__ const r = rec_ptr();
+                    r[0] = st.A[0];
+#pragma unroll
+                    for (int j = 0; j < RG_TM_DIM; ++j) r[(size_t)(1 + j) * total_recs] = st.B[0][j];
+                }
+#pragma unroll 1
+                for (uint32_t w = 1; w < m; ++w) {
+                    const uint64_t wstart = start + (uint64_t)w * L;
+                    uint32_t lenw = 0;
+                    if (active && wstart < tr.frames) {
+                        const uint64_t rem = tr.frames - wstart;
+                        lenw = rem < L ? (uint32_t)rem : L;
+                    }
+                    if (!__any(lenw != 0)) break;  // the track ended in an earlier window for every row of this wave
+                    st.A[0] = 0.0;
+                    const bool plainw = lenw == L && wstart + ((L + 3u) & ~3u) <= tr.frames;
+                    if (__all(plainw))
+                        tm_fast_path<FMT, false, false>(st, pk, K, L, H, chp, tr.frames, wave_seg0, seg_stride, (uint64_t)w * L, lenw, T12, T2, wtile);
+                    else
+                        tm_fast_path<FMT, true, false>(st, pk, K, L, H, chp, tr.frames, wave_seg0, seg_stride, (uint64_t)w * L, lenw, T12, T2, wtile);
+                    note_nonfinite(st.A[0], seg * m + w, lenw != 0);
+                    if (lenw != 0) win_energy[(size_t)chan * total_windows + tr.win_base + (size_t)seg * m + w] = st.A[0];
+                }
+            }
         }
     }
     if (!done) {
-        // ---- generic path: other sample formats, tables too large for LDS, and waves holding the tail
-        // of a track.  Frames past `len` are fed as zeros and their output is excluded from the moments;
+        // ---- generic path: tables too large for LDS (m == 1 only; rg_enqueue.hip never picks multi-window segments
+        // then).  Frames past `len` are fed as zeros and their output is excluded from the moments;
         // the end state of such a lane is never used (the track ends inside it).
         gelem *const p0 = chp + start;
         for (uint32_t n = 0; n < L; ++n) {
@@ -453,19 +517,17 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
         dbg[w + 3] = done ? 1ull : 0ull;
     }
 
-    // A sample that is not finite (NaN / Inf in float PCM) leaves the reference's filter state NaN for the rest of
-    // the track (src/replaygain.rs:586-616 has no reset): remember the first segment it happens in, the fix-up
-    // kernel turns every window from there on into a NaN window (bin 2000, as `NaN as i32` = 0 does)
-    {
-        const bool bad = active && !(fabs(st.A[0]) <= 1.7976931348623157e308);
-        if (__any(bad) && bad) atomicMax(&nonfinite[tr.track_index], 0xFFFFFFFFu - seg);
-    }
-    // ---- segment record, structure-of-arrays: field f of channel c at ((c*RG_TM_REC + f) * total_recs + idx)
-    if (active) {
-        double *__restrict__ r = rec + (size_t)chan * RG_TM_REC * total_recs + ((size_t)tr.rec_base + seg);
-        r[0] = st.A[0];
+    if constexpr (!MULTI) {
+        note_nonfinite(st.A[0], seg, active);
+        if (active) {
+            double *__restrict__ const r = rec_ptr();
+            r[0] = st.A[0];
 #pragma unroll
-        for (int j = 0; j < RG_TM_DIM; ++j) r[(size_t)(1 + j) * total_recs] = st.B[0][j];
+            for (int j = 0; j < RG_TM_DIM; ++j) r[(size_t)(1 + j) * total_recs] = st.B[0][j];
+        }
+    }
+    if (active) {
+        double *__restrict__ const r = rec_ptr();
 #pragma unroll
         for (int j = 0; j < 10; ++j) r[(size_t)(13 + j) * total_recs] = st.s[0][j];
         r[(size_t)23 * total_recs] = st.t[0][0];
@@ -503,7 +565,9 @@ __device__ __forceinline__ double tm_quad_half(GP Gm, const double (&sg)[RG_TM_D
 template <int NCH>
 __global__ void __launch_bounds__(RG_TM_BLOCK)
 rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__restrict__ tracks, uint32_t n_tracks,
-                 const double *__restrict__ rec, uint32_t total_recs, uint32_t *__restrict__ nonfinite,
+                 const double *__restrict__ rec, uint32_t total_recs,
+                 const double *__restrict__ win_energy /* [NCH][total_windows], m > 1 */, uint32_t total_windows,
+                 uint32_t *__restrict__ nonfinite,
                  uint32_t *__restrict__ imprecise, uint32_t *__restrict__ hist,
                  unsigned long long *__restrict__ peak_bits, uint32_t *__restrict__ done_count,
                  rg_track_result *__restrict__ results,
@@ -649,7 +713,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     TM_FIX_STAMP(2);
     double S = 0.0, Mseg = 0.0;
     if (owner) {
-        const uint64_t start = (uint64_t)seg * G.L;
+        const uint64_t start = (uint64_t)seg * G.L * G.m;  // the moments cover the segment's first window (all of it when m == 1)
         const uint64_t rem = tr.frames - start;
         const uint32_t len = rem < G.L ? (uint32_t)rem : G.L;
         const bool full = len == G.L;
@@ -706,7 +770,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     }
     // windows at or after the first non-finite sample of the track are NaN windows (see the main kernel)
     const uint32_t nf = nonfinite[tr.track_index];
-    if (nf != 0 && owner && (uint32_t)seg >= 0xFFFFFFFFu - nf) S = __longlong_as_double(0x7FF8000000000000ll);
+    if (nf != 0 && owner && (uint64_t)seg * G.m >= 0xFFFFFFFFu - nf) S = __longlong_as_double(0x7FF8000000000000ll);
     pieces[i] = owner ? S : 0.0;
     pieces_m[i] = owner ? Mseg : 0.0;
     __syncthreads();
@@ -747,7 +811,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     int bin = -1;
     bool cancelled = false;
     if ((uint32_t)i < G.fix_windows) {
-        const uint64_t widx = (uint64_t)b * G.fix_windows + i;
+        const uint64_t widx = ((uint64_t)b * G.fix_windows + i) * G.m;  // m > 1: k == 1, the segment's first window
         if (widx < tr.n_windows) {
             double total = 0.0, mtot = 0.0;
             for (uint32_t q = 0; q < G.k; ++q) {
@@ -783,6 +847,42 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
             for (uint32_t q = i + 1; q < G.fix_windows; ++q) count += bins[q] == bin ? 1u : 0u;
             tm_performed(atomicAdd(&hist[(size_t)tr.track_index * RG_HISTOGRAM_SIZE + bin], count));
         }
+    }
+
+    // ---- multi-window segments: windows 2..m of this lane's segment arrive as plain energies from the main kernel.
+    // The start state's transient in them is sigma' T[n >= W]: below 1e-15 of sigma at the start of window 2 and
+    // falling; it is bounded here with the lane's own sigma (slow pair; the fast block is gone after H10 frames) and a
+    // window whose bin that bound could change marks the track imprecise, like a cancelling moment window above.
+    if (G.m > 1) {
+        bool any_flag = false;
+        if (owner) {
+            double dlt[NCH];
+            const double t10 = fabs(G.T[(size_t)(G.L - 1) * RG_TM_DIM + 10]), t11 = fabs(G.T[(size_t)(G.L - 1) * RG_TM_DIM + 11]);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) dlt[c] = fabs(sgm[c][10]) * t10 + fabs(sgm[c][11]) * t11;
+            for (uint32_t w = 1; w < G.m; ++w) {
+                const uint64_t widx = (uint64_t)seg * G.m + w;
+                if (widx >= tr.n_windows) break;
+                const uint64_t rem = tr.frames - widx * G.W;
+                const uint32_t n = rem < G.W ? (uint32_t)rem : G.W;
+                double total = 0.0, e = 0.0;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const double a = win_energy[(size_t)c * total_windows + tr.win_base + widx];
+                    total += a;
+                    if (w == 1) e += 2.0 * dlt[c] * sqrt((double)n * fabs(a)) + (double)n * dlt[c] * dlt[c];
+                }
+                if (NCH == 1) { total *= 2.0; e *= 2.0; }
+                if (nf != 0 && widx >= 0xFFFFFFFFu - nf) total = __longlong_as_double(0x7FF8000000000000ll);
+                const int wb = rg_window_bin(total, 0.0, n);
+                if (w == 1 && e > 1.0e-13 * total) {
+                    const double lo = total - e;
+                    any_flag = any_flag || rg_window_bin(lo < 0.0 ? 0.0 : lo, 0.0, n) != rg_window_bin(total + e, 0.0, n);
+                }
+                if (wb >= 0) tm_performed(atomicAdd(&hist[(size_t)tr.track_index * RG_HISTOGRAM_SIZE + wb], 1u));
+            }
+        }
+        if (__any(any_flag) && lane == 0) tm_performed(atomicOr(&imprecise[tr.track_index], 1u));
     }
 
     TM_FIX_STAMP(4);
@@ -822,45 +922,53 @@ extern "C" void rg_tm_set_fix_debug_buffer(unsigned long long *d_buf) { g_tm_fix
 
 template <int FMT>
 static hipError_t launch_main_fmt(int nch, const RgTmCoef &K, const RgTmGeom &G, const RgTmTrack *d_tracks,
-                                  uint32_t n_tracks, uint32_t grid, double *d_rec, uint32_t total_recs,
-                                  uint32_t *d_nonfinite, uint32_t *d_zero, uint64_t zero_count, hipStream_t s) {
+                                  uint32_t n_tracks, uint32_t grid, double *d_rec, uint32_t total_recs, double *d_win,
+                                  uint32_t total_windows, uint32_t *d_nonfinite, uint32_t *d_zero, uint64_t zero_count,
+                                  hipStream_t s) {
     // LDS: T12 (H10 x 12 doubles) + T2 ((L - H10) x 2 doubles) + one 4 KiB PCM tile per wave
     size_t lds = rg_tm_lds_bytes(G.L, G.H10, G.block);
     uint32_t lds_tables = lds <= RG_TM_LDS_BYTES ? 1u : 0u;
     if (!lds_tables) lds = 0;
     static bool attr_set = false;
     if (lds > 48 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void *)rg_tm_main_kernel<FMT>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_TM_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)rg_tm_main_kernel<FMT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_TM_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)rg_tm_main_kernel<FMT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_TM_LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((rg_tm_main_kernel<FMT>), dim3(grid, nch), dim3(G.block), lds, s, K, G, d_tracks, n_tracks,
-                       d_rec, total_recs, d_nonfinite, lds_tables, d_zero, zero_count, g_tm_debug);
+    if (G.m > 1) {
+        if (!lds_tables) return hipErrorInvalidValue;  // multi-window segments exist on the LDS path only
+        hipLaunchKernelGGL((rg_tm_main_kernel<FMT, true>), dim3(grid, nch), dim3(G.block), lds, s, K, G, d_tracks, n_tracks,
+                           d_rec, total_recs, d_win, total_windows, d_nonfinite, lds_tables, d_zero, zero_count, g_tm_debug);
+    } else {
+        hipLaunchKernelGGL((rg_tm_main_kernel<FMT, false>), dim3(grid, nch), dim3(G.block), lds, s, K, G, d_tracks, n_tracks,
+                           d_rec, total_recs, d_win, total_windows, d_nonfinite, lds_tables, d_zero, zero_count, g_tm_debug);
+    }
     return hipGetLastError();
 }
 
 extern "C" hipError_t rg_launch_tm_main(int fmt, int nch, const RgTmCoef *K, const RgTmGeom *G,
                                         const RgTmTrack *d_tracks, uint32_t n_tracks, uint32_t grid, double *d_rec,
-                                        uint32_t total_recs, uint32_t *d_nonfinite, uint32_t *d_zero, uint64_t zero_count,
-                                        hipStream_t s) {
+                                        uint32_t total_recs, double *d_win, uint32_t total_windows, uint32_t *d_nonfinite,
+                                        uint32_t *d_zero, uint64_t zero_count, hipStream_t s) {
     if (grid == 0) return hipSuccess;
     switch (fmt) {
-        case RG_FMT_F32_PLANAR: return launch_main_fmt<RG_FMT_F32_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_nonfinite, d_zero, zero_count, s);
-        case RG_FMT_S16_PLANAR: return launch_main_fmt<RG_FMT_S16_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_nonfinite, d_zero, zero_count, s);
-        default: return launch_main_fmt<RG_FMT_S32_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_nonfinite, d_zero, zero_count, s);
+        case RG_FMT_F32_PLANAR: return launch_main_fmt<RG_FMT_F32_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_win, total_windows, d_nonfinite, d_zero, zero_count, s);
+        case RG_FMT_S16_PLANAR: return launch_main_fmt<RG_FMT_S16_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_win, total_windows, d_nonfinite, d_zero, zero_count, s);
+        default: return launch_main_fmt<RG_FMT_S32_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_win, total_windows, d_nonfinite, d_zero, zero_count, s);
     }
 }
 
 extern "C" hipError_t rg_launch_tm_fix(int nch, const RgTmGeom *G, const RgTmFixTables *FT, const RgTmTrack *d_tracks,
                                        uint32_t n_tracks, uint32_t grid, const double *d_rec, uint32_t total_recs,
-                                       uint32_t *d_nonfinite, uint32_t *d_imprecise, uint32_t *d_hist,
+                                       const double *d_win, uint32_t total_windows, uint32_t *d_nonfinite, uint32_t *d_imprecise, uint32_t *d_hist,
                                        unsigned long long *d_peak_bits, uint32_t *d_done, rg_track_result *d_results,
                                        hipStream_t s) {
     if (grid == 0) return hipSuccess;
     if (nch == 1)
         hipLaunchKernelGGL((rg_tm_fix_kernel<1>), dim3(grid), dim3(RG_TM_BLOCK), 0, s, *G, *FT, d_tracks, n_tracks, d_rec,
-                           total_recs, d_nonfinite, d_imprecise, d_hist, d_peak_bits, d_done, d_results, g_tm_fix_debug);
+                           total_recs, d_win, total_windows, d_nonfinite, d_imprecise, d_hist, d_peak_bits, d_done, d_results, g_tm_fix_debug);
     else
         hipLaunchKernelGGL((rg_tm_fix_kernel<2>), dim3(grid), dim3(RG_TM_BLOCK), 0, s, *G, *FT, d_tracks, n_tracks, d_rec,
-                           total_recs, d_nonfinite, d_imprecise, d_hist, d_peak_bits, d_done, d_results, g_tm_fix_debug);
+                           total_recs, d_win, total_windows, d_nonfinite, d_imprecise, d_hist, d_peak_bits, d_done, d_results, g_tm_fix_debug);
     return hipGetLastError();
 }

@@ -65,7 +65,7 @@ struct RgTmTrack {
     uint32_t fix_blocks;       // number of fix-up blocks of this track (the last one to finish writes the result)
     uint32_t sample_rate;
     uint32_t file_type;
-    uint32_t pad_;
+    uint32_t win_base;         // first entry of this track in the per-window energy array (multi-window segments)
 };
 
 // launch-group geometry (passed by value)
@@ -79,7 +79,10 @@ struct RgTmGeom {
     uint32_t warm;         // warm-up lanes per fix-up block (2^R)
     uint32_t fix_windows;  // whole windows per fix-up block
     uint32_t block;        // threads per main-kernel block: RG_TM_BLOCK, or RG_TM_BLOCK_WIDE when the LDS image is large
-    uint32_t pad_;
+    uint32_t m;            // windows per segment (1 = a segment is L <= W frames; > 1 needs L == W: a lane then runs m
+                           // whole windows, the transient moments only over the first -- by the second window the
+                           // start state has decayed below 1e-30 of itself -- and hands windows 2..m over as plain
+                           // energies, which rg_tm_direct_kernel bins)
     const double *T;       // [L][12] homogeneous responses, block-diagonal coordinates
     const double *Tlds;    // the same packed for LDS: [H10][12] then [L - H10][2] (only the slow pair)
 };

@@ -50,17 +50,29 @@ def _ctx(capi):
 #   (2, 0)    transient-moment kernels, segment length chosen by the library
 #   (2, -1)   transient-moment kernels, smallest admissible segment (many segments per window)
 #   (2, -2)   transient-moment kernels, one segment per window
-@pytest.fixture(params=[(1, 0), (2, 0), (2, -1), (2, -2)], ids=["halo", "tm-auto", "tm-short", "tm-window"])
+#   (2, -3)   transient-moment kernels, four windows per segment (moments over the first, plain energies for the rest)
+#   (2, -4)   transient-moment kernels, sixteen windows per segment
+@pytest.fixture(params=[(1, 0), (2, 0), (2, -1), (2, -2), (2, -3), (2, -4)],
+                ids=["halo", "tm-auto", "tm-short", "tm-window", "tm-multi4", "tm-multi16"])
 def analyzer(_ctx, request):
     variant, seg = request.param
     _ctx.set_kernel(variant)
     _ctx.set_tuning(1, 0)
     _ctx.set_tuning(2, 0)
+    _ctx.set_tuning(4, 0)
     if seg == -1:
         _ctx.set_tuning(2, 1 << 40)  # unreachable lane target -> smallest admissible segment
     elif seg == -2:
-        _ctx.set_tuning(2, 1)        # any lane count is enough -> largest segment (= the window)
+        _ctx.set_tuning(2, 1)        # any lane count is enough -> largest segment (= the window) ...
+        _ctx.set_tuning(4, 1)        # ... of one window
+    elif seg == -3:
+        _ctx.set_tuning(2, 1)
+        _ctx.set_tuning(4, 4)
+    elif seg == -4:
+        _ctx.set_tuning(2, 1)
+        _ctx.set_tuning(4, 16)
     yield _ctx
     _ctx.set_kernel(0)
     _ctx.set_tuning(1, 0)
     _ctx.set_tuning(2, 0)
+    _ctx.set_tuning(4, 0)

@@ -12,7 +12,8 @@ TAG=$1; FRAMES=$2; shift 2
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=gpurun_out/prof_$TAG
 cd /tmp && export TMPDIR=/tmp
-mkdir -p $R/$OUT $R/profiles
+export PROFILES_DIR=$R/gpurun_out/profiles   # only gpurun_out/ travels back: copy from there into profiles/
+mkdir -p $R/$OUT $PROFILES_DIR
 cd $R
 BENCH_ARGS="$*"
 run() { name=$1; shift; timeout ${PROF_TIMEOUT:-400} rocprofv3 "$@" -d $OUT/$name --output-format csv -- python bench.py --cpu-seconds 0 --no-configs1 $BENCH_ARGS $EXTRA > $OUT/$name.log 2>&1 || echo "$name failed/timeout"; }
@@ -32,5 +33,5 @@ run pmc_tcc --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run pmc_lds --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT
 run pmc_lat --pmc SQ_INST_LEVEL_SMEM SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_BUSY_CU_CYCLES
 fi
-python tools/prof_summary.py $OUT $TAG $FRAMES "$BENCH_ARGS" > profiles/r02_${TAG}_pmc_summary.txt 2>&1
-tail -5 profiles/r02_${TAG}_pmc_summary.txt
+python tools/prof_summary.py $OUT $TAG $FRAMES "$BENCH_ARGS" > $PROFILES_DIR/r02_${TAG}_pmc_summary.txt 2>&1
+tail -5 $PROFILES_DIR/r02_${TAG}_pmc_summary.txt

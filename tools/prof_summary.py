@@ -18,7 +18,8 @@ import sys
 from collections import defaultdict
 
 d, tag, frames, bench_args = sys.argv[1], sys.argv[2], int(sys.argv[3]), (sys.argv[4] if len(sys.argv) > 4 else "")
-prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+prof = os.environ.get("PROFILES_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+os.makedirs(prof, exist_ok=True)
 MAIN = "rg_tm_main_kernel"
 
 for f in glob.glob(f"{d}/kt/*/*kernel_stats.csv"):
