@@ -192,9 +192,10 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
     for (uint32_t d = 1; d <= W; ++d)
         if (W % d == 0 && (d >= kMinSegment || d == W)) cand.push_back(Cand{d, 1});
     if (c->tune_tm_windows != 1) {
-        static const uint32_t ms[] = {2, 3, 4, 6, 8, 12, 16};
-        for (uint32_t m : ms)
-            if (c->tune_tm_windows == 0 || m <= c->tune_tm_windows) cand.push_back(Cand{W, m});
+        // every m is legal (a track's last segment simply holds fewer windows); which one wins is mostly a matter of how
+        // well ceil(windows / m) lanes fill whole blocks of the track
+        const uint32_t m_max = c->tune_tm_windows ? c->tune_tm_windows : 16;
+        for (uint32_t m = 2; m <= m_max; ++m) cand.push_back(Cand{W, m});
     }
     auto lanes_of = [&](const Cand &q) {
         uint64_t lanes = 0;
@@ -217,7 +218,7 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
     // Cost model.  Per lane: 28 VALU slots per frame (27 FMA + convert), + 2 per frame of the first window (slow pair of
     // moments), + 10 for its first H10 frames (fast block), + a fixed part (prologue, record, the fix-up kernel's share:
     // one 208-byte record per channel read back plus ~400 FMAs; measured 2.4 ms per 10.8 M segments beside 24 ms of main)
-    //   waves(L, m) = sum over tracks and channels of ceil(nseg / block) * block / 64
+    //   waves(L, m) = ceil(sum over tracks and channels of nseg / block) * block / 64
     //   time        ~ ceil(waves / 1024) * cost   when everything is resident at once,
     //                 (waves / 1024 + 1) * cost   otherwise (many rounds, one extra for the ragged tail)
     // Consecutive batches overlap across the context's pipeline slots, so `waves` counts the batches in flight.
@@ -229,11 +230,9 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
         const uint32_t Hl = H10 >= L ? L : H10;
         const uint32_t block = rg_tm_choose_block(L, Hl);
         const uint64_t stride = (uint64_t)L * m;
-        double waves = 0;
-        for (uint32_t id : g.ids) {
-            const uint64_t nseg = (tracks[id].frames + stride - 1) / stride;
-            waves += (double)((nseg + block - 1) / block) * (block / 64) * g.nch;
-        }
+        double lanes = 0;
+        for (uint32_t id : g.ids) lanes += (double)((tracks[id].frames + stride - 1) / stride) * g.nch;
+        double waves = ceil(lanes / block) * (block / 64);  // blocks run through track boundaries: no per-track padding
         waves *= c->n_slots < RG_SLOT_STREAMS ? c->n_slots : RG_SLOT_STREAMS;  // batches in flight = streams
         const double cost = (double)stride * 28.0 + (double)L * 2.0 + (double)std::min(L, H10) * 10.0 + 1500.0 + 1500.0 + 60.0 * (m - 1);
         // residency: the LDS image of the response tables + one 4 KiB tile per wave bound the blocks per CU
@@ -415,7 +414,7 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
             o.nseg = (uint32_t)((cd.frames + seg_stride - 1) / seg_stride);
             o.n_windows = cd.n_windows;
             o.rec_base = (uint32_t)recs;
-            o.main_block_base = (uint32_t)mb;
+            o.lane_base = (uint32_t)mb;
             o.fix_block_base = (uint32_t)fb;
             o.track_index = id;
             o.fix_blocks = (o.nseg + NB - 1) / NB;
@@ -430,7 +429,7 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
                 ++n_k1;
             }
             recs += o.nseg;
-            mb += (o.nseg + geom_block - 1) / geom_block;
+            mb += (uint64_t)o.nseg * g.nch;  // lanes, not blocks: the main kernel's blocks run through track boundaries
             fb += (o.nseg + NB - 1) / NB;
             if (recs > 0x7FFFFFFFull || mb > 0x7FFFFFFFull || fb > 0x7FFFFFFFull || wins > 0x7FFFFFFFull)
                 return rg_set_err(c, RG_ERR_INVALID_ARG, "batch too large");
@@ -438,7 +437,7 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
         gl.total_recs = (uint32_t)recs;
         gl.total_windows = (uint32_t)wins;
         if (geo.m > 1) max_win_doubles = std::max(max_win_doubles, (size_t)wins * g.nch);
-        gl.main_grid = (uint32_t)mb;
+        gl.main_grid = (uint32_t)((mb + geom_block - 1) / geom_block);
         gl.fix_grid = (uint32_t)fb;
         max_rec_doubles = std::max(max_rec_doubles, (size_t)recs * RG_TM_REC * g.nch);
         launches.push_back(gl);

@@ -198,13 +198,13 @@ __device__ __forceinline__ void tm_load_row(double (&dst)[NX], const double *__r
 //
 // MOM = the transient moments B are accumulated (the first window of a segment); without it the tile loop is the
 // cascade and the energy alone (windows 2..m of a multi-window segment: no table reads at all).
-// A row is L frames; row r of the wave starts at frame (wave_seg0 + r) * seg_stride + row_off of the channel.
+// A row is up to L frames: lane r of the wave owns row r, which starts at `rowp` (this lane's) and has `len` valid
+// frames.  The rows of a wave need not belong to one track or channel: the loader lanes fetch the bases by shuffle.
 template <int FMT, bool TAIL, bool MOM>
 __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::peak_t &pk, const RgTmCoef &K, const uint32_t L,
                                              const uint32_t H,
-                                             const __attribute__((address_space(1))) typename Fmt<FMT>::elem *chp,
-                                             const uint64_t frames, const uint32_t wave_seg0, const uint64_t seg_stride,
-                                             const uint64_t row_off, const uint32_t len,
+                                             const __attribute__((address_space(1))) typename Fmt<FMT>::elem *rowp,
+                                             const uint32_t len,
                                              const double *__restrict__ T12, const double *__restrict__ T2,
                                              char *const wtile /* RG_TM_WAVE_TILE_BYTES */) {
     typedef Fmt<FMT> F;
@@ -212,16 +212,16 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
     const int lane = threadIdx.x & 63;
     // loader role: instruction q covers rows 16q .. 16q+15; this lane fetches for row 16q + (lane >> 2)
     const int lrow = lane >> 2, lslot = lane & 3;
-    uint64_t lfirst[4];  // first frame (within the channel) of the piece this lane fetches, tile 0
+    gelem *lfirst[4];    // the piece this lane fetches in tile 0
     uint32_t llen[4];    // valid frames of that row
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = 16 * q + lrow;
         const int piece = lslot ^ ((row >> 2) & 3);
-        const uint64_t row0 = (uint64_t)(wave_seg0 + row) * seg_stride + row_off;
-        lfirst[q] = row0 + 4u * piece;
+        const unsigned long long base = __shfl((unsigned long long)(uintptr_t)rowp, row, 64);
+        lfirst[q] = (gelem *)(uintptr_t)base + 4u * piece;
         llen[q] = L;
-        if (TAIL) llen[q] = row0 >= frames ? 0u : (frames - row0 < L ? (uint32_t)(frames - row0) : L);
+        if (TAIL) llen[q] = __shfl(len, row, 64);
     }
     // consumer role: row == lane
     const char *const rrow = wtile + lane * 64;
@@ -246,9 +246,9 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
             const uint32_t pn = n0 + 4u * piece;  // frame index of the piece within its row
             if (!TAIL) {
                 // pieces starting past the row's end are never read; only the last tile can have such pieces
-                if (n0 + RG_TM_TILE <= L || pn < L) stage[q] = load4(chp + lfirst[q] + n0);
+                if (n0 + RG_TM_TILE <= L || pn < L) stage[q] = load4(lfirst[q] + n0);
             } else {
-                gelem *src = chp + lfirst[q] + n0;
+                gelem *src = lfirst[q] + n0;
                 if (pn + 4u <= llen[q]) {
                     stage[q] = load4(src);
                 } else {
@@ -382,19 +382,29 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
     // the batch's histograms, peaks and arrival counters are cleared here instead of by a memset of
     // their own: nothing in this kernel reads them, and everything that does is behind it in the stream
     if (zero_words) {
-        const uint64_t stride = (uint64_t)gridDim.x * gridDim.y * blockDim.x;
-        for (uint64_t w = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; w < zero_count; w += stride)
-            zero_words[w] = 0u;
+        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+        for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < zero_count; w += stride) zero_words[w] = 0u;
     }
-    const uint32_t t = find_track(tracks, n_tracks, blockIdx.x, &RgTmTrack::main_block_base);
-    const RgTmTrack tr = tracks[t];
-    const int chan = blockIdx.y;
-    const uint32_t seg = (blockIdx.x - tr.main_block_base) * blockDim.x + threadIdx.x;
+    // Lanes are numbered through the whole launch group: track t owns lanes [lane_base, lane_base + channels * nseg),
+    // channel 0's segments first.  Blocks and waves are not padded per track (a 3-minute track in 5-window segments is
+    // 720 lanes: padded to whole 768-lane blocks per channel that was 6 % idle lanes, at other lengths up to 60 %).
+    const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = find_track(tracks, n_tracks, gl, &RgTmTrack::lane_base);
+    // Per-lane now (a wave can straddle tracks), so only what the frame loops need stays in registers: the channel
+    // base, the track length and the segment's place; everything else is read again from tracks[t] where it is used.
+    struct { const void *ch0, *ch1; uint64_t frames; uint32_t nseg; } tr;
+    {
+        const RgTmTrack &q = tracks[t];
+        tr.ch0 = q.ch0; tr.ch1 = q.ch1; tr.frames = q.frames; tr.nseg = q.nseg;
+    }
+    const uint32_t rel = gl - tracks[t].lane_base;
+    const int chan = (tr.ch1 != nullptr && rel >= tr.nseg) ? 1 : 0;
+    const uint32_t seg = rel - (chan ? tr.nseg : 0u);
     const uint32_t L = G.L;
     const uint32_t H = G.H10;
     const uint32_t m = MULTI ? G.m : 1u;            // windows per segment (L == W when m > 1)
     const uint64_t seg_stride = (uint64_t)L * m;
-    const bool active = seg < tr.nseg;
+    const bool active = seg < tr.nseg;  // false only for the lanes past the group's last track
     const uint64_t start = (uint64_t)seg * seg_stride;
     uint32_t len = 0;                               // valid frames of the first window (the moment zone)
     if (active) {
@@ -414,13 +424,13 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
     typename F::peak_t pk = 0;
     // segment record, structure-of-arrays: field f of channel c at ((c*RG_TM_REC + f) * total_recs + idx)
     // (the address is formed where it is used: a pointer held across the frame loops costs two VGPRs there)
-    auto rec_ptr = [&]() -> double * { return rec + (size_t)chan * RG_TM_REC * total_recs + ((size_t)tr.rec_base + (active ? seg : 0)); };
+    auto rec_ptr = [&]() -> double * { return rec + (size_t)chan * RG_TM_REC * total_recs + ((size_t)tracks[t].rec_base + (active ? seg : 0)); };
     // A sample that is not finite (NaN / Inf in float PCM) leaves the reference's filter state NaN for the rest of
     // the track (src/replaygain.rs:586-616 has no reset): remember the first unit (segment, or window of a multi-window
     // segment) it happens in; every window from there on becomes a NaN window (bin 2000, as `NaN as i32` = 0 does)
     auto note_nonfinite = [&](const double energy, const uint32_t unit, const bool counts) {
         const bool bad = counts && !(fabs(energy) <= 1.7976931348623157e308);
-        if (__any(bad) && bad) atomicMax(&nonfinite[tr.track_index], 0xFFFFFFFFu - unit);
+        if (__any(bad) && bad) atomicMax(&nonfinite[tracks[t].track_index], 0xFFFFFFFFu - unit);
     };
 
     bool done = false;
@@ -448,14 +458,13 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
             const double *const T12 = reinterpret_cast<const double *>(smem);
             const double *const T2 = T12 + (size_t)H * 12;
             char *const wtile = smem + (size_t)tbl_doubles * sizeof(double) + (threadIdx.x >> 6) * RG_TM_WAVE_TILE_BYTES;
-            const uint32_t wave_seg0 = seg - (threadIdx.x & 63);
             // a 16-byte piece may reach up to 3 frames past its row: full rows that end exactly at the end
             // of the channel go through the element-wise staging of the TAIL variant too
             const bool plain = len == L && start + ((L + 3u) & ~3u) <= tr.frames;
             if (__all(plain))
-                tm_fast_path<FMT, false, true>(st, pk, K, L, H, chp, tr.frames, wave_seg0, seg_stride, 0, len, T12, T2, wtile);
+                tm_fast_path<FMT, false, true>(st, pk, K, L, H, chp + start, len, T12, T2, wtile);
             else if (__any(len != 0))
-                tm_fast_path<FMT, true, true>(st, pk, K, L, H, chp, tr.frames, wave_seg0, seg_stride, 0, len, T12, T2, wtile);
+                tm_fast_path<FMT, true, true>(st, pk, K, L, H, chp + start, len, T12, T2, wtile);
             if constexpr (MULTI) {
                 // ---- windows 2..m of the segment: the start state's transient is gone (|Phi| < 1e-15 per window,
                 // rg_design.cpp), what is left is the running cascade and one energy per window.  The moments of the
@@ -479,11 +488,11 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
                     st.A[0] = 0.0;
                     const bool plainw = lenw == L && wstart + ((L + 3u) & ~3u) <= tr.frames;
                     if (__all(plainw))
-                        tm_fast_path<FMT, false, false>(st, pk, K, L, H, chp, tr.frames, wave_seg0, seg_stride, (uint64_t)w * L, lenw, T12, T2, wtile);
+                        tm_fast_path<FMT, false, false>(st, pk, K, L, H, chp + wstart, lenw, T12, T2, wtile);
                     else
-                        tm_fast_path<FMT, true, false>(st, pk, K, L, H, chp, tr.frames, wave_seg0, seg_stride, (uint64_t)w * L, lenw, T12, T2, wtile);
+                        tm_fast_path<FMT, true, false>(st, pk, K, L, H, chp + wstart, lenw, T12, T2, wtile);
                     note_nonfinite(st.A[0], seg * m + w, lenw != 0);
-                    if (lenw != 0) win_energy[(size_t)chan * total_windows + tr.win_base + (size_t)seg * m + w] = st.A[0];
+                    if (lenw != 0) win_energy[(size_t)chan * total_windows + tracks[t].win_base + (size_t)seg * m + w] = st.A[0];
                 }
             }
         }
@@ -507,7 +516,7 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
     }
 
     if (dbg && (threadIdx.x & 63) == 0) {
-        const size_t w = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x / 64) + (threadIdx.x >> 6)) * 6;
+        const size_t w = ((size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * 6;
         dbg[w + 4] = dbg_c0;
         dbg[w + 5] = __builtin_readcyclecounter();
         dbg[w + 0] = dbg_t0;
@@ -937,10 +946,10 @@ static hipError_t launch_main_fmt(int nch, const RgTmCoef &K, const RgTmGeom &G,
     }
     if (G.m > 1) {
         if (!lds_tables) return hipErrorInvalidValue;  // multi-window segments exist on the LDS path only
-        hipLaunchKernelGGL((rg_tm_main_kernel<FMT, true>), dim3(grid, nch), dim3(G.block), lds, s, K, G, d_tracks, n_tracks,
+        hipLaunchKernelGGL((rg_tm_main_kernel<FMT, true>), dim3(grid), dim3(G.block), lds, s, K, G, d_tracks, n_tracks,
                            d_rec, total_recs, d_win, total_windows, d_nonfinite, lds_tables, d_zero, zero_count, g_tm_debug);
     } else {
-        hipLaunchKernelGGL((rg_tm_main_kernel<FMT, false>), dim3(grid, nch), dim3(G.block), lds, s, K, G, d_tracks, n_tracks,
+        hipLaunchKernelGGL((rg_tm_main_kernel<FMT, false>), dim3(grid), dim3(G.block), lds, s, K, G, d_tracks, n_tracks,
                            d_rec, total_recs, d_win, total_windows, d_nonfinite, lds_tables, d_zero, zero_count, g_tm_debug);
     }
     return hipGetLastError();

@@ -59,7 +59,7 @@ struct RgTmTrack {
     uint32_t nseg;             // ceil(frames / L)
     uint32_t n_windows;        // ceil(frames / W)
     uint32_t rec_base;         // first segment record of this track
-    uint32_t main_block_base;  // first block of this track in the main kernel's grid
+    uint32_t lane_base;        // first lane of this track in the main kernel's grid (channel 0's segments, then channel 1's)
     uint32_t fix_block_base;   // first block of this track in the fix-up kernel's grid
     uint32_t track_index;      // row in the histogram / peak arrays
     uint32_t fix_blocks;       // number of fix-up blocks of this track (the last one to finish writes the result)

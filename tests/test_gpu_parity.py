@@ -481,15 +481,21 @@ def test_exact_repeat_touches_only_the_flagged_tracks(_ctx, oracle):
     assert [bool(g.flags & 2) for g in forced] == [False, False, False, True, False, False, False]
     an.set_kernel(0)
     an.analyze_tracks(tracks)  # warm
-    t0 = time.perf_counter()
-    got, h = an.analyze_tracks(tracks, return_histograms=True)
-    dt_auto = time.perf_counter() - t0
+    dt_auto = 1e9
+    for _ in range(3):  # best of three: both calls share a 300 MB pageable H2D copy whose duration wanders
+        t0 = time.perf_counter()
+        got, h = an.analyze_tracks(tracks, return_histograms=True)
+        dt_auto = min(dt_auto, time.perf_counter() - t0)
     an.set_kernel(1)
-    t0 = time.perf_counter()
     an.analyze_tracks(tracks)
-    dt_v1 = time.perf_counter() - t0
+    dt_v1 = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        an.analyze_tracks(tracks)
+        dt_v1 = min(dt_v1, time.perf_counter() - t0)
     an.set_kernel(0)
     for g, hh, tr in zip(got, h, tracks):
         want, wh = oracle.analyze_pcm(tr.channels[0], tr.channels[1], rate)
         assert np.array_equal(hh, wh) and g.loudness_db == want["loudness_db"] and not g.flags & 2
-    assert dt_auto < dt_v1  # six 2-minute tracks on variant 1 cost far more than the H2D copy both calls share
+    # six 2-minute tracks on variant 1 cost more than variant 2 for all + variant 1 for the one flagged 3-second track
+    assert dt_auto < dt_v1, f"auto {dt_auto * 1e3:.2f} ms, variant 1 {dt_v1 * 1e3:.2f} ms"
