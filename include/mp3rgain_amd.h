@@ -173,7 +173,10 @@ int rg_set_kernel(rg_ctx *ctx, int variant);
  * over min(slots, 4) HIP streams so that batches overlap on the GPU; rg_collect / rg_album_finish always refer to
  * the most recent enqueue,
  * key 4 = most windows one lane of variant 2 may run in a row (multi-window segments; 0 = chosen from the batch size, up
- * to 16; 1 = never more than one) */
+ * to 16; 1 = never more than one),
+ * key 5 = sub-batch size in KiB of the streamed host ingest (0 = 2 GiB): rg_analyze_pcm_batch / rg_analyze_album_pcm on a
+ * HOST arena larger than this are cut at track boundaries into sub-batches; two device arenas of that size take turns,
+ * the copy of one sub-batch running under the kernels of the previous, so an arena larger than HBM is fine */
 int rg_set_tuning(rg_ctx *ctx, int key, int64_t value);
 /* diagnostic (host only): variant 2's design for one rate and segment length.  T_out: [L][12],
  * gram_last_out: [78]; either may be NULL.  RG_ERR_INVALID_ARG when no design exists. */

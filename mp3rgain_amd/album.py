@@ -100,3 +100,27 @@ def gather_track_results(local: Sequence, n_tracks: int, group=None, frames: Opt
         for k, t in enumerate(shard_indices(n_tracks, world, r, frames)):
             out[t] = buckets[r][k]
     return out
+
+
+class AlbumAborted(RuntimeError):
+    """An album analysis stopped because some rank could not analyse one of its tracks."""
+
+
+def abort_if_any_failed(local_error: Optional[BaseException], group=None) -> None:
+    """The reference's album loop ends at the first track that fails (`?` at src/replaygain.rs:1055): no album result,
+    no per-track results.  Sharded over ranks that has to be a joint decision -- a rank that raised on its own would
+    leave the others waiting in the exchange.  Call this between the per-rank analysis and the collective: every rank
+    passes its own exception (or None); if any rank failed, every rank raises AlbumAborted carrying the message of the
+    failing rank with the lowest number (its tracks come first in input order among equals), and nobody enters the
+    collective."""
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if local_error is not None:
+            raise AlbumAborted(str(local_error)) from local_error
+        return
+    msgs = [None] * dist.get_world_size(group)
+    dist.all_gather_object(msgs, None if local_error is None else str(local_error), group=group)
+    for r, m in enumerate(msgs):
+        if m is not None:
+            raise AlbumAborted(f"rank {r}: {m}")

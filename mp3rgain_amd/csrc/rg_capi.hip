@@ -251,6 +251,16 @@ extern "C" void rg_destroy(rg_ctx *c) {
     c->d_peak_bits.release();
     c->d_arena.release();
     c->d_wav.release();
+    c->d_ingest[0].release();
+    c->d_ingest[1].release();
+    c->d_album_packs.release();
+    if (c->ingest_stream) {
+        (void)hipStreamDestroy(c->ingest_stream);
+        for (int k = 0; k < 2; ++k) {
+            (void)hipEventDestroy(c->ingest_copied[k]);
+            (void)hipEventDestroy(c->ingest_free[k]);
+        }
+    }
     rg_tm_tables_release(c);
     delete c;
 }
@@ -288,6 +298,7 @@ extern "C" int rg_set_tuning(rg_ctx *c, int key, int64_t value) {
         case RG_TUNE_TM_SEGMENT: c->tune_tm_segment = (uint32_t)value; return RG_OK;
         case RG_TUNE_TM_TARGET_LANES: c->tune_tm_target_lanes = (uint64_t)value; return RG_OK;
         case RG_TUNE_TM_WINDOWS: c->tune_tm_windows = (uint32_t)(value > 255 ? 255 : value); return RG_OK;
+        case RG_TUNE_INGEST_CHUNK_KIB: c->tune_ingest_chunk_kib = (uint64_t)value; return RG_OK;
         case RG_TUNE_PIPELINE_SLOTS: {
             if (sync_all(c) != RG_OK) return RG_ERR_DEVICE;
             c->n_slots = value == 0 ? RG_DEFAULT_SLOTS : (value > RG_MAX_SLOTS ? RG_MAX_SLOTS : (int)value);
@@ -584,10 +595,148 @@ struct ExactPass {  // scope of the repeat: the per-track routing mask is droppe
 };
 }  // namespace
 
+namespace {
+// ---- streamed host ingest ------------------------------------------------------------------------------------------
+// A host arena does not have to fit HBM, and its copy (PCIe: ~55 GB/s against 3.4 TB/s of analysis) is the whole cost
+// of the call: the batch is cut at track boundaries into sub-batches of at most `chunk` bytes, two device arenas take
+// turns -- sub-batch i+1 is copied on the ingest stream while the kernels of sub-batch i run on a pipeline stream -- and
+// results come back per sub-batch, so the device holds two chunks at any time whatever the album's size.  Pageable
+// memory goes through the runtime's own pinned staging (hipMemcpyAsync returns when the host buffer has been read);
+// pinned memory (hipHostMalloc / hipHostRegister by the caller) is DMA'd in place.
+// Bits are those of the one-shot path: tracks are independent, per-track results are written to their input positions,
+// and the album histogram is the sum of the sub-batches' histograms (u32 adds commute), the peak their maximum.
+constexpr uint64_t kDefaultIngestChunk = 2ull << 30;
+
+int ingest_setup(rg_ctx *c) {
+    if (c->ingest_stream) return RG_OK;
+    RG_HIP(c, hipStreamCreateWithFlags(&c->ingest_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+        RG_HIP(c, hipEventCreateWithFlags(&c->ingest_copied[k], hipEventDisableTiming));
+        RG_HIP(c, hipEventCreateWithFlags(&c->ingest_free[k], hipEventDisableTiming));
+    }
+    return RG_OK;
+}
+
+struct SubBatch {
+    size_t first, count;  // tracks [first, first + count)
+    size_t bytes;
+};
+
+int analyze_host_streamed(rg_ctx *c, const rg_track_desc *tracks, size_t n, const unsigned char *host, int album,
+                          rg_track_result *out, uint32_t *hist_out, rg_album_result *album_out, uint32_t *album_hist_out,
+                          uint64_t chunk) {
+    int rc = rg_bind_device(c);
+    if (rc != RG_OK) return rc;
+    rc = ingest_setup(c);
+    if (rc != RG_OK) return rc;
+    auto track_bytes = [&](size_t t) { return (size_t)tracks[t].channels * tracks[t].frames * rg_bytes_per_sample(tracks[t].format); };
+    std::vector<SubBatch> subs;
+    for (size_t t = 0; t < n;) {
+        SubBatch sb{t, 0, 0};
+        while (t < n) {
+            const size_t b = (track_bytes(t) + 15) & ~(size_t)15;
+            if (sb.count && sb.bytes + b > chunk) break;
+            sb.bytes += b;
+            ++sb.count;
+            ++t;
+        }
+        subs.push_back(sb);
+    }
+    size_t max_bytes = 16;
+    for (const SubBatch &sb : subs) max_bytes = std::max(max_bytes, sb.bytes);
+    rc = sync_all(c);
+    if (rc != RG_OK) return rc;
+    for (int k = 0; k < 2; ++k) RG_HIP(c, c->d_ingest[k].reserve(max_bytes));
+    if (album) RG_HIP(c, c->d_album_packs.reserve(subs.size() * (size_t)RG_ALBUM_PACK_WORDS));
+    std::vector<rg_track_result> res(n ? n : 1);
+    std::vector<std::vector<rg_track_desc>> descs(subs.size());
+
+    auto copy_sub = [&](size_t i) -> int {  // H2D of sub-batch i into arena i & 1, compacted, on the ingest stream
+        const SubBatch &sb = subs[i];
+        const int k = (int)(i & 1);
+        if (i >= 2) RG_HIP(c, hipStreamWaitEvent(c->ingest_stream, c->ingest_free[k], 0));  // kernels of sub-batch i-2 are done with it
+        descs[i].resize(sb.count);
+        size_t off = 0;
+        for (size_t q = 0; q < sb.count; ++q) {
+            const rg_track_desc &d = tracks[sb.first + q];
+            const size_t b = track_bytes(sb.first + q);
+            if (b) RG_HIP(c, hipMemcpyAsync(c->d_ingest[k].p + off, host + d.offset_bytes, b, hipMemcpyHostToDevice, c->ingest_stream));
+            descs[i][q] = d;
+            descs[i][q].offset_bytes = off;
+            off += (b + 15) & ~(size_t)15;
+        }
+        RG_HIP(c, hipEventRecord(c->ingest_copied[k], c->ingest_stream));
+        return RG_OK;
+    };
+    auto enqueue_sub = [&](size_t i) -> int {
+        const SubBatch &sb = subs[i];
+        const int k = (int)(i & 1);
+        // every pipeline stream may run this batch: they all wait for the copy (one event wait each, per sub-batch)
+        for (int s = 0; s < c->n_slots; ++s) RG_HIP(c, hipStreamWaitEvent(c->slots[s].stream, c->ingest_copied[k], 0));
+        return rg_enqueue_impl(c, descs[i].data(), sb.count, c->d_ingest[k].p, sb.bytes, album);
+    };
+    auto finish_sub = [&](size_t i) -> int {  // results of sub-batch i (the most recent enqueue), exact repeat included
+        const SubBatch &sb = subs[i];
+        const int k = (int)(i & 1);
+        uint32_t *h = hist_out ? hist_out + sb.first * (size_t)RG_HISTOGRAM_SIZE : nullptr;
+        int r = rg_collect(c, res.data() + sb.first, h);
+        if (r != RG_OK) return r;
+        if (needs_exact_pass(c, res.data() + sb.first, sb.count)) {
+            ExactPass exact(c);
+            r = rg_enqueue_impl(c, descs[i].data(), sb.count, c->d_ingest[k].p, sb.bytes, album);
+            if (r != RG_OK) return r;
+            r = rg_collect(c, res.data() + sb.first, h);
+            if (r != RG_OK) return r;
+        }
+        RgSlot &S = c->slot();
+        if (album)
+            RG_HIP(c, hipMemcpyAsync(c->d_album_packs.p + i * (size_t)RG_ALBUM_PACK_WORDS, S.d_album_hist.p,
+                                     (size_t)RG_ALBUM_PACK_WORDS * sizeof(uint32_t), hipMemcpyDeviceToDevice, S.stream));
+        RG_HIP(c, hipEventRecord(c->ingest_free[k], S.stream));
+        return RG_OK;
+    };
+
+    // copy(0); then per step: copy(i+1) goes out BEFORE the results of i are waited for, so the copy engine never idles
+    rc = copy_sub(0);
+    if (rc != RG_OK) return rc;
+    for (size_t i = 0; i < subs.size(); ++i) {
+        rc = enqueue_sub(i);
+        if (rc != RG_OK) return rc;
+        if (i + 1 < subs.size()) {
+            rc = copy_sub(i + 1);
+            if (rc != RG_OK) return rc;
+        }
+        rc = finish_sub(i);
+        if (rc != RG_OK) return rc;
+    }
+    if (out)
+        for (size_t t = 0; t < n; ++t) out[t] = res[t];
+    if (album) {
+        RgSlot &S = c->slot();
+        RG_HIP(c, rg_launch_album_reduce_gathered(c->d_album_packs.p, (uint32_t)subs.size(), S.d_album_hist.p, S.d_album_peak.p, S.stream));
+        S.album_ready = true;
+        return rg_album_finish(c, album_out, album_hist_out);
+    }
+    return RG_OK;
+}
+
+// host input larger than one ingest chunk takes the streamed route
+bool wants_streaming(const rg_ctx *c, size_t n, size_t pcm_bytes, int on_device, uint64_t *chunk) {
+    *chunk = c->tune_ingest_chunk_kib ? c->tune_ingest_chunk_kib * 1024ull : kDefaultIngestChunk;
+    return !on_device && n > 1 && pcm_bytes > *chunk && !c->user_attached;
+}
+}  // namespace
+
 extern "C" int rg_analyze_pcm_batch(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *pcm_base,
                                     size_t pcm_bytes, int on_device, rg_track_result *out, uint32_t *hist_out) {
     if (!c) return RG_ERR_INVALID_ARG;
     if (n && !pcm_base) return rg_set_err(c, RG_ERR_INVALID_ARG, "null pcm_base");
+    uint64_t chunk = 0;
+    if (wants_streaming(c, n, pcm_bytes, on_device, &chunk)) {
+        int v = rg_validate_batch(c, tracks, n, pcm_bytes);
+        if (v != RG_OK) return v;
+        return analyze_host_streamed(c, tracks, n, (const unsigned char *)pcm_base, 0, out, hist_out, nullptr, nullptr, chunk);
+    }
     const void *d_base = nullptr;
     int rc = stage_pcm(c, pcm_base, pcm_bytes, on_device, &d_base);
     if (rc != RG_OK) return rc;
@@ -606,6 +755,12 @@ extern "C" int rg_analyze_album_pcm(rg_ctx *c, const rg_track_desc *tracks, size
                                     rg_album_result *album_out, uint32_t *album_hist_out) {
     if (!c) return RG_ERR_INVALID_ARG;
     if (n && !pcm_base) return rg_set_err(c, RG_ERR_INVALID_ARG, "null pcm_base");
+    uint64_t chunk = 0;
+    if (wants_streaming(c, n, pcm_bytes, on_device, &chunk)) {
+        int v = rg_validate_batch(c, tracks, n, pcm_bytes);
+        if (v != RG_OK) return v;
+        return analyze_host_streamed(c, tracks, n, (const unsigned char *)pcm_base, 1, tracks_out, nullptr, album_out, album_hist_out, chunk);
+    }
     const void *d_base = nullptr;
     int rc = stage_pcm(c, pcm_base, pcm_bytes, on_device, &d_base);
     if (rc != RG_OK) return rc;

@@ -62,7 +62,7 @@ struct RgTmDeviceTables {
     RgTmFixTables fix{};
 };
 
-enum { RG_TUNE_TM_SEGMENT = 1, RG_TUNE_TM_TARGET_LANES = 2, RG_TUNE_PIPELINE_SLOTS = 3, RG_TUNE_TM_WINDOWS = 4 };
+enum { RG_TUNE_TM_SEGMENT = 1, RG_TUNE_TM_TARGET_LANES = 2, RG_TUNE_PIPELINE_SLOTS = 3, RG_TUNE_TM_WINDOWS = 4, RG_TUNE_INGEST_CHUNK_KIB = 5 };
 
 #define RG_MAX_SLOTS 8
 #define RG_SLOT_STREAMS 4   // HIP streams the slots are spread over (the runtime has 4 hardware queues by default)
@@ -134,6 +134,11 @@ struct rg_ctx {
 
     DevBuf<unsigned long long> d_peak_bits;  // rg_find_peak_pcm
     DevBuf<unsigned char> d_arena;           // staging for host PCM (synchronous API)
+    DevBuf<unsigned char> d_ingest[2];       // streamed host ingest: two sub-batch arenas, one filling while the other is analysed
+    DevBuf<uint32_t> d_album_packs;          // streamed album: one [histogram | peak] pack per sub-batch, folded at the end
+    hipStream_t ingest_stream = nullptr;     // H2D copies of the streamed ingest
+    hipEvent_t ingest_copied[2] = {nullptr, nullptr}, ingest_free[2] = {nullptr, nullptr};
+    uint64_t tune_ingest_chunk_kib = 0;      // 0 = default (2 GiB)
     DevBuf<unsigned char> d_wav;             // interleaved WAV samples awaiting de-interleave (rg_files.hip)
     std::string decoder_cmd;                 // rg_set_decoder_command
     std::vector<unsigned char> force_exact;  // per track of the next enqueue: 1 = use variant 1 (exact repeat of flagged tracks)
@@ -155,6 +160,7 @@ int rg_bind_device(rg_ctx *c);
 int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *d_pcm_base, size_t pcm_bytes,
                     int album);
 void rg_tm_tables_release(rg_ctx *c);
+int rg_validate_batch(rg_ctx *c, const rg_track_desc *tracks, size_t n, size_t pcm_bytes);  // argument checks of an enqueue
 
 #define RG_HIP(ctx, call)                                                                          \
     do {                                                                                           \

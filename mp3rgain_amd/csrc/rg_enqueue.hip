@@ -281,6 +281,8 @@ int timing_begin(rg_ctx *c, hipEvent_t *e1) {
 
 }  // namespace
 
+int rg_validate_batch(rg_ctx *c, const rg_track_desc *tracks, size_t n, size_t pcm_bytes) { return validate(c, tracks, n, pcm_bytes); }
+
 void rg_tm_tables_release(rg_ctx *c) {
     for (auto &kv : c->tm_tables) {
         if (kv.second->d_blob) (void)hipFree(kv.second->d_blob);

@@ -106,6 +106,61 @@ def test_two_rank_album_matches_the_sequential_reference(tmp_path, oracle, capi)
         assert [o[1] for o in got["ordered"]] == [r["loudness_db"] for r, _ in wants]
 
 
+def _abort_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    from mp3rgain_amd import album
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rank 1 cannot decode one of its files; rank 0 is fine.  Both must give the album up, neither may hang.
+    err = FileNotFoundError("Failed to open: /music/07.mp3") if rank == 1 else None
+    outcome = "ok"
+    try:
+        album.abort_if_any_failed(err)
+        h = torch.zeros(12000, dtype=torch.int32)
+        album.allreduce_album(h, torch.zeros(1, dtype=torch.float64))  # must not be reached
+    except album.AlbumAborted as ex:
+        outcome = str(ex)
+    (Path(outdir) / f"abort_{rank}.txt").write_text(outcome)
+    # a clean second album on the same group works (nothing was left half-way in a collective)
+    album.abort_if_any_failed(None)
+    t = torch.ones(1, dtype=torch.int32)
+    dist.all_reduce(t)
+    assert int(t) == world
+    dist.destroy_process_group()
+
+
+def test_failing_rank_aborts_the_album_on_every_rank(tmp_path, capi):
+    """src/replaygain.rs:1055: the first failing track ends analyze_album for good.  Sharded, every rank must learn of
+    it before the exchange."""
+    import torch.multiprocessing as mp
+
+    world, port = 2, _free_port()
+    mp.spawn(_abort_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        assert (tmp_path / f"abort_{rank}.txt").read_text() == "rank 1: Failed to open: /music/07.mp3"
+
+
+def test_shards_balance_by_frames():
+    """shards balanced by total frames, not by count; results still come back in input order."""
+    from mp3rgain_amd import album
+
+    frames = [600] + [10] * 60 + [300, 300]  # one 10-minute track among sixty 10-second ones and two 5-minute ones
+    world = 4
+    shards = [album.shard_indices(len(frames), world, r, frames=frames) for r in range(world)]
+    assert sorted(t for s in shards for t in s) == list(range(len(frames)))
+    loads = [sum(frames[t] for t in s) for s in shards]
+    assert max(loads) == 600 and min(loads) >= 190        # round robin would give one rank 600 + 15 * 10 + ... = 900
+    rr = [sum(frames[t] for t in album.shard_indices(len(frames), world, r)) for r in range(world)]
+    assert max(rr) > max(loads)
+    assert all(s == sorted(s) for s in shards)             # each rank walks its tracks in input order
+    assert shards == [album.shard_indices(len(frames), world, r, frames=frames) for r in range(world)]  # deterministic
+    with pytest.raises(ValueError):
+        album.shard_indices(3, 2, 0, frames=[1, 2])
+
+
 def test_single_process_allreduce_is_a_no_op(capi):
     import torch
 

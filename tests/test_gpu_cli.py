@@ -162,6 +162,13 @@ def test_album_gain(box, oracle):
         for f, b in zip(files, before):
             assert mp3gain.analyze(f).max_gain == max(0, min(255, b + steps))
             assert f"  v {f.name} (" in out
+    # the files now carry the album gain in their global_gain fields, and the decoder reads those: the second analysis
+    # sees every track `steps` global_gain steps (2^(1/4) in amplitude each) louder
+    per2 = [want_for(oracle, f) for f in files]
+    alb2, _ = oracle.album_from_hists([h for _, h in per2], [w["peak"] for w, _ in per2])
+    if steps != 0:
+        assert abs((alb2["album_loudness_db"] - alb["album_loudness_db"]) - steps * 20 * math.log10(2 ** 0.25)) <= 0.03
+    per, alb, steps = per2, alb2, round(alb2["album_gain_db"] / 1.5)
     rc, out, _ = run("-o", "json", "-n", "-a", *files)
     d = json.loads(out)
     assert d["album"] == {"loudness_db": alb["album_loudness_db"], "gain_db": alb["album_gain_db"], "gain_steps": steps, "peak": alb["album_peak"]}

@@ -155,6 +155,61 @@ def test_attached_stream_orders_the_album_tail(analyzer, oracle):
         analyzer.set_stream(None)
 
 
+def test_fold_of_two_different_ranks(analyzer, oracle):
+    """rg_album_reduce_gathered with a genuinely different second pack: this context's album pack next to the pack a
+    second rank would have sent (its tracks analysed by the oracle), folded on the device: bins add, peaks take the
+    maximum, the album percentile reads the sum -- analyze_album's merge (src/replaygain.rs:1056-1066) across ranks."""
+    import torch
+
+    from mp3rgain_amd import album
+
+    lens = [RATE * 11, RATE * 4 + 100]
+    seeds = [0x5EED6000, 0x5EED6001]
+    buf, descs = _device_batch(analyzer, seeds, lens)
+    mine_h = np.zeros(12000, dtype=np.uint32)
+    peaks = []
+    for s, f in zip(seeds, lens):
+        r, h = oracle.analyze_pcm(oracle.synth_f32(s, 0, RATE, f), oracle.synth_f32(s, 1, RATE, f), RATE)
+        mine_h += h
+        peaks.append(r["peak"])
+    # the other rank: three other tracks, one of them hot (peak 1.0) and one at another level
+    other_h = np.zeros(12000, dtype=np.uint32)
+    other_peak = 0.0
+    for s, f in ((0x5EED7000 | (1 << 40), RATE * 6), (0x5EED7001, RATE * 9 + 1), (0x5EED7002, RATE * 2)):
+        r, h = oracle.analyze_pcm(oracle.synth_f32(s, 0, RATE, f), oracle.synth_f32(s, 1, RATE, f), RATE)
+        other_h += h
+        other_peak = max(other_peak, r["peak"])
+    assert other_peak > max(peaks) and not np.array_equal(other_h, mine_h)
+    pack2 = np.zeros(album.ALBUM_PACK_WORDS, dtype=np.uint32)
+    pack2[:12000] = other_h
+    pack2[12000:] = np.array([other_peak], dtype=np.float64).view(np.uint32)
+    pack2_t = torch.from_numpy(pack2.view(np.int32).copy()).cuda()
+
+    class _View:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 3}
+
+    analyzer.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        for order in (0, 1):  # this rank's pack first, then second: the fold does not care who is rank 0
+            analyzer.enqueue_device(descs, 2, buf.data_ptr(), buf.numel() * 4, album=True)
+            view = analyzer.device_view()
+            pack = torch.as_tensor(_View(view.d_album_hist, album.ALBUM_PACK_WORDS), device="cuda")
+            gathered = torch.cat([pack, pack2_t] if order == 0 else [pack2_t, pack])
+            analyzer.album_reduce_gathered(gathered.data_ptr(), 2)
+            analyzer.album_result_enqueue()
+            alb, ah = analyzer.album_finish(want_hist=True)
+            assert np.array_equal(ah, mine_h + other_h)
+            assert alb.album_peak == other_peak
+            assert alb.album_loudness_db == oracle.hist_loudness(mine_h + other_h)
+            assert alb.windows == int(mine_h.sum()) + int(other_h.sum())
+            # host restatement of the fold agrees
+            fh, fp = album.fold_gathered(gathered.cpu().numpy().view(np.uint32), 2)
+            assert np.array_equal(fh, ah) and fp == other_peak
+    finally:
+        analyzer.set_stream(None)
+
+
 def test_library_communicator_exchange_on_the_batch_stream(analyzer, oracle):
     """rg_comm_* + rg_album_exchange: the album exchange as one RCCL all-gather + device fold on the stream of the
     batch (what bench.py runs at N > 1).  One GPU can host only a 1-rank communicator, so the collective is the
@@ -328,3 +383,49 @@ def test_config5_full_size_mixed_batch(_ctx, oracle):
         assert got[t].peak == want["peak"] and got[t].loudness_db == want["loudness_db"] and got[t].gain_steps() == want["gain_steps"]
     del buf
     torch.cuda.empty_cache()
+
+
+def test_streamed_host_ingest_gives_the_one_shot_bits(_ctx, oracle):
+    """rg_analyze_pcm_batch / rg_analyze_album_pcm on a host arena larger than the ingest chunk (tuning key 5): the
+    batch is cut at track boundaries, two device arenas take turns, copies run under the previous sub-batch's kernels.
+    Same bits as the one-shot path -- per-track results in input order, histograms, album -- including a track that
+    variant 2 flags (exact repeat inside its sub-batch), mixed rates, formats, a mono and an empty track."""
+    import mp3rgain_amd as rg
+
+    an = _ctx
+    an.set_kernel(0)
+    for key in (1, 2, 3, 4, 5):
+        an.set_tuning(key, 0)
+    rng = np.random.default_rng(77)
+    tracks = []
+    for t in range(14):
+        rate = [44100, 48000, 32000, 22050][t % 4]
+        n = int(rate * (0.7 + 1.9 * rng.random()))
+        ch = [oracle.synth_f32(0x5EED9000 + t, c, rate, n) for c in range(1 if t == 5 else 2)]
+        if t % 5 == 2:
+            ch = [np.round(c * 32767).astype(np.int16) for c in ch]
+        tracks.append(rg.PcmTrack(ch, rate))
+    dc = [(s * 0.9 + 3e-5 * rng.standard_normal(44100 * 2)).astype(np.float32) for s in (1.0, -1.0)]
+    tracks.insert(6, rg.PcmTrack(dc, 44100))                      # every window cancels: flagged by variant 2
+    tracks.insert(9, rg.PcmTrack([np.zeros(0, np.float32)] * 2, 44100))  # empty track
+    one, one_h = an.analyze_tracks(tracks, return_histograms=True)
+    alb1, alb1_h = an.analyze_album(tracks, return_histogram=True)
+    total = sum(sum(c.nbytes for c in t.channels) for t in tracks)
+    for chunk_kib in (64, 300, 1024):
+        assert total > chunk_kib * 1024 * 2
+        an.set_tuning(5, chunk_kib)
+        try:
+            got, got_h = an.analyze_tracks(tracks, return_histograms=True)
+            alb, alb_h = an.analyze_album(tracks, return_histogram=True)
+        finally:
+            an.set_tuning(5, 0)
+        assert np.array_equal(got_h, one_h)
+        for a, b in zip(got, one):
+            assert (a.loudness_db, a.gain_db, a.peak, a.sample_rate, a.windows, a.flags) == (b.loudness_db, b.gain_db, b.peak, b.sample_rate, b.windows, b.flags)
+        assert np.array_equal(alb_h, alb1_h)
+        assert (alb.album_loudness_db, alb.album_gain_db, alb.album_peak) == (alb1.album_loudness_db, alb1.album_gain_db, alb1.album_peak)
+        assert [r.loudness_db for r in alb.tracks] == [r.loudness_db for r in alb1.tracks]
+    # and the bits are the oracle's
+    for tr, r, h in zip(tracks, one, one_h):
+        want, wh = oracle.analyze_pcm(tr.channels[0], tr.channels[1] if len(tr.channels) > 1 else None, tr.sample_rate)
+        assert np.array_equal(h, wh) and r.loudness_db == want["loudness_db"] and r.peak == want["peak"] and not r.flags & 2
