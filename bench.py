@@ -91,7 +91,7 @@ def pmc_for(tag: str, frames_per_launch: int):
 
 
 def roofline_block(frames_per_launch: int, k_ms_sum: float, k_launches: int, k_span_ms: float, tag: str,
-                   algo_bytes: int = 0, algo_flop: int = 0, launches_per_step: int = 1) -> dict:
+                   algo_bytes: int = 0, algo_flop: int = 0, launches_per_step: int = 1, channel_samples: int = 0) -> dict:
     """Both bounds for the dominant kernel.
 
     Consecutive batches run in separate pipeline slots, so several launches can be in flight at once:
@@ -114,17 +114,19 @@ def roofline_block(frames_per_launch: int, k_ms_sum: float, k_launches: int, k_s
     fp64 = {"achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
             "algorithmic_flop_per_launch": algo_flop, "executed": None}
     if pm and pm.get("valu_insts_per_launch"):
-        # executed: PMC wave-instruction counts of one launch x 64 lanes; FMA = 2 flop
+        # executed: PMC wave-instruction counts (mean per launch) x launches per step x 64 lanes; FMA = 2 flop
+        chs = channel_samples or 2 * frames_per_launch
         ex = {"source": f"profiles/{PROFILE_ROUND}_pmc_{tag}.json",
               "valu_wave_insts_per_launch": pm["valu_insts_per_launch"]}
         fma = pm.get("fma_f64_insts_per_launch")
         if fma:
             ex["fma_f64_wave_insts_per_launch"] = fma
-            ex["fma_f64_per_channel_sample"] = fma * 64.0 / (2.0 * frames_per_launch)
-            ex["tflops"] = 2.0 * 64.0 * fma * k_steps / span_s / 1e12 if span_s > 0 else 0.0
+            ex["fma_f64_per_channel_sample"] = fma * launches_per_step * 64.0 / chs
+            ex["tflops"] = 2.0 * 64.0 * fma * k_launches / span_s / 1e12 if span_s > 0 else 0.0
+            ex["frac_of_peak"] = ex["tflops"] / FP64_PEAK_TFLOPS
         else:  # no FP64-specific counter: every VALU instruction priced as an FMA (upper bound on the flops)
-            ex["tflops_upper_bound"] = 2.0 * 64.0 * pm["valu_insts_per_launch"] * k_steps / span_s / 1e12 if span_s > 0 else 0.0
-        ex["valu_per_channel_sample"] = pm["valu_insts_per_launch"] * 64.0 / (2.0 * frames_per_launch)
+            ex["tflops_upper_bound"] = 2.0 * 64.0 * pm["valu_insts_per_launch"] * k_launches / span_s / 1e12 if span_s > 0 else 0.0
+        ex["valu_per_channel_sample"] = pm["valu_insts_per_launch"] * launches_per_step * 64.0 / chs
         fp64["executed"] = ex
     return {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
             "traffic": traffic,
@@ -335,7 +337,8 @@ def main() -> int:
     # a mixed batch is several launch groups (rate x channel count) per step: the per-launch figures are per group
     groups = len({(sp[1], sp[2]) for sp in specs}) or 1
     roof = roofline_block(batch_frames, k1_ms_sum, k1_launches, k1_span_ms, tag, algo_bytes=batch_algo_bytes,
-                          algo_flop=batch_algo_flop, launches_per_step=groups)
+                          algo_flop=batch_algo_flop, launches_per_step=groups,
+                          channel_samples=sum(sp[2] * sp[3] for sp in specs))
 
     # ---- secondary workload on one GPU: configs[1], one 10-minute track (fits the Infinity Cache) ----------
     configs1 = None

@@ -22,24 +22,50 @@ prof = os.environ.get("PROFILES_DIR") or os.path.join(os.path.dirname(os.path.ab
 os.makedirs(prof, exist_ok=True)
 MAIN = "rg_tm_main_kernel"
 
-for f in glob.glob(f"{d}/kt/*/*kernel_stats.csv"):
+
+def newest(pattern):
+    """gpurun merges the output of successive calls into one tree: of several runs of a pass keep the latest"""
+    by_pass = {}
+    for f in glob.glob(pattern):
+        key = f.split(os.sep)[-3]  # the pass directory (kt, pmc_fetch, ...)
+        if key not in by_pass or os.path.getmtime(f) > os.path.getmtime(by_pass[key]):
+            by_pass[key] = f
+    return sorted(by_pass.values())
+
+
+for f in newest(f"{d}/kt/*/*kernel_stats.csv"):
     shutil.copy(f, os.path.join(prof, f"r02_{tag}_kernel_stats.csv"))
     print("== kernel stats (rocprofv3 --kernel-trace --stats)")
     for r in csv.DictReader(open(f)):
         print(f"  {r['Name'][:60]:60s} calls {r['Calls']:>5s} avg_ns {float(r['AverageNs']):12.1f} pct {r['Percentage']}")
 
 # ---- span / concurrency per kernel from the raw trace ------------------------------------------------------
+# The bench line printed under the profiler (kt.log) says how many timed steps there were and how many launch groups a
+# step has; the timed region of a kernel is then its LAST steps x groups launches (pre-roll and warm-up come before, and
+# a barrier + device synchronise separates them from the timed region).
+bench_line = None
+try:
+    for ln in open(f"{d}/kt.log"):
+        if ln.startswith('{"metric"'):
+            bench_line = json.loads(ln)
+except OSError:
+    pass
+if bench_line:
+    json.dump(bench_line, open(os.path.join(prof, f"r02_{tag}_bench_under_rocprofv3.json"), "w"))
+steps = bench_line["steps"] if bench_line else None
+groups = bench_line["roofline"].get("launch_groups_per_step", 1) if bench_line else 1
 spans = {}
-for f in glob.glob(f"{d}/kt/*/*kernel_trace.csv"):
+for f in newest(f"{d}/kt/*/*kernel_trace.csv"):
     per = defaultdict(list)
     for r in csv.DictReader(open(f)):
-        per[r["Kernel_Name"].split("(")[0].replace("void ", "")].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]  # all instantiations of a kernel together
+        per[name].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
     for k, iv in per.items():
         if "rg_" not in k:
             continue
         iv.sort()
-        # the timed region's launches: drop the pre-roll / warm-up by keeping the last 60 % of the launches
-        keep = iv[int(len(iv) * 0.4):] if len(iv) >= 10 else iv
+        ntimed = steps * groups if steps and len(iv) >= steps * groups and ("tm_main" in k or "tm_fix" in k or "k1_halo" in k) else None
+        keep = iv[-ntimed:] if ntimed else iv
         tot = sum(e - s for s, e in keep)
         span = max(e for _, e in keep) - min(s for s, _ in keep)
         spans[k] = {"launches_all": len(iv), "launches_counted": len(keep), "sum_duration_ms": tot / 1e6,
@@ -48,22 +74,25 @@ for f in glob.glob(f"{d}/kt/*/*kernel_trace.csv"):
 if spans:
     m = next((v for k, v in spans.items() if MAIN in k), None)
     doc = {"command": f"rocprofv3 --kernel-trace --stats -- python bench.py --cpu-seconds 0 --no-configs1 {bench_args}".strip(),
-           "frames_per_launch": frames, "kernels": spans,
-           "note": "launches_counted = the last 60 % of each kernel's launches (pre-roll and warm-up dropped); "
+           "frames_per_step": frames, "timed_steps": steps, "launch_groups_per_step": groups, "kernels": spans,
+           "note": "launches_counted = the timed region's launches (the last steps x groups of the kernel); "
                    "span = first start to last end of those; concurrency = sum of durations / span"}
-    if m:
-        doc["dominant_kernel"] = {"name": MAIN, "algorithmic_bytes_per_launch": 8 * frames,
-                                  "achieved_GBps_span": 8 * frames / (m["span_per_launch_ms"] * 1e-3) / 1e9,
-                                  "hbm_frac_span": 8 * frames / (m["span_per_launch_ms"] * 1e-3) / 8e12,
-                                  "achieved_GBps_avg_duration": 8 * frames / (m["avg_duration_ms"] * 1e-3) / 1e9,
-                                  "fp64_algorithmic_tflops_span": 108 * frames / (m["span_per_launch_ms"] * 1e-3) / 1e12}
+    if m and bench_line:
+        algo = bench_line["roofline"]["algorithmic_bytes_per_launch"] * groups  # per step
+        step_ms = m["span_ms"] / steps
+        doc["dominant_kernel"] = {"name": MAIN, "algorithmic_bytes_per_step": algo,
+                                  "span_per_step_ms": step_ms,
+                                  "achieved_GBps_span": algo / (step_ms * 1e-3) / 1e9,
+                                  "hbm_frac_span": algo / (step_ms * 1e-3) / 8e12,
+                                  "bench_line_frac_same_run": bench_line["roofline"]["frac"],
+                                  "bench_line_kernel_ms_same_run": bench_line["roofline"]["kernel_ms"]}
     json.dump(doc, open(os.path.join(prof, f"r02_{tag}_span.json"), "w"), indent=1)
     print("== span", json.dumps(doc.get("dominant_kernel")))
 
 acc = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(f"{d}/pmc_*/*/*counter_collection.csv"):
+for f in newest(f"{d}/pmc_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")[:44]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0][:44]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("== PMC (mean per dispatch)")
 for k, cs in acc.items():
     if "rg_" not in k:
