@@ -93,6 +93,8 @@ int finish_k1_list(rg_ctx *c, RgTrackDev *list, size_t n, uint32_t *total_items)
     uint64_t items = 0;
     for (size_t t = 0; t < n; ++t) {
         RgTrackDev &o = list[t];
+        // a wave (64 items) never mixes sample rates: the kernel keeps the filter constants in scalar registers
+        if (t > 0 && list[t - 1].coef_idx != o.coef_idx) items = (items + 63) & ~(uint64_t)63;
         if (c->design[o.coef_idx].stable) {
             o.seg_windows = seg_windows;
             o.halo = c->design[o.coef_idx].halo_frames;

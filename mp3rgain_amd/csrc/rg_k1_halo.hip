@@ -9,6 +9,9 @@
 //   EqualLoudnessFilter::process   src/replaygain.rs:586-616   (direct form I, same sum order)
 //   add_sample / add_mono_sample   src/replaygain.rs:720-740
 //   finish_window                  src/replaygain.rs:743-765   (mean square -> dB*100 -> bin)
+// Twelve frames per loop turn: the histories rotate through twelve physical slots instead of shifting (same
+// operations on the same values, in the same order), and the turn's PCM arrives as three 16-byte loads per channel
+// issued one turn ahead.
 // With halo == UINT32_MAX and one segment per track the kernel is the reference's sequential
 // algorithm verbatim (used for the unstable 88.2 kHz coefficient row and as a parity anchor).
 // This variant is the correctness anchor; variant 2 (rg_k2_tm.hip) is the fast path.
@@ -32,15 +35,30 @@
         f(std::integral_constant<int, 8>{}); f(std::integral_constant<int, 9>{}); f(std::integral_constant<int, 10>{}); \
     } while (0)
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, 11>), in three groups of four (one 16-byte piece each)
+#define RG_K1_TWELVE(f)                                                                                       \
+    do {                                                                                                      \
+        f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{});   \
+        f(std::integral_constant<int, 3>{});                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        f(std::integral_constant<int, 4>{}); f(std::integral_constant<int, 5>{}); f(std::integral_constant<int, 6>{});   \
+        f(std::integral_constant<int, 7>{});                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        f(std::integral_constant<int, 8>{}); f(std::integral_constant<int, 9>{}); f(std::integral_constant<int, 10>{}); \
+        f(std::integral_constant<int, 11>{});                                                                            \
+    } while (0)
+
 namespace {
 
+// twelve physical slots for the eleven-entry histories: one spare, so that the rotation period is twelve frames --
+// three 16-byte pieces of PCM -- instead of eleven
 struct Df1State {
-    double yx[11], yy[11], bx[3], by[3];
+    double yx[12], yy[12], bx[3], by[3];
 };
 
 __device__ __forceinline__ void df1_reset(Df1State &f) {
 #pragma unroll
-    for (int i = 0; i < 11; ++i) { f.yx[i] = 0.0; f.yy[i] = 0.0; }
+    for (int i = 0; i < 12; ++i) { f.yx[i] = 0.0; f.yy[i] = 0.0; }
 #pragma unroll
     for (int i = 0; i < 3; ++i) { f.bx[i] = 0.0; f.by[i] = 0.0; }
 }
@@ -73,20 +91,21 @@ __device__ __forceinline__ double df1_process(Df1State &f, const RgCoefDev &c, d
     return z;
 }
 
-// The same step with the Yule-Walker histories rotated instead of shifted.  K = 0..10 counts the frames since the
-// histories were last in their natural order; the shift of frame K would move x_buf[i-1] to x_buf[i], so after it
-// the value the reference holds in x_buf[i] / y_buf[i] lives in physical slot (i - K - 1) mod 11 without having
-// been moved, and the new sample goes to slot (10 - K).  The twenty moves of the shift disappear when eleven
-// consecutive frames are unrolled with K = 0..10 -- and after the eleventh the histories are in natural order again.  Same products, same subtraction,
-// same fold order: bit-identical to df1_process.
+// The same step with the Yule-Walker histories rotated instead of shifted.  K = 0..11 counts the frames since the
+// histories were last in their natural order (logical entry i in physical slot i).  The shift of a frame would move
+// x_buf[i-1] to x_buf[i]; after K + 1 of them the value the reference holds in x_buf[i] / y_buf[i] lives in physical
+// slot (i - K - 1) mod 12 without having been moved, and the new sample goes to slot (11 - K).  The twenty moves of
+// the shift disappear when twelve consecutive frames are unrolled with K = 0..11 -- and after the twelfth the
+// histories are in natural order again (slot 11 then holds the entry the reference has just dropped).
+// Same products, same subtraction, same fold order: bit-identical to df1_process.
 template <int K>
 __device__ __forceinline__ double df1_process_rot(Df1State &f, const RgCoefDev &c, double s) {
-    constexpr int P0 = (10 - K) % 11;
+    constexpr int P0 = (11 - K) % 12;
     f.yx[P0] = s;
     double acc = 0.0;
 #pragma unroll
     for (int i = 1; i < 11; ++i) {
-        const int p = (i - K - 1 + 22) % 11;
+        const int p = (i - K - 1 + 24) % 12;
         double t = c.yb[i] * f.yx[p] - c.ya[i] * f.yy[p];
         acc = acc + t;
     }
@@ -123,6 +142,36 @@ __device__ __forceinline__ double load_input(const void *base, uint64_t i, uint3
         mag = fabs(v / 32768.0);
         return v;
     }
+}
+
+// the same conversion from a staged 32-bit word (float bits, or a sign-extended integer)
+__device__ __forceinline__ double cvt_input(uint32_t w, uint32_t fmt, double &mag) {
+    if (fmt == RG_FMT_F32_PLANAR) {
+        const double xn = (double)__uint_as_float(w);
+        mag = fabs(xn);
+        return xn * 32768.0;
+    } else if (fmt == RG_FMT_S16_PLANAR) {
+        const double v = (double)(int32_t)w;
+        mag = fabs(v / 32768.0);
+        return v;
+    } else {
+        const double v = (double)(int32_t)w * (32768.0 / 2147483648.0);
+        mag = fabs(v / 32768.0);
+        return v;
+    }
+}
+
+typedef uint32_t __attribute__((ext_vector_type(4), aligned(4))) k1_u32x4u;  // 16-byte load, 4-byte aligned
+typedef short __attribute__((ext_vector_type(4), aligned(2))) k1_s16x4u;     // 8-byte load, 2-byte aligned
+
+// four consecutive samples of one channel as 32-bit words
+__device__ __forceinline__ uint4 load_piece(const void *base, uint64_t i, uint32_t fmt) {
+    if (fmt == RG_FMT_S16_PLANAR) {
+        const k1_s16x4u v = *(const k1_s16x4u *)((const int16_t *)base + i);
+        return make_uint4((uint32_t)(int32_t)v.x, (uint32_t)(int32_t)v.y, (uint32_t)(int32_t)v.z, (uint32_t)(int32_t)v.w);
+    }
+    const k1_u32x4u v = *(const k1_u32x4u *)((const uint32_t *)base + i);
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 }  // namespace
@@ -166,7 +215,9 @@ __global__ void __launch_bounds__(256) rg_k1_halo_kernel(const RgTrackDev *__res
     const RgTrackDev tr = tracks[t];
     const uint32_t seg = g - tr.item_base;
     if (seg >= tr.n_segments) return;
-    const RgCoefDev c = coefs[tr.coef_idx];
+    // every wave holds items of one sample rate (rg_enqueue.hip pads the item list to a wave boundary where the rate
+    // changes), so the 28 filter constants are wave-uniform: scalar loads into SGPRs instead of 56 VGPRs per lane
+    const RgCoefDev c = coefs[__builtin_amdgcn_readfirstlane(tr.coef_idx)];
 
     const uint64_t W = tr.window;
     const uint64_t first = (uint64_t)seg * tr.seg_windows * W;
@@ -181,38 +232,26 @@ __global__ void __launch_bounds__(256) rg_k1_halo_kernel(const RgTrackDev *__res
     df1_reset(fr);
     double mag;
 
-    {
-        uint64_t i = warm;
-        for (; i + 11 <= first; i += 11) {  // eleven frames per turn: rotated histories, no shifts
-            auto step = [&](auto k) {
-                constexpr int K = decltype(k)::value;
-                (void)df1_process_rot<K>(fl, c, load_input(tr.ch0, i + K, fmt, mag));
-                if (stereo) (void)df1_process_rot<K>(fr, c, load_input(tr.ch1, i + K, fmt, mag));
-            };
-            RG_K1_ELEVEN(step);
-        }
-        for (; i < first; ++i) {
-            (void)df1_process(fl, c, load_input(tr.ch0, i, fmt, mag));
-            if (stereo) (void)df1_process(fr, c, load_input(tr.ch1, i, fmt, mag));
-        }
-    }
-
     double peak = 0.0, lsum = 0.0, rsum = 0.0;
     uint32_t n = 0;
     uint32_t *const h = hist + (size_t)tr.track_index * RG_HISTOGRAM_SIZE;
     const uint64_t bad_from = first_bad[tr.track_index];  // ~0 when every sample is finite
     const double qnan = __longlong_as_double(0x7FF8000000000000ll);
-    // one frame of the segment; ROT >= 0 selects the rotated step of that phase, -1 the shifting one
-    auto frame = [&](const uint64_t i, auto rot) {
+    // One frame.  Frames before `first` are the warm-up halo: the cascade runs, nothing is counted.
+    // ROT >= 0 selects the rotated step of that phase, -1 the shifting one.
+    auto frame = [&](const uint64_t i, const double xl, const double ml, const double xr, const double mr, auto rot) {
         constexpr int ROT = decltype(rot)::value;
         double lf, rf = 0.0;
-        if constexpr (ROT >= 0) lf = df1_process_rot<ROT>(fl, c, load_input(tr.ch0, i, fmt, mag));
-        else lf = df1_process(fl, c, load_input(tr.ch0, i, fmt, mag));
-        if (mag > peak) peak = mag;
+        if constexpr (ROT >= 0) lf = df1_process_rot<ROT>(fl, c, xl);
+        else lf = df1_process(fl, c, xl);
         if (stereo) {
-            if constexpr (ROT >= 0) rf = df1_process_rot<ROT>(fr, c, load_input(tr.ch1, i, fmt, mag));
-            else rf = df1_process(fr, c, load_input(tr.ch1, i, fmt, mag));
-            if (mag > peak) peak = mag;
+            if constexpr (ROT >= 0) rf = df1_process_rot<ROT>(fr, c, xr);
+            else rf = df1_process(fr, c, xr);
+        }
+        if (i < first) return;
+        if (ml > peak) peak = ml;
+        if (stereo) {
+            if (mr > peak) peak = mr;
             lsum += lf * lf;
             rsum += rf * rf;
         } else {
@@ -228,13 +267,54 @@ __global__ void __launch_bounds__(256) rg_k1_halo_kernel(const RgTrackDev *__res
         }
     };
     {
-        uint64_t i = first;
-        for (; i + 11 <= last; i += 11) {
-            auto step = [&](auto k) { frame(i + decltype(k)::value, k); };
-            RG_K1_ELEVEN(step);
+        // Twelve frames per turn: rotated histories (no shifts), and the PCM of a turn is three 16-byte loads per
+        // channel issued one turn ahead (per-sample loads from 64 different rows cost a cache line each and sat on
+        // the critical path: a lone 3-second track took 4.3 ms, 18x its bytes came from HBM).
+        uint64_t i = warm;
+        uint4 pl[3], pr[3];  // the three pieces of the current turn; piece p is refilled for the next turn as soon as
+                             // its four frames are done, so one set of registers serves as the prefetch buffer
+        if (i + 12 <= last) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                pl[p] = load_piece(tr.ch0, i + 4u * p, fmt);
+                if (stereo) pr[p] = load_piece(tr.ch1, i + 4u * p, fmt);
+            }
         }
-        for (; i < last; ++i) frame(i, std::integral_constant<int, -1>{});
+        for (; i + 12 <= last; i += 12) {
+            const bool more = i + 24 <= last;
+            auto four = [&](auto piece) {
+                constexpr int P = decltype(piece)::value;
+                const uint32_t wl[4] = {pl[P].x, pl[P].y, pl[P].z, pl[P].w};
+                const uint32_t wr[4] = {pr[P].x, pr[P].y, pr[P].z, pr[P].w};
+                if (more) {
+                    pl[P] = load_piece(tr.ch0, i + 12u + 4u * P, fmt);
+                    if (stereo) pr[P] = load_piece(tr.ch1, i + 12u + 4u * P, fmt);
+                }
+                auto step = [&](auto k) {
+                    constexpr int K = decltype(k)::value;
+                    double ml, mr = 0.0, xr = 0.0;
+                    const double xl = cvt_input(wl[K & 3], fmt, ml);
+                    if (stereo) xr = cvt_input(wr[K & 3], fmt, mr);
+                    frame(i + K, xl, ml, xr, mr, k);
+                };
+                step(std::integral_constant<int, 4 * P>{});
+                step(std::integral_constant<int, 4 * P + 1>{});
+                step(std::integral_constant<int, 4 * P + 2>{});
+                step(std::integral_constant<int, 4 * P + 3>{});
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            four(std::integral_constant<int, 0>{});
+            four(std::integral_constant<int, 1>{});
+            four(std::integral_constant<int, 2>{});
+        }
+        for (; i < last; ++i) {
+            double ml, mr = 0.0, xr = 0.0;
+            const double xl = load_input(tr.ch0, i, fmt, ml);
+            if (stereo) xr = load_input(tr.ch1, i, fmt, mr);
+            frame(i, xl, ml, xr, mr, std::integral_constant<int, -1>{});
+        }
     }
+    (void)mag;
     if (n > 0) {  // final partial window, src/replaygain.rs:907
         if (last - 1 >= bad_from) lsum = qnan;
         const int idx = rg_window_bin(lsum, rsum, n);
