@@ -176,7 +176,11 @@ int rg_set_kernel(rg_ctx *ctx, int variant);
  * to 16; 1 = never more than one),
  * key 5 = sub-batch size in KiB of the streamed host ingest (0 = 2 GiB): rg_analyze_pcm_batch / rg_analyze_album_pcm on a
  * HOST arena larger than this are cut at track boundaries into sub-batches; two device arenas of that size take turns,
- * the copy of one sub-batch running under the kernels of the previous, so an arena larger than HBM is fine */
+ * the copy of one sub-batch running under the kernels of the previous, so an arena larger than HBM is fine,
+ * key 6 = 1: MPEG Layer III files of the file-level entry points are decoded by the SPLIT decoder -- the serial part
+ * (frame walk, side information, bit reservoir, scalefactors, Huffman) on the host's cores, requantisation, joint stereo,
+ * IMDCT and the polyphase filterbank on the GPU, PCM written straight into the analysis arena (mp3rgain_amd_dec.h);
+ * bit-identical PCM to the host decoder, ~15x its speed per host core.  0 (default) = the host decoder */
 int rg_set_tuning(rg_ctx *ctx, int key, int64_t value);
 /* diagnostic (host only): variant 2's design for one rate and segment length.  T_out: [L][12],
  * gram_last_out: [78]; either may be NULL.  RG_ERR_INVALID_ARG when no design exists. */
@@ -278,6 +282,9 @@ int rg_analyze_album(rg_ctx *ctx, const char *const *paths, size_t n, int32_t tr
                      rg_track_result *tracks_out, rg_album_result *album_out);
 /* find_peak_amplitude (src/replaygain.rs:1140-1249) */
 int rg_find_peak_amplitude(rg_ctx *ctx, const char *path, rg_peak_result *out);
+/* One MPEG Layer III stream through the split decoder (stage A on the host, stages B-E on the device), PCM copied back
+ * to the host: same outputs as rg_mp3_decode_f32 of mp3rgain_amd_dec.h, bit for bit.  `info` is an rg_mp3_stream_info. */
+int rg_mp3_decode_device(rg_ctx *ctx, const void *data, size_t len, float *ch0, float *ch1, uint64_t capacity, void *info);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,36 @@ int rg_mp3_scan(const void *data, size_t len, rg_mp3_stream_info *out);
  * On RG_MP3DEC_OK out->frames holds the number of frames written per channel. */
 int rg_mp3_decode_f32(const void *data, size_t len, float *ch0, float *ch1, uint64_t capacity, rg_mp3_stream_info *out);
 
+/* ---- split decode: stage A on the host, stages B-E on the GPU (include/mp3rgain_amd.h: tuning key 6) -------------------
+ * The serial part of Layer III decoding -- frame walk, side information, bit reservoir, scalefactors, Huffman -- is a
+ * few percent of a decoder's work and strictly sequential per frame; everything after it (requantisation, joint stereo,
+ * reordering, alias reduction, IMDCT + overlap, polyphase synthesis) has no recursion across granules and runs on the
+ * device (rg_mp3dev.hip).  rg_mp3_parse_units is that serial part: per decoded granule and channel one `rg_mp3_unit`
+ * and 576 quantised spectral values (int16), in decode order: unit = granule * channels + channel, granule counting the
+ * granules of decodable frames only (a dropped frame contributes nothing, exactly as in rg_mp3_decode_f32). */
+typedef struct rg_mp3_unit {
+    uint8_t sf[40];          /* scalefactors, flat: long bands, then short bands x 3 windows (see rg_mp3dec.cpp)        */
+    uint64_t illegal;        /* bit i: sf[i] is an LSF intensity position meaning "not intensity coded"                */
+    uint16_t nz;             /* number of spectral lines decoded (the rest are zero)                                   */
+    uint8_t global_gain;
+    uint8_t block_type;      /* 0 normal, 1 start, 2 short, 3 stop                                                      */
+    uint8_t mixed;
+    uint8_t subblock_gain[3];
+    uint8_t scalefac_scale;
+    uint8_t preflag;
+    uint8_t long_end;        /* long scalefactor bands in this granule (22, 8 / 6 for mixed, 0 for short)               */
+    uint8_t short_start;     /* first short band (13 = none)                                                            */
+    uint8_t mode_ext;        /* joint stereo only: bit 0 intensity, bit 1 mid/side; 0 otherwise                         */
+    uint8_t intensity_scale; /* LSF: low bit of the right channel's scalefac_compress                                   */
+    uint8_t reserved[2];
+} rg_mp3_unit;               /* 64 bytes */
+
+/* is_out: int16 [capacity_units][576]; units_out: [capacity_units].  out->frames / audio_frames / skipped_frames as
+ * rg_mp3_decode_f32 reports them; *n_units = units written.  Frames whose channel count differs from the stream's
+ * first frame are dropped here (the one-shot decoder spreads / truncates them). */
+int rg_mp3_parse_units(const void *data, size_t len, int16_t *is_out, rg_mp3_unit *units_out, uint64_t capacity_units,
+                       uint64_t *n_units, rg_mp3_stream_info *out);
+
 /* Text of the last error of the calling thread ("" if none). */
 const char *rg_mp3dec_last_error(void);
 

@@ -136,6 +136,7 @@ SYMBOLS = [
     ("rg_analyze_track", _int, [_vp, C.c_char_p, _i32, _P(TrackResult)]),
     ("rg_analyze_album", _int, [_vp, _P(C.c_char_p), _sz, _i32, _P(TrackResult), _P(AlbumResult)]),
     ("rg_find_peak_amplitude", _int, [_vp, C.c_char_p, _P(PeakResult)]),
+    ("rg_mp3_decode_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
 ]
 
 _lib = None

@@ -62,7 +62,8 @@ struct RgTmDeviceTables {
     RgTmFixTables fix{};
 };
 
-enum { RG_TUNE_TM_SEGMENT = 1, RG_TUNE_TM_TARGET_LANES = 2, RG_TUNE_PIPELINE_SLOTS = 3, RG_TUNE_TM_WINDOWS = 4, RG_TUNE_INGEST_CHUNK_KIB = 5 };
+enum { RG_TUNE_TM_SEGMENT = 1, RG_TUNE_TM_TARGET_LANES = 2, RG_TUNE_PIPELINE_SLOTS = 3, RG_TUNE_TM_WINDOWS = 4, RG_TUNE_INGEST_CHUNK_KIB = 5,
+       RG_TUNE_GPU_MP3_DECODE = 6 };
 
 #define RG_MAX_SLOTS 8
 #define RG_SLOT_STREAMS 4   // HIP streams the slots are spread over (the runtime has 4 hardware queues by default)
@@ -133,6 +134,14 @@ struct rg_ctx {
     std::vector<RgTmTrack> h_tm_tracks;
 
     DevBuf<unsigned long long> d_peak_bits;  // rg_find_peak_pcm
+    // split MP3 decode (rg_mp3dev.hip): constants, and one chunk's spectra / units / IMDCT halves / track descriptors
+    DevBuf<unsigned char> d_mp3_tab;
+    DevBuf<int16_t> d_mp3_is;
+    DevBuf<unsigned char> d_mp3_units;
+    DevBuf<float> d_mp3_hyb;
+    DevBuf<unsigned char> d_mp3_tracks;
+    bool mp3_tab_ready = false;
+    int gpu_mp3_decode = 0;                  // tuning key 6: 1 = stages B-E of MP3 decoding run on the device
     DevBuf<unsigned char> d_arena;           // staging for host PCM (synchronous API)
     DevBuf<unsigned char> d_ingest[2];       // streamed host ingest: two sub-batch arenas, one filling while the other is analysed
     DevBuf<uint32_t> d_album_packs;          // streamed album: one [histogram | peak] pack per sub-batch, folded at the end

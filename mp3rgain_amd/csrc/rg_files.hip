@@ -26,6 +26,7 @@
 #include "../../include/mp3rgain_amd_dec.h"
 #include "../../include/mp3rgain_amd_mp4.h"
 #include "rg_ctx.h"
+#include "rg_mp3dev_host.h"
 
 // =================================================================================================
 // WAV container (host)
@@ -198,6 +199,12 @@ struct LoadedAudio {
     uint32_t sample_rate = 0, channels = 0;
     uint64_t frames = 0;
     bool decoded = false;       // planar is valid
+    // split decode (tuning key 6): stage A ran on the host, stages B-E will run on the device into the arena
+    std::vector<int16_t> is;
+    std::vector<rg_mp3_unit> units;
+    uint64_t n_units = 0;
+    uint32_t lsf = 0;
+    bool split = false;
 };
 
 size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -258,7 +265,7 @@ int stage_loaded(rg_ctx *c, const std::vector<LoadedAudio> &in, std::vector<rg_t
     for (size_t i = 0; i < n; ++i) {
         rg_track_desc &d = (*descs)[i];
         d.offset_bytes = dst_total;
-        if (in[i].decoded) {
+        if (in[i].decoded || in[i].split) {
             d.frames = in[i].frames;
             d.sample_rate = in[i].sample_rate;
             d.channels = (uint16_t)in[i].channels;
@@ -289,8 +296,22 @@ int stage_loaded(rg_ctx *c, const std::vector<LoadedAudio> &in, std::vector<rg_t
     RG_HIP(c, c->d_wav.reserve(src_total ? src_total : 16));
     RG_HIP(c, c->d_arena.reserve(dst_total ? dst_total : 16));
     hipStream_t fs = c->user_attached ? c->user_stream : c->slot().stream;
+    std::vector<RgMp3SplitItem> split;
     for (size_t i = 0; i < n; ++i) {
         unsigned char *dst = c->d_arena.p + (*descs)[i].offset_bytes;
+        if (in[i].split) {
+            RgMp3SplitItem it{};
+            it.is = in[i].is.data();
+            it.units = in[i].units.data();
+            it.n_units = in[i].n_units;
+            it.channels = in[i].channels;
+            it.rate_row = (uint32_t)rg_mp3_rate_row(in[i].sample_rate);
+            it.lsf = in[i].lsf;
+            it.d_ch0 = reinterpret_cast<float *>(dst);
+            it.d_ch1 = in[i].channels == 2 ? it.d_ch0 + in[i].frames : nullptr;
+            split.push_back(it);
+            continue;
+        }
         if (in[i].decoded) {
             const size_t bytes = (size_t)in[i].frames * in[i].channels * sizeof(float);
             if (bytes) RG_HIP(c, hipMemcpyAsync(dst, in[i].planar.data(), bytes, hipMemcpyHostToDevice, fs));
@@ -300,6 +321,10 @@ int stage_loaded(rg_ctx *c, const std::vector<LoadedAudio> &in, std::vector<rg_t
         if (it.src_len == 0) continue;
         RG_HIP(c, hipMemcpyAsync(c->d_wav.p + it.src_off, it.bytes + it.info.data_offset, it.src_len, hipMemcpyHostToDevice, fs));
         RG_HIP(c, launch_deinterleave(it.kind, c->d_wav.p + it.src_off, dst, it.info.frames, it.info.channels, fs));
+    }
+    if (!split.empty()) {  // the device half of the MP3 decoder writes PCM straight into the arena
+        rc = rg_mp3dev_decode(c, split.data(), split.size(), fs);
+        if (rc != RG_OK) return rc;
     }
     // the host buffers are the caller's locals: the copies must have left them before this returns
     RG_HIP(c, hipStreamSynchronize(fs));
@@ -327,7 +352,7 @@ std::string shell_quote(const char *s) {
 
 // Load one file (no device work; safe to call from several threads at once as long as `err` is per call).
 // RIFF/WAVE: the bytes; MPEG Layer III: decoded planar f32; anything else: the decoder command's stdout.
-int load_audio_for(const std::string &decoder_cmd, const char *path, LoadedAudio *out, std::string *err) {
+int load_audio_for(const std::string &decoder_cmd, bool gpu_decode, const char *path, LoadedAudio *out, std::string *err) {
     char msg[1024];
     auto fail = [&](int code, const char *fmt, const char *a, int b = 0) {
         snprintf(msg, sizeof msg, fmt, a, b);
@@ -350,6 +375,20 @@ int load_audio_for(const std::string &decoder_cmd, const char *path, LoadedAudio
         // the probe (src/replaygain.rs:815-822) and the packet loop (:881-904) for an MPEG audio stream
         rg_mp3_stream_info si;
         if (rg_mp3_scan(bytes.data(), bytes.size(), &si) == RG_MP3DEC_OK && si.audio_frames > 0) {
+            if (gpu_decode) {  // stage A here (frame walk, side info, reservoir, scalefactors, Huffman), the rest on the device
+                const uint64_t cap = (uint64_t)si.audio_frames * (si.mpeg_version == 1 ? 2u : 1u) * si.channels;
+                out->is.assign((size_t)cap * 576, 0);
+                out->units.assign((size_t)cap, rg_mp3_unit{});
+                rg_mp3_stream_info di;
+                const int rc = rg_mp3_parse_units(bytes.data(), bytes.size(), out->is.data(), out->units.data(), cap, &out->n_units, &di);
+                if (rc != RG_MP3DEC_OK) return fail(RG_ERR_FORMAT, "Failed to decode: %s", path);
+                out->sample_rate = di.sample_rate;
+                out->channels = di.channels;
+                out->frames = di.frames;
+                out->lsf = di.mpeg_version == 1 ? 0u : 1u;
+                out->split = true;
+                return RG_OK;
+            }
             out->planar.assign((size_t)si.frames * si.channels, 0.0f);
             rg_mp3_stream_info di;
             const int rc = rg_mp3_decode_f32(bytes.data(), bytes.size(), out->planar.data(),
@@ -386,7 +425,7 @@ int load_audio_for(const std::string &decoder_cmd, const char *path, LoadedAudio
 
 int load_one(rg_ctx *c, const char *path, LoadedAudio *out) {
     std::string err;
-    const int rc = load_audio_for(c->decoder_cmd, path, out, &err);
+    const int rc = load_audio_for(c->decoder_cmd, c->gpu_mp3_decode != 0, path, out, &err);
     if (rc != RG_OK) return rg_set_err(c, rc, "%s", err.c_str());
     return RG_OK;
 }
@@ -405,8 +444,9 @@ int load_many(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedA
     if (workers > n) workers = (unsigned)n;
     std::atomic<size_t> next{0};
     const std::string cmd = c->decoder_cmd;
+    const bool gpu_decode = c->gpu_mp3_decode != 0;
     auto work = [&]() {
-        for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) rcs[i] = load_audio_for(cmd, paths[i], &(*out)[i], &errs[i]);
+        for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) rcs[i] = load_audio_for(cmd, gpu_decode, paths[i], &(*out)[i], &errs[i]);
     };
     if (workers <= 1) {
         work();
@@ -509,4 +549,44 @@ extern "C" int rg_find_peak_amplitude(rg_ctx *c, const char *path, rg_peak_resul
     if (rc != RG_OK) return rc;
     // the arena was produced on the stream rg_find_peak_pcm uses, so no further ordering is needed
     return rg_find_peak_pcm(c, &descs[0], c->d_arena.p, arena_bytes, 1, out);
+}
+
+// Decode one MPEG Layer III stream through the split decoder (stage A on the host, B-E on the device) and bring the PCM
+// back: the parity hook of tests/test_gpu_mp3.py.  Same outputs as rg_mp3_decode_f32.
+extern "C" int rg_mp3_decode_device(rg_ctx *c, const void *data, size_t len, float *ch0, float *ch1, uint64_t capacity,
+                                    void *info) {
+    rg_mp3_stream_info *out = static_cast<rg_mp3_stream_info *>(info);
+    if (!c || !data || !out || !ch0) return RG_ERR_INVALID_ARG;
+    rg_mp3_stream_info si;
+    if (rg_mp3_scan(data, len, &si) != RG_MP3DEC_OK) return rg_set_err(c, RG_ERR_FORMAT, "%s", rg_mp3dec_last_error());
+    const uint64_t cap = (uint64_t)si.audio_frames * (si.mpeg_version == 1 ? 2u : 1u) * si.channels;
+    std::vector<int16_t> is((size_t)cap * 576 + 1);
+    std::vector<rg_mp3_unit> units((size_t)cap + 1);
+    uint64_t n_units = 0;
+    if (rg_mp3_parse_units(data, len, is.data(), units.data(), cap, &n_units, out) != RG_MP3DEC_OK)
+        return rg_set_err(c, RG_ERR_FORMAT, "%s", rg_mp3dec_last_error());
+    if (out->frames > capacity) return rg_set_err(c, RG_ERR_INVALID_ARG, "capacity %llu < %llu frames", (unsigned long long)capacity, (unsigned long long)out->frames);
+    if (out->channels == 2 && !ch1) return rg_set_err(c, RG_ERR_INVALID_ARG, "stereo stream needs a second output channel");
+    int rc = rg_bind_device(c);
+    if (rc != RG_OK) return rc;
+    for (int s = 0; s < c->n_slots; ++s) RG_HIP(c, hipStreamSynchronize(c->slots[s].stream));
+    const size_t bytes = (size_t)out->frames * out->channels * sizeof(float);
+    RG_HIP(c, c->d_arena.reserve(bytes ? bytes : 16));
+    RgMp3SplitItem it{};
+    it.is = is.data();
+    it.units = units.data();
+    it.n_units = n_units;
+    it.channels = out->channels;
+    it.rate_row = (uint32_t)rg_mp3_rate_row(out->sample_rate);
+    it.lsf = out->mpeg_version == 1 ? 0u : 1u;
+    it.d_ch0 = reinterpret_cast<float *>(c->d_arena.p);
+    it.d_ch1 = out->channels == 2 ? it.d_ch0 + out->frames : nullptr;
+    hipStream_t fs = c->slot().stream;
+    rc = rg_mp3dev_decode(c, &it, 1, fs);
+    if (rc != RG_OK) return rc;
+    if (out->frames) {
+        RG_HIP(c, hipMemcpy(ch0, it.d_ch0, (size_t)out->frames * sizeof(float), hipMemcpyDeviceToHost));
+        if (out->channels == 2) RG_HIP(c, hipMemcpy(ch1, it.d_ch1, (size_t)out->frames * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return RG_OK;
 }

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "rg_mp3_tables.h"
+#include "rg_mp3dev.h"
 
 namespace {
 
@@ -737,9 +738,18 @@ void synth(const float S[18][32], ChannelState &cs, const Tables &T, float *pcm 
 // ---------------------------------------------------------------------------------------------------------------
 // the frame loop
 // ---------------------------------------------------------------------------------------------------------------
+// where stage A's output goes when the back half runs elsewhere (rg_mp3_parse_units)
+struct UnitSink {
+    int16_t *is;
+    rg_mp3_unit *units;
+    uint64_t cap, count;
+    bool overflow;
+};
+
 struct Decoder {
     ChannelState ch[2];
     std::vector<uint8_t> reservoir;  // main data of the frames so far (tail kept)
+    UnitSink *sink = nullptr;
     Decoder() {
         memset(ch, 0, sizeof ch);
         reservoir.reserve(8192);
@@ -757,6 +767,7 @@ bool decode_frame(Decoder &D, const uint8_t *f, const Header &h, const Tables &T
     // the frame's own main data joins the reservoir whether or not the frame can be decoded
     D.reservoir.insert(D.reservoir.end(), main, main + main_len);
     bool ok = side_ok && (size_t)si.main_data_begin <= have;
+    const uint64_t sink_mark = D.sink ? D.sink->count : 0;  // a frame that fails half-way leaves no units behind
     if (ok) {
         const size_t begin = have - (size_t)si.main_data_begin;
         const size_t total = D.reservoir.size() - begin;
@@ -778,10 +789,37 @@ bool decode_frame(Decoder &D, const uint8_t *f, const Header &h, const Tables &T
                 int is[576];
                 if (b.pos > b.end) { ok = false; break; }
                 nz[c] = decode_spectrum(b, g, T, is);
-                requantize(is, nz[c], g, D.ch[c].sf[h.lsf ? 0 : gr], h, T, xr[c]);
                 bit += (size_t)g.part2_3_length;
+                if (D.sink) {  // stage A only: hand the quantised values and the granule's parameters over
+                    UnitSink &S = *D.sink;
+                    if (S.count >= S.cap) { S.overflow = true; S.count += 1; continue; }
+                    int16_t *dst = S.is + S.count * 576;
+                    for (int i = 0; i < 576; ++i) dst[i] = (int16_t)(is[i] > 8207 ? 8207 : (is[i] < -8207 ? -8207 : is[i]));
+                    rg_mp3_unit &u = S.units[S.count];
+                    memset(&u, 0, sizeof u);
+                    const int *sf = D.ch[c].sf[h.lsf ? 0 : gr];
+                    for (int i = 0; i < 40; ++i) {
+                        u.sf[i] = (uint8_t)sf[i];
+                        if (D.ch[c].illegal[i]) u.illegal |= 1ull << i;
+                    }
+                    u.nz = (uint16_t)nz[c];
+                    u.global_gain = (uint8_t)g.global_gain;
+                    u.block_type = (uint8_t)g.block_type;
+                    u.mixed = (uint8_t)g.mixed;
+                    for (int k = 0; k < 3; ++k) u.subblock_gain[k] = (uint8_t)g.subblock_gain[k];
+                    u.scalefac_scale = (uint8_t)g.scalefac_scale;
+                    u.preflag = (uint8_t)g.preflag;
+                    u.long_end = (uint8_t)g.long_end;
+                    u.short_start = (uint8_t)g.short_start;
+                    u.mode_ext = (uint8_t)(h.channels == 2 && h.mode == 1 ? h.mode_ext : 0);
+                    u.intensity_scale = (uint8_t)(si.g[gr][h.channels - 1].scalefac_compress & 1);
+                    S.count += 1;
+                    continue;
+                }
+                requantize(is, nz[c], g, D.ch[c].sf[h.lsf ? 0 : gr], h, T, xr[c]);
             }
             if (!ok) break;
+            if (D.sink) continue;
             if (h.channels == 2 && h.mode == 1)
                 stereo(xr, si.g[gr][1], D.ch[1].sf[h.lsf ? 0 : gr], D.ch[1].illegal, nz[0], nz[1], h, T);
             for (int c = 0; c < h.channels; ++c) {
@@ -798,6 +836,7 @@ bool decode_frame(Decoder &D, const uint8_t *f, const Header &h, const Tables &T
             }
         }
     }
+    if (D.sink && !ok) D.sink->count = sink_mark;
     // keep only what a later frame may still reach back to (main_data_begin < 512 bytes)
     if (D.reservoir.size() > 4096) D.reservoir.erase(D.reservoir.begin(), D.reservoir.end() - 2048);
     return ok;
@@ -894,4 +933,68 @@ extern "C" int rg_mp3_decode_f32(const void *data, size_t len, float *ch0, float
     if (stream_channels == 2 && !ch1) return fail(RG_MP3DEC_ERR_ARG, "stereo stream needs a second output channel");
     if (overflow) return fail(RG_MP3DEC_ERR_CAPACITY, "output capacity %llu < %llu frames", (unsigned long long)capacity, (unsigned long long)produced);
     return RG_MP3DEC_OK;
+}
+
+extern "C" int rg_mp3_parse_units(const void *data, size_t len, int16_t *is_out, rg_mp3_unit *units_out, uint64_t capacity_units,
+                                  uint64_t *n_units, rg_mp3_stream_info *out) {
+    if (!data || !out || !n_units || (capacity_units && (!is_out || !units_out))) return fail(RG_MP3DEC_ERR_ARG, "null argument");
+    g_err[0] = 0;
+    const Tables &T = tables();
+    Decoder *D = new Decoder();
+    UnitSink sink{is_out, units_out, capacity_units, 0, false};
+    D->sink = &sink;
+    uint64_t produced = 0;
+    uint32_t decoded = 0, skipped = 0;
+    int stream_channels = 0;
+    const int rc = walk_frames((const uint8_t *)data, len, out, [&](const uint8_t *f, const Header &h) {
+        if (!stream_channels) stream_channels = h.channels;
+        if (h.channels != stream_channels || !decode_frame(*D, f, h, T, nullptr, nullptr)) { ++skipped; return; }
+        ++decoded;
+        produced += (uint64_t)h.samples;
+    });
+    delete D;
+    if (rc != RG_MP3DEC_OK) return rc;
+    out->audio_frames = decoded;
+    out->skipped_frames = skipped;
+    out->frames = produced;
+    *n_units = sink.count;
+    if (sink.overflow) return fail(RG_MP3DEC_ERR_CAPACITY, "unit capacity %llu < %llu", (unsigned long long)capacity_units, (unsigned long long)sink.count);
+    return RG_MP3DEC_OK;
+}
+
+// The device half's constants, from the tables above (rg_mp3dev.h): same numbers on both sides.
+extern "C" void rg_mp3_fill_device_tables(RgMp3DevTables *o) {
+    const Tables &T = tables();
+    memset(o, 0, sizeof *o);
+    memcpy(o->pow43, T.pow43, sizeof o->pow43);
+    for (int q = RG_MP3_GAIN_Q_MIN; q <= RG_MP3_GAIN_Q_MAX; ++q) o->gain[q - RG_MP3_GAIN_Q_MIN] = (float)exp2((double)q / 4.0);
+    for (int k = 0; k < 32; ++k) {
+        o->lsf_is[0][k] = (float)exp2(-0.25 * k);
+        o->lsf_is[1][k] = (float)exp2(-0.5 * k);
+    }
+    for (int i = 0; i < 7; ++i) { o->is_l[i] = T.is_ratio_l[i]; o->is_r[i] = T.is_ratio_r[i]; }
+    memcpy(o->cs, T.cs, sizeof o->cs);
+    memcpy(o->ca, T.ca, sizeof o->ca);
+    memcpy(o->win, T.win, sizeof o->win);
+    memcpy(o->imdct36, T.imdct36, sizeof o->imdct36);
+    memcpy(o->imdct12, T.imdct12, sizeof o->imdct12);
+    memcpy(o->matrix, T.matrix, sizeof o->matrix);
+    memcpy(o->D, T.D, sizeof o->D);
+    for (int r = 0; r < 9; ++r) {
+        for (int b = 0; b < 23; ++b) o->sfb_long[r][b] = T.sfb_long[r][b];
+        for (int b = 0; b < 14; ++b) o->sfb_short[r][b] = T.sfb_short[r][b];
+        for (int b = 0; b < 22; ++b)
+            for (int i = T.sfb_long[r][b]; i < T.sfb_long[r][b + 1]; ++i) o->long_band_of_line[r][i] = (uint8_t)b;
+        int pos = 0;
+        for (int b = 0; b < 13; ++b) {
+            const int wd = T.sfb_short[r][b + 1] - T.sfb_short[r][b];
+            for (int w = 0; w < 3; ++w)
+                for (int i = 0; i < wd; ++i) {
+                    o->short_idx_of_line[r][pos + w * wd + i] = (uint8_t)(3 * b + w);
+                    o->short_reorder_src[r][pos + 3 * i + w] = (uint16_t)(pos + w * wd + i);
+                }
+            pos += 3 * wd;
+        }
+    }
+    for (int b = 0; b < 22; ++b) o->pretab[b] = kPretab[b];
 }

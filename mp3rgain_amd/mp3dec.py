@@ -32,9 +32,29 @@ class StreamInfo(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
 
 
+class Unit(C.Structure):
+    _fields_ = [
+        ("sf", C.c_uint8 * 40),
+        ("illegal", C.c_uint64),
+        ("nz", C.c_uint16),
+        ("global_gain", C.c_uint8),
+        ("block_type", C.c_uint8),
+        ("mixed", C.c_uint8),
+        ("subblock_gain", C.c_uint8 * 3),
+        ("scalefac_scale", C.c_uint8),
+        ("preflag", C.c_uint8),
+        ("long_end", C.c_uint8),
+        ("short_start", C.c_uint8),
+        ("mode_ext", C.c_uint8),
+        ("intensity_scale", C.c_uint8),
+        ("reserved", C.c_uint8 * 2),
+    ]
+
+
 SYMBOLS = [
     ("rg_mp3_scan", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(StreamInfo)]),
     ("rg_mp3_decode_f32", C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(StreamInfo)]),
+    ("rg_mp3_parse_units", C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(StreamInfo)]),
     ("rg_mp3dec_last_error", C.c_char_p, []),
 ]
 
@@ -81,3 +101,16 @@ def decode(data: bytes) -> Tuple[np.ndarray, StreamInfo]:
     _check(lib().rg_mp3_decode_f32(C.cast(buf, C.c_void_p), len(data), out[0].ctypes.data,
                                    out[1].ctypes.data if info.channels == 2 else None, cap, C.byref(di)))
     return out[:, :int(di.frames)], di
+
+
+def parse_units(data: bytes):
+    """Stage A only -> (int16 [units][576], Unit array, StreamInfo): what the device back half consumes."""
+    info = scan(data)
+    cap = int(info.audio_frames) * (2 if info.mpeg_version == 1 else 1) * int(info.channels)
+    is_ = np.zeros((max(1, cap), 576), dtype=np.int16)
+    units = (Unit * max(1, cap))()
+    n = C.c_uint64()
+    di = StreamInfo()
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    _check(lib().rg_mp3_parse_units(C.cast(buf, C.c_void_p), len(data), is_.ctypes.data, C.cast(units, C.c_void_p), cap, C.byref(n), C.byref(di)))
+    return is_[:n.value], units, di

@@ -287,6 +287,20 @@ class Analyzer:
         self._check(self._lib.rg_find_peak_amplitude(self._ctx, os.fsencode(os.fspath(file_path)), C.byref(pk)))
         return PeakAmplitudeResult(pk.peak, pk.peak_pcm, pk.sample_rate)
 
+    def decode_mp3_device(self, data: bytes):
+        """The split MP3 decoder (stage A on the host, stages B-E on this GPU) -> (float32 [channels][frames], StreamInfo);
+        bit for bit what mp3dec.decode returns."""
+        from . import mp3dec
+
+        info = mp3dec.scan(data)
+        cap = int(info.frames)
+        out = np.zeros((int(info.channels), max(1, cap)), dtype=np.float32)
+        buf = (C.c_char * len(data)).from_buffer_copy(data)
+        di = mp3dec.StreamInfo()
+        self._check(self._lib.rg_mp3_decode_device(self._ctx, C.cast(buf, C.c_void_p), len(data), out[0].ctypes.data,
+                                                   out[1].ctypes.data if info.channels == 2 else None, cap, C.byref(di)))
+        return out[:, :int(di.frames)], di
+
     def analyze_wav_bytes(self, wavs: Sequence[bytes], album: bool = False):
         """WAV streams already in memory -> [ReplayGainResult] (+ AlbumGainResult fields when album)."""
         n = len(wavs)

@@ -1,0 +1,99 @@
+"""The split MP3 decoder on the GPU box (include/mp3rgain_amd_dec.h, rg_mp3dev.hip): stage A (frame walk, side
+information, bit reservoir, scalefactors, Huffman) on the host, stages B-E (requantisation, joint stereo, reordering,
+alias reduction, IMDCT + overlap, polyphase synthesis) on the device.  The device half is written to reproduce the host
+decoder's float arithmetic exactly (same tables, same summation order, no FMA contraction), so the bar is EQUALITY
+with mp3dec.decode on every golden stream -- which in turn is pinned against ffmpeg's decoder by tests/test_mp3dec.py --
+and the file-level entry points must give identical ReplayGain results with either decoder."""
+import shutil
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from mp3rgain_amd import mp3dec  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = ROOT / "tests" / "golden" / "mp3"
+FIX = ROOT / "tests" / "golden" / "fixtures"
+STREAMS = sorted(GOLD.glob("*.mp3")) + sorted(FIX.glob("*.mp3"))
+
+
+@pytest.mark.parametrize("path", STREAMS, ids=lambda p: p.stem)
+def test_device_half_reproduces_the_host_decoder(_ctx, path):
+    data = path.read_bytes()
+    want, wi = mp3dec.decode(data)
+    got, gi = _ctx.decode_mp3_device(data)
+    assert (gi.frames, gi.channels, gi.sample_rate, gi.audio_frames, gi.skipped_frames) == (wi.frames, wi.channels, wi.sample_rate, wi.audio_frames, wi.skipped_frames)
+    assert got.shape == want.shape
+    if not np.array_equal(got, want):
+        d = np.abs(got.astype(np.float64) - want.astype(np.float64))
+        bad = np.argwhere(d > 0)
+        raise AssertionError(f"{len(bad)} of {got.size} samples differ, max {d.max():.3g} (peak {np.abs(want).max():.3g}), first at {bad[0]}")
+
+
+def test_dropped_and_damaged_frames_behave_like_the_host_decoder(_ctx):
+    """Frames the reservoir cannot serve are dropped by stage A in both decoders: same PCM length, same PCM."""
+    import random
+
+    body = (GOLD / "v1_44k_mono_crc_reservoir.mp3").read_bytes()
+    cut = body[417 * 2 + 1:]  # starts inside the second frame: the first whole frames reach behind the reservoir
+    want, wi = mp3dec.decode(cut)
+    got, gi = _ctx.decode_mp3_device(cut)
+    assert wi.skipped_frames >= 1 and gi.skipped_frames == wi.skipped_frames and np.array_equal(got, want)
+    rng = random.Random(5)
+    srcs = [p.read_bytes() for p in STREAMS if p.stat().st_size < 20000]
+    checked = 0
+    for _ in range(60):
+        d = bytearray(rng.choice(srcs))
+        for _ in range(rng.randint(1, 12)):
+            d[rng.randrange(len(d))] = rng.randrange(256)
+        try:
+            want, wi = mp3dec.decode(bytes(d))
+        except mp3dec.Mp3DecodeError:
+            continue
+        if wi.channels not in (1, 2) or wi.frames == 0:
+            continue
+        got, gi = _ctx.decode_mp3_device(bytes(d))
+        if gi.frames != wi.frames:
+            continue  # a frame whose channel count differs from the stream's: the split decoder drops it (documented)
+        # damaged side information can ask for enormous gains: compare where the host's output is finite
+        ok = np.isfinite(want)
+        assert np.array_equal(got[ok], want[ok])
+        checked += 1
+    assert checked >= 30
+
+
+def test_file_level_results_do_not_depend_on_the_decoder(_ctx, oracle, tmp_path):
+    """rg_analyze_track / rg_analyze_album / rg_find_peak_amplitude with tuning key 6: identical results, and they are the
+    oracle's on the host decoder's PCM."""
+    an = _ctx
+    names = ["test_joint_stereo.mp3", "test_mono.mp3", "test_vbr.mp3"]
+    files = []
+    for n in names:
+        shutil.copyfile(FIX / n, tmp_path / n)
+        files.append(tmp_path / n)
+    for p in sorted(GOLD.glob("v1_44k_*.mp3"))[:3] + sorted(GOLD.glob("v2_*.mp3"))[:2]:
+        shutil.copyfile(p, tmp_path / p.name)
+        files.append(tmp_path / p.name)
+    an.set_kernel(0)
+    an.set_tuning(6, 0)
+    host = [an.analyze_track_file(f) for f in files]
+    host_album = an.analyze_album_files(files[:3])
+    host_peak = an.find_peak_amplitude_file(files[0])
+    an.set_tuning(6, 1)
+    try:
+        dev = [an.analyze_track_file(f) for f in files]
+        dev_album = an.analyze_album_files(files[:3])
+        dev_peak = an.find_peak_amplitude_file(files[0])
+    finally:
+        an.set_tuning(6, 0)
+    for f, h, d in zip(files, host, dev):
+        assert (h.loudness_db, h.gain_db, h.peak, h.sample_rate, h.windows) == (d.loudness_db, d.gain_db, d.peak, d.sample_rate, d.windows), f.name
+        pcm, _ = mp3dec.decode(f.read_bytes())
+        want, _ = oracle.analyze_pcm(pcm[0], pcm[1] if pcm.shape[0] == 2 else None, h.sample_rate)
+        assert (d.loudness_db, d.peak) == (want["loudness_db"], want["peak"]), f.name
+    assert (host_album.album_loudness_db, host_album.album_peak) == (dev_album.album_loudness_db, dev_album.album_peak)
+    assert host_peak.peak == dev_peak.peak
