@@ -256,6 +256,9 @@ extern "C" void rg_destroy(rg_ctx *c) {
     c->d_mp3_units.release();
     c->d_mp3_hyb.release();
     c->d_mp3_tracks.release();
+    c->d_mp3_huff.release();
+    c->d_mp3_recs.release();
+    c->d_mp3_main.release();
     c->d_ingest[0].release();
     c->d_ingest[1].release();
     c->d_album_packs.release();
@@ -304,7 +307,7 @@ extern "C" int rg_set_tuning(rg_ctx *c, int key, int64_t value) {
         case RG_TUNE_TM_TARGET_LANES: c->tune_tm_target_lanes = (uint64_t)value; return RG_OK;
         case RG_TUNE_TM_WINDOWS: c->tune_tm_windows = (uint32_t)(value > 255 ? 255 : value); return RG_OK;
         case RG_TUNE_INGEST_CHUNK_KIB: c->tune_ingest_chunk_kib = (uint64_t)value; return RG_OK;
-        case RG_TUNE_GPU_MP3_DECODE: c->gpu_mp3_decode = value ? 1 : 0; return RG_OK;
+        case RG_TUNE_GPU_MP3_DECODE: c->gpu_mp3_decode = value > 2 ? 2 : (int)value; return RG_OK;
         case RG_TUNE_PIPELINE_SLOTS: {
             if (sync_all(c) != RG_OK) return RG_ERR_DEVICE;
             c->n_slots = value == 0 ? RG_DEFAULT_SLOTS : (value > RG_MAX_SLOTS ? RG_MAX_SLOTS : (int)value);

@@ -26,6 +26,7 @@
 #include "../../include/mp3rgain_amd_dec.h"
 #include "../../include/mp3rgain_amd_mp4.h"
 #include "rg_ctx.h"
+#include "rg_mp3dev.h"
 #include "rg_mp3dev_host.h"
 
 // =================================================================================================
@@ -205,6 +206,9 @@ struct LoadedAudio {
     uint64_t n_units = 0;
     uint32_t lsf = 0;
     bool split = false;
+    // tuning key 6 = 2: the host only walks the frames; scalefactors and Huffman run on the device as well
+    std::vector<uint8_t> main_stream;
+    std::vector<RgMp3HuffRec> recs;
 };
 
 size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -303,6 +307,11 @@ int stage_loaded(rg_ctx *c, const std::vector<LoadedAudio> &in, std::vector<rg_t
             RgMp3SplitItem it{};
             it.is = in[i].is.data();
             it.units = in[i].units.data();
+            if (!in[i].recs.empty()) {
+                it.recs = in[i].recs.data();
+                it.main = in[i].main_stream.data();
+                it.main_len = in[i].main_stream.size();
+            }
             it.n_units = in[i].n_units;
             it.channels = in[i].channels;
             it.rate_row = (uint32_t)rg_mp3_rate_row(in[i].sample_rate);
@@ -352,7 +361,7 @@ std::string shell_quote(const char *s) {
 
 // Load one file (no device work; safe to call from several threads at once as long as `err` is per call).
 // RIFF/WAVE: the bytes; MPEG Layer III: decoded planar f32; anything else: the decoder command's stdout.
-int load_audio_for(const std::string &decoder_cmd, bool gpu_decode, const char *path, LoadedAudio *out, std::string *err) {
+int load_audio_for(const std::string &decoder_cmd, int gpu_decode, const char *path, LoadedAudio *out, std::string *err) {
     char msg[1024];
     auto fail = [&](int code, const char *fmt, const char *a, int b = 0) {
         snprintf(msg, sizeof msg, fmt, a, b);
@@ -375,6 +384,18 @@ int load_audio_for(const std::string &decoder_cmd, bool gpu_decode, const char *
         // the probe (src/replaygain.rs:815-822) and the packet loop (:881-904) for an MPEG audio stream
         rg_mp3_stream_info si;
         if (rg_mp3_scan(bytes.data(), bytes.size(), &si) == RG_MP3DEC_OK && si.audio_frames > 0) {
+            if (gpu_decode == 2) {  // only the frame walk here: side information and where each granule's bits are
+                rg_mp3_stream_info di;
+                const int rc = rg_mp3_index_stream(bytes.data(), bytes.size(), &out->main_stream, &out->recs, &di);
+                if (rc != RG_MP3DEC_OK) return fail(RG_ERR_FORMAT, "Failed to decode: %s", path);
+                out->n_units = out->recs.size();
+                out->sample_rate = di.sample_rate;
+                out->channels = di.channels;
+                out->frames = di.frames;
+                out->lsf = di.mpeg_version == 1 ? 0u : 1u;
+                out->split = true;
+                return RG_OK;
+            }
             if (gpu_decode) {  // stage A here (frame walk, side info, reservoir, scalefactors, Huffman), the rest on the device
                 const uint64_t cap = (uint64_t)si.audio_frames * (si.mpeg_version == 1 ? 2u : 1u) * si.channels;
                 out->is.assign((size_t)cap * 576, 0);
@@ -425,7 +446,7 @@ int load_audio_for(const std::string &decoder_cmd, bool gpu_decode, const char *
 
 int load_one(rg_ctx *c, const char *path, LoadedAudio *out) {
     std::string err;
-    const int rc = load_audio_for(c->decoder_cmd, c->gpu_mp3_decode != 0, path, out, &err);
+    const int rc = load_audio_for(c->decoder_cmd, c->gpu_mp3_decode, path, out, &err);
     if (rc != RG_OK) return rg_set_err(c, rc, "%s", err.c_str());
     return RG_OK;
 }
@@ -444,7 +465,7 @@ int load_many(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedA
     if (workers > n) workers = (unsigned)n;
     std::atomic<size_t> next{0};
     const std::string cmd = c->decoder_cmd;
-    const bool gpu_decode = c->gpu_mp3_decode != 0;
+    const int gpu_decode = c->gpu_mp3_decode;
     auto work = [&]() {
         for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) rcs[i] = load_audio_for(cmd, gpu_decode, paths[i], &(*out)[i], &errs[i]);
     };
@@ -560,11 +581,21 @@ extern "C" int rg_mp3_decode_device(rg_ctx *c, const void *data, size_t len, flo
     rg_mp3_stream_info si;
     if (rg_mp3_scan(data, len, &si) != RG_MP3DEC_OK) return rg_set_err(c, RG_ERR_FORMAT, "%s", rg_mp3dec_last_error());
     const uint64_t cap = (uint64_t)si.audio_frames * (si.mpeg_version == 1 ? 2u : 1u) * si.channels;
-    std::vector<int16_t> is((size_t)cap * 576 + 1);
-    std::vector<rg_mp3_unit> units((size_t)cap + 1);
+    std::vector<int16_t> is;
+    std::vector<rg_mp3_unit> units;
+    std::vector<uint8_t> main_stream;
+    std::vector<RgMp3HuffRec> recs;
     uint64_t n_units = 0;
-    if (rg_mp3_parse_units(data, len, is.data(), units.data(), cap, &n_units, out) != RG_MP3DEC_OK)
-        return rg_set_err(c, RG_ERR_FORMAT, "%s", rg_mp3dec_last_error());
+    if (c->gpu_mp3_decode == 2) {
+        if (rg_mp3_index_stream(data, len, &main_stream, &recs, out) != RG_MP3DEC_OK)
+            return rg_set_err(c, RG_ERR_FORMAT, "%s", rg_mp3dec_last_error());
+        n_units = recs.size();
+    } else {
+        is.resize((size_t)cap * 576 + 1);
+        units.resize((size_t)cap + 1);
+        if (rg_mp3_parse_units(data, len, is.data(), units.data(), cap, &n_units, out) != RG_MP3DEC_OK)
+            return rg_set_err(c, RG_ERR_FORMAT, "%s", rg_mp3dec_last_error());
+    }
     if (out->frames > capacity) return rg_set_err(c, RG_ERR_INVALID_ARG, "capacity %llu < %llu frames", (unsigned long long)capacity, (unsigned long long)out->frames);
     if (out->channels == 2 && !ch1) return rg_set_err(c, RG_ERR_INVALID_ARG, "stereo stream needs a second output channel");
     int rc = rg_bind_device(c);
@@ -575,6 +606,11 @@ extern "C" int rg_mp3_decode_device(rg_ctx *c, const void *data, size_t len, flo
     RgMp3SplitItem it{};
     it.is = is.data();
     it.units = units.data();
+    if (c->gpu_mp3_decode == 2) {
+        it.recs = recs.data();
+        it.main = main_stream.data();
+        it.main_len = main_stream.size();
+    }
     it.n_units = n_units;
     it.channels = out->channels;
     it.rate_row = (uint32_t)rg_mp3_rate_row(out->sample_rate);

@@ -30,6 +30,42 @@ struct RgMp3DevTables {
     uint8_t pretab[24];
 };
 
+// Flattened Huffman look-up tables as the host decoder builds them (rg_mp3dec.cpp: HuffLut): per table a primary
+// array of 2^primary_bits entries, long codes continue in secondary arrays.  Entry: leaf = len | xy << 8,
+// link = 0x80000000 | sub_bits | offset << 8 (offset relative to the table's own base).
+struct RgMp3DevHuff {
+    uint32_t base[32];          // first entry of table t in `e`
+    uint8_t primary_bits[32];   // 0 = the table is empty (all zeros)
+    uint8_t linbits[32];
+    uint8_t quadA[64];          // count1 table A: 6 peeked bits -> len << 4 | vwxy
+    uint32_t n_entries;
+    uint32_t e[14000];
+};
+
+// One granule of one channel of a decodable frame, as the host's frame indexer hands it to the device Huffman
+// stage: where its bits are in the track's contiguous main-data stream, and its side information.
+struct RgMp3HuffRec {
+    uint64_t bit_off;          // first bit of part 2 (scalefactors), relative to the batch's main-data buffer
+    uint64_t frame_end_bit;    // end of the frame's own main data: bits at or past it read as zero (the host decoder
+                               // works on a copy that ends there)
+    uint16_t part2_3_length;
+    uint16_t big_values;
+    uint16_t scalefac_compress;
+    uint8_t global_gain;
+    uint8_t block_type;
+    uint8_t mixed;
+    uint8_t table_select[3];
+    uint8_t subblock_gain[3];
+    uint8_t region0_count, region1_count;
+    uint8_t preflag, scalefac_scale, count1table;
+    uint8_t scfsi;             // bit k: group k of granule 1 reuses granule 0's scalefactors (MPEG-1)
+    uint8_t gr;
+    uint8_t mode_ext;          // joint stereo only, else 0
+    uint8_t intensity_right;   // LSF: this is the right channel of an intensity-stereo frame
+    uint8_t intensity_scale;   // low bit of the right channel's scalefac_compress
+    uint8_t pad_[7];
+};                             // 48 bytes
+
 struct RgMp3DevTrack {
     uint64_t unit_base;      // first unit of the track in the batch's unit / spectrum arrays
     uint32_t granule_base;   // first granule of the track in the batch's granule numbering
@@ -37,16 +73,24 @@ struct RgMp3DevTrack {
     uint32_t channels;
     uint32_t rate_row;
     uint32_t lsf;
-    uint32_t pad_;
+    uint32_t fc_base;        // first (frame, channel) pair of the track: one Huffman-stage thread each
     float *ch0;              // PCM outputs (planar); 576 frames per granule
     float *ch1;
+    uint64_t main_base;      // device Huffman stage: byte offset of the track's main-data stream in the chunk buffer
 };
 
 #ifdef __cplusplus
+#include <vector>
+// host (rg_mp3dec.cpp): the frame walk and side information only.  Appends every frame's main data to `main_stream`
+// (what the bit reservoir is made of) and, for the frames the one-shot decoder would decode, one record per granule and
+// channel in decode order.  `bit_base` = bit position of main_stream's first byte in the batch buffer.
+int rg_mp3_index_stream(const void *data, size_t len, std::vector<uint8_t> *main_stream, std::vector<RgMp3HuffRec> *recs,
+                        rg_mp3_stream_info *info);
 extern "C" {
 #endif
-// host: fill the table block (rg_mp3dec.cpp)
+// host: fill the table blocks (rg_mp3dec.cpp)
 void rg_mp3_fill_device_tables(RgMp3DevTables *out);
+void rg_mp3_fill_device_huff(RgMp3DevHuff *out);
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,38 @@ __device__ __forceinline__ uint32_t find_by_unit(const RgMp3DevTrack *__restrict
     return lo;
 }
 
+__device__ __forceinline__ uint32_t find_by_fc(const RgMp3DevTrack *__restrict__ tr, uint32_t n, uint32_t fc) {
+    uint32_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (tr[mid].fc_base <= fc) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// Bit reader over the batch's main-data buffer; bits at or past `limit` (the end of the frame's own main data) read
+// as zero, which is what the host decoder's private copy of the frame's data does.
+struct DevBits {
+    const uint8_t *__restrict__ p;
+    uint64_t pos, end, limit;
+    __device__ __forceinline__ uint32_t window() const {  // 32 bits starting at the byte that holds `pos`
+        const uint64_t byte = pos >> 3;
+        const uint8_t *q = p + byte;
+        uint32_t w = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
+        const int64_t valid = (int64_t)limit - (int64_t)(byte << 3);
+        if (valid < 32) w = valid <= 0 ? 0u : (w & (0xFFFFFFFFu << (32 - (int)valid)));
+        return w;
+    }
+    __device__ __forceinline__ uint32_t peek(int n) const { return (window() << (pos & 7)) >> (32 - n); }  // 1 <= n <= 25
+    __device__ __forceinline__ uint32_t get(int n) {
+        if (n == 0) return 0;
+        const uint32_t v = peek(n);
+        pos += n;
+        return v;
+    }
+    __device__ __forceinline__ uint32_t get1() { return get(1); }
+};
+
 // hyb[unit][half][t][sb]
 __device__ __forceinline__ size_t hyb_index(uint64_t unit, int half, int t, int sb) {
     return (((size_t)unit * 2 + (size_t)half) * 18 + (size_t)t) * 32 + (size_t)sb;
@@ -321,6 +353,196 @@ rg_mp3_synth_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *_
         }
         dst[e] = s;
     }
+}
+
+
+// =====================================================================================================================
+// Stage A's heavy part on the device: scalefactors + Huffman-coded spectrum (rg_mp3dec.cpp: read_scalefactors_v1 /
+// read_scalefactors_lsf / decode_spectrum), one thread per (frame, channel) -- granule 1 of an MPEG-1 frame may reuse
+// granule 0's scalefactors (scfsi), so a thread does its channel's granules in order.  Integer work throughout: the
+// outputs (576 int16 per unit + one rg_mp3_unit) are exactly what rg_mp3_parse_units writes on the host.
+__global__ void __launch_bounds__(64)
+rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *__restrict__ H,
+                      const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks, const RgMp3HuffRec *__restrict__ recs,
+                      const uint8_t *__restrict__ main, rg_mp3_unit *__restrict__ units, int16_t *__restrict__ is, uint32_t total_fc) {
+    const uint32_t fc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (fc >= total_fc) return;
+    const uint32_t ti = find_by_fc(tracks, n_tracks, fc);
+    const RgMp3DevTrack tr = tracks[ti];
+    const uint32_t local = fc - tr.fc_base;
+    const int nch = (int)tr.channels, ngr = tr.lsf ? 1 : 2, rr = (int)tr.rate_row;
+    const uint32_t f = local / nch;
+    const int c = (int)(local % nch);
+    static const uint8_t kSlen0[16] = {0, 0, 0, 0, 3, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4};
+    static const uint8_t kSlen1[16] = {0, 1, 2, 3, 0, 1, 2, 3, 1, 2, 3, 1, 2, 3, 2, 3};
+    static const uint8_t kPart[6][3][4] = {
+        {{6, 5, 5, 5}, {9, 9, 9, 9}, {6, 9, 9, 9}},   {{6, 5, 7, 3}, {9, 9, 12, 6}, {6, 9, 12, 6}},
+        {{11, 10, 0, 0}, {18, 18, 0, 0}, {15, 18, 0, 0}}, {{7, 7, 7, 0}, {12, 12, 12, 0}, {6, 15, 12, 0}},
+        {{6, 6, 6, 3}, {12, 9, 9, 6}, {6, 12, 9, 6}},  {{8, 8, 5, 0}, {15, 12, 9, 0}, {6, 18, 9, 0}}};
+    uint8_t sf0[40];  // granule 0's scalefactors (scfsi)
+    for (int gr = 0; gr < ngr; ++gr) {
+        const uint64_t u = tr.unit_base + ((uint64_t)f * ngr + gr) * nch + c;
+        const RgMp3HuffRec r = recs[u];
+        const uint8_t *__restrict__ tmain = main + tr.main_base;  // the records' bit offsets are relative to the track's stream
+        DevBits b{tmain, r.bit_off, r.bit_off + r.part2_3_length, r.frame_end_bit};
+        uint8_t sf[40];
+        uint64_t illegal = 0;
+        int preflag = r.preflag;
+        // ---- band layout and big_values regions (rg_mp3dec.cpp: parse_side_info, derived part) ----
+        int long_end, short_start;
+        if (r.block_type == 2) {
+            if (r.mixed) { long_end = rr <= 2 ? 8 : 6; short_start = 3; }
+            else { long_end = 0; short_start = 0; }
+        } else { long_end = 22; short_start = 13; }
+        const int bv2 = (int)r.big_values * 2;
+        int r0, r1;
+        if (r.block_type != 0) {
+            r0 = r.block_type == 2 ? 3 * (int)T->sfb_short[rr][3] : (int)T->sfb_long[rr][8];
+            r1 = 576;
+        } else {
+            const int i0 = r.region0_count + 1, i1 = r.region0_count + r.region1_count + 2;
+            r0 = T->sfb_long[rr][i0 > 22 ? 22 : i0];
+            r1 = T->sfb_long[rr][i1 > 22 ? 22 : i1];
+        }
+        const int region_end[3] = {r0 < bv2 ? r0 : bv2, r1 < bv2 ? r1 : bv2, bv2};
+        // ---- scalefactors ----
+        if (!tr.lsf) {
+            const int s1 = kSlen0[r.scalefac_compress & 15], s2 = kSlen1[r.scalefac_compress & 15];
+            if (r.block_type == 2) {
+                int i = 0;
+                if (r.mixed) {
+                    for (; i < 8; ++i) sf[i] = (uint8_t)b.get(s1);
+                    for (int k = 0; k < 9; ++k) sf[i++] = (uint8_t)b.get(s1);
+                    for (int k = 0; k < 18; ++k) sf[i++] = (uint8_t)b.get(s2);
+                } else {
+                    for (int k = 0; k < 18; ++k) sf[i++] = (uint8_t)b.get(s1);
+                    for (int k = 0; k < 18; ++k) sf[i++] = (uint8_t)b.get(s2);
+                }
+                for (; i < 40; ++i) sf[i] = 0;
+            } else {
+                const int lo[5] = {0, 6, 11, 16, 21};
+                for (int k = 0; k < 4; ++k) {
+                    const int bits = k < 2 ? s1 : s2;
+                    if (gr == 1 && ((r.scfsi >> k) & 1)) {
+                        for (int band = lo[k]; band < lo[k + 1]; ++band) sf[band] = sf0[band];
+                    } else {
+                        for (int band = lo[k]; band < lo[k + 1]; ++band) sf[band] = (uint8_t)b.get(bits);
+                    }
+                }
+                for (int i = 21; i < 40; ++i) sf[i] = 0;
+            }
+        } else {
+            int slen[4], set;
+            int sfc = r.scalefac_compress;
+            preflag = 0;
+            if (!r.intensity_right) {
+                if (sfc < 400) { slen[0] = (sfc >> 4) / 5; slen[1] = (sfc >> 4) % 5; slen[2] = (sfc & 15) >> 2; slen[3] = sfc & 3; set = 0; }
+                else if (sfc < 500) { sfc -= 400; slen[0] = (sfc >> 2) / 5; slen[1] = (sfc >> 2) % 5; slen[2] = sfc & 3; slen[3] = 0; set = 1; }
+                else { sfc -= 500; slen[0] = sfc / 3; slen[1] = sfc % 3; slen[2] = 0; slen[3] = 0; set = 2; preflag = 1; }
+            } else {
+                sfc >>= 1;
+                if (sfc < 180) { slen[0] = sfc / 36; slen[1] = (sfc % 36) / 6; slen[2] = (sfc % 36) % 6; slen[3] = 0; set = 3; }
+                else if (sfc < 244) { sfc -= 180; slen[0] = (sfc & 0x3F) >> 4; slen[1] = (sfc & 0xF) >> 2; slen[2] = sfc & 3; slen[3] = 0; set = 4; }
+                else { sfc -= 244; slen[0] = sfc / 3; slen[1] = sfc % 3; slen[2] = 0; slen[3] = 0; set = 5; }
+            }
+            const int kind = r.block_type == 2 ? (r.mixed ? 2 : 1) : 0;
+            int i = 0;
+            for (int k = 0; k < 4; ++k) {
+                const int n = kPart[set][kind][k];
+                for (int q = 0; q < n; ++q, ++i) {
+                    const int v = (int)b.get(slen[k]);
+                    sf[i] = (uint8_t)v;
+                    if (r.intensity_right && slen[k] > 0 && v == (1 << slen[k]) - 1) illegal |= 1ull << i;
+                }
+            }
+            for (; i < 40; ++i) sf[i] = 0;
+        }
+        if (gr == 0)
+            for (int i = 0; i < 40; ++i) sf0[i] = sf[i];
+        // ---- Huffman-coded spectrum ----
+        uint32_t *__restrict__ row = reinterpret_cast<uint32_t *>(is + u * 576);  // two int16 per word
+        int line = 0;
+        for (int reg = 0; reg < 3; ++reg) {
+            const int end = region_end[reg];
+            const int t = r.table_select[reg];
+            const int P = H->primary_bits[t];
+            if (P == 0) {
+                for (; line < end; line += 2) row[line >> 1] = 0u;
+                continue;
+            }
+            const uint32_t *__restrict__ E = H->e + H->base[t];
+            const int linbits = H->linbits[t];
+            while (line < end) {
+                if (b.pos >= b.end) { for (; line < end; line += 2) row[line >> 1] = 0u; break; }
+                uint32_t e = E[b.peek(P)];
+                if (e & 0x80000000u) {
+                    b.pos += P;
+                    e = E[((e >> 8) & 0x7FFFFF) + b.peek((int)(e & 0xFF))];
+                }
+                b.pos += e & 0xFF;
+                int x = (int)((e >> 12) & 15), y = (int)((e >> 8) & 15);
+                if (x) {
+                    if (linbits && x == 15) x += (int)b.get(linbits);
+                    if (b.get1()) x = -x;
+                }
+                if (y) {
+                    if (linbits && y == 15) y += (int)b.get(linbits);
+                    if (b.get1()) y = -y;
+                }
+                row[line >> 1] = ((uint32_t)x & 0xFFFFu) | ((uint32_t)y << 16);
+                line += 2;
+            }
+        }
+        while (line <= 572 && b.pos < b.end) {
+            int v;
+            if (r.count1table) {
+                v = (int)(~b.get(4)) & 15;
+            } else {
+                const uint8_t q = H->quadA[b.peek(6)];
+                b.pos += q >> 4;
+                v = q & 15;
+            }
+            int q4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                q4[k] = (v >> (3 - k)) & 1;
+                if (q4[k] && b.get1()) q4[k] = -1;
+            }
+            if (b.pos > b.end) break;  // the quadruple ran past the granule's bits: stuffing, not data
+            row[line >> 1] = ((uint32_t)q4[0] & 0xFFFFu) | ((uint32_t)q4[1] << 16);
+            row[(line >> 1) + 1] = ((uint32_t)q4[2] & 0xFFFFu) | ((uint32_t)q4[3] << 16);
+            line += 4;
+        }
+        const int nz = line;
+        for (; line < 576; line += 2) row[line >> 1] = 0u;
+        // ---- the unit ----
+        rg_mp3_unit o;
+#pragma unroll
+        for (int i = 0; i < 40; ++i) o.sf[i] = sf[i];
+        o.illegal = illegal;
+        o.nz = (uint16_t)nz;
+        o.global_gain = r.global_gain;
+        o.block_type = r.block_type;
+        o.mixed = r.mixed;
+        o.subblock_gain[0] = r.subblock_gain[0]; o.subblock_gain[1] = r.subblock_gain[1]; o.subblock_gain[2] = r.subblock_gain[2];
+        o.scalefac_scale = r.scalefac_scale;
+        o.preflag = (uint8_t)preflag;
+        o.long_end = (uint8_t)long_end;
+        o.short_start = (uint8_t)short_start;
+        o.mode_ext = r.mode_ext;
+        o.intensity_scale = r.intensity_scale;
+        o.reserved[0] = o.reserved[1] = 0;
+        units[u] = o;
+    }
+}
+
+extern "C" hipError_t rg_launch_mp3_huffman(const RgMp3DevTables *d_tab, const RgMp3DevHuff *d_huff, const RgMp3DevTrack *d_tracks,
+                                            uint32_t n_tracks, const RgMp3HuffRec *d_recs, const uint8_t *d_main, rg_mp3_unit *d_units,
+                                            int16_t *d_is, uint32_t total_fc, hipStream_t s) {
+    if (total_fc == 0) return hipSuccess;
+    hipLaunchKernelGGL(rg_mp3_huffman_kernel, dim3((total_fc + 63) / 64), dim3(64), 0, s, d_tab, d_huff, d_tracks, n_tracks, d_recs,
+                       d_main, d_units, d_is, total_fc);
+    return hipGetLastError();
 }
 
 extern "C" hipError_t rg_launch_mp3_hybrid(const RgMp3DevTables *d_tab, const RgMp3DevTrack *d_tracks, uint32_t n_tracks,

@@ -9,9 +9,15 @@
 
 struct rg_ctx;
 
+struct RgMp3HuffRec;
 struct RgMp3SplitItem {
+    // either stage A's output from the host ...
     const int16_t *is;         // host: [n_units][576]
     const rg_mp3_unit *units;  // host: [n_units]
+    // ... or, when `recs` is set, the frame index only: scalefactors and Huffman run on the device too
+    const RgMp3HuffRec *recs;  // host: [n_units]
+    const uint8_t *main;       // host: the track's main-data stream
+    uint64_t main_len;
     uint64_t n_units;
     uint32_t channels, rate_row, lsf;
     float *d_ch0, *d_ch1;      // device outputs, (n_units / channels) * 576 frames each

@@ -21,8 +21,17 @@ FIX = ROOT / "tests" / "golden" / "fixtures"
 STREAMS = sorted(GOLD.glob("*.mp3")) + sorted(FIX.glob("*.mp3"))
 
 
+# tuning key 6: 1 = scalefactors + Huffman on the host, stages B-E on the device; 2 = the host only walks the frames
+# (headers, side information, where each granule's bits lie), scalefactors and Huffman run on the device as well
+@pytest.fixture(params=[1, 2], ids=["huffman-on-host", "huffman-on-device"])
+def split_mode(_ctx, request):
+    _ctx.set_tuning(6, request.param)
+    yield request.param
+    _ctx.set_tuning(6, 0)
+
+
 @pytest.mark.parametrize("path", STREAMS, ids=lambda p: p.stem)
-def test_device_half_reproduces_the_host_decoder(_ctx, path):
+def test_device_half_reproduces_the_host_decoder(_ctx, path, split_mode):
     data = path.read_bytes()
     want, wi = mp3dec.decode(data)
     got, gi = _ctx.decode_mp3_device(data)
@@ -34,7 +43,7 @@ def test_device_half_reproduces_the_host_decoder(_ctx, path):
         raise AssertionError(f"{len(bad)} of {got.size} samples differ, max {d.max():.3g} (peak {np.abs(want).max():.3g}), first at {bad[0]}")
 
 
-def test_dropped_and_damaged_frames_behave_like_the_host_decoder(_ctx):
+def test_dropped_and_damaged_frames_behave_like_the_host_decoder(_ctx, split_mode):
     """Frames the reservoir cannot serve are dropped by stage A in both decoders: same PCM length, same PCM."""
     import random
 
@@ -66,7 +75,7 @@ def test_dropped_and_damaged_frames_behave_like_the_host_decoder(_ctx):
     assert checked >= 30
 
 
-def test_file_level_results_do_not_depend_on_the_decoder(_ctx, oracle, tmp_path):
+def test_file_level_results_do_not_depend_on_the_decoder(_ctx, oracle, tmp_path, split_mode):
     """rg_analyze_track / rg_analyze_album / rg_find_peak_amplitude with tuning key 6: identical results, and they are the
     oracle's on the host decoder's PCM."""
     an = _ctx
@@ -83,7 +92,7 @@ def test_file_level_results_do_not_depend_on_the_decoder(_ctx, oracle, tmp_path)
     host = [an.analyze_track_file(f) for f in files]
     host_album = an.analyze_album_files(files[:3])
     host_peak = an.find_peak_amplitude_file(files[0])
-    an.set_tuning(6, 1)
+    an.set_tuning(6, split_mode)
     try:
         dev = [an.analyze_track_file(f) for f in files]
         dev_album = an.analyze_album_files(files[:3])
