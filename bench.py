@@ -139,6 +139,46 @@ def roofline_block(frames_per_launch: int, k_ms_sum: float, k_launches: int, k_s
             "algorithmic_bytes_per_launch": algo_bytes // launches_per_step}
 
 
+def mp3_end_to_end(an, nfiles: int) -> dict:
+    """rg_analyze_album over `nfiles` three-minute MP3 files (the frames of tests/golden/mp3/v1_44k_stereo_long.mp3, a
+    dense 320 kb/s 44.1 kHz stereo stream, repeated), with each of the library's three decode routes (tuning key 6)."""
+    import tempfile
+
+    from mp3rgain_amd import mp3dec
+
+    body = (ROOT / "tests" / "golden" / "mp3" / "v1_44k_stereo_long.mp3").read_bytes()
+    one = mp3dec.scan(body)
+    reps = max(1, int(180.0 / (one.frames / one.sample_rate)))
+    stream = body * reps
+    si = mp3dec.scan(stream)
+    tmp = Path(tempfile.mkdtemp(prefix="rg_bench_mp3_"))
+    files = []
+    for k in range(nfiles):
+        p = tmp / f"t{k:04d}.mp3"
+        p.write_bytes(stream)
+        files.append(p)
+    leg = {"workload": f"{nfiles} files x {si.frames / si.sample_rate:.0f} s, 320 kb/s 44.1 kHz stereo Layer III ({len(stream) / 1e6:.1f} MB each), "
+                       "rg_analyze_album(paths): file read + decode + analysis + album percentile",
+           "unit": "stereo samples/s", "routes": {}}
+    try:
+        for mode, name in ((2, "device: host walks frames only"), (1, "split: Huffman on host"), (0, "host decoder")):
+            an.set_tuning(6, mode)
+            an.analyze_album_files(files[:2])
+            t0 = time.perf_counter()
+            res = an.analyze_album_files(files)
+            dt = time.perf_counter() - t0
+            leg["routes"][name] = {"seconds": dt, "value": nfiles * si.frames / dt, "x_real_time": nfiles * si.frames / si.sample_rate / dt,
+                                   "album_loudness_db": res.album_loudness_db}
+    finally:
+        an.set_tuning(6, 2)
+        for p in files:
+            p.unlink()
+        tmp.rmdir()
+    loud = {r["album_loudness_db"] for r in leg["routes"].values()}
+    leg["routes_agree"] = len(loud) == 1
+    return leg
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,6 +200,8 @@ def main() -> int:
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU time budget of each cpu_baseline leg (0 = skip baseline and parity)")
     ap.add_argument("--parity-tracks", type=int, default=16, help="tracks of the batch whose full histogram is compared with the oracle")
     ap.add_argument("--no-configs1", action="store_true", help="skip the secondary configs[1] measurement")
+    ap.add_argument("--no-mp3", action="store_true", help="skip the MP3 end-to-end leg (decode + analysis from compressed files)")
+    ap.add_argument("--mp3-files", type=int, default=64, help="files of the MP3 end-to-end leg (3-minute 320 kb/s streams)")
     ap.add_argument("--configs1-steps", type=int, default=300)
     ap.add_argument("--pre-roll", type=float, default=PRE_ROLL_SECONDS, help="untimed pre-roll before the warm-up steps, seconds of work")
     args = ap.parse_args()
@@ -359,6 +401,15 @@ def main() -> int:
                                "flags": r1[0].flags}}
         del pcm1
 
+    # ---- informational leg on one GPU: from compressed MP3 files to album gain (north_star's "MP3 frame decode to
+    # PCM" in front of the measured path).  Never `value`: it includes file reads, the host's frame walk and PCIe. ----
+    mp3_leg = None
+    if world == 1 and not args.no_mp3 and not album and not args.mixed:
+        try:
+            mp3_leg = mp3_end_to_end(an, args.mp3_files)
+        except Exception as ex:  # noqa: BLE001
+            mp3_leg = {"error": str(ex)}
+
     out = None
     if rank == 0:
         cpu = None
@@ -462,6 +513,7 @@ def main() -> int:
             "cpu_baseline": cpu,
             "parity": parity,
             "configs1": configs1,
+            "mp3_end_to_end": mp3_leg,
             "result": {"loudness_db": res[0].loudness_db if ntr else None, "gain_db": res[0].gain_db if ntr else None,
                        "peak": res[0].peak if ntr else None,
                        "album_loudness_db": alb.album_loudness_db if alb else None,

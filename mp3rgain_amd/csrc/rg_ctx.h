@@ -144,7 +144,8 @@ struct rg_ctx {
     DevBuf<unsigned char> d_mp3_recs;
     DevBuf<unsigned char> d_mp3_main;
     bool mp3_tab_ready = false;
-    int gpu_mp3_decode = 0;                  // tuning key 6: 1 = stages B-E of MP3 decoding run on the device, 2 = scalefactors + Huffman too
+    int gpu_mp3_decode = 2;                  // tuning key 6: 0 = host decoder, 1 = stages B-E of MP3 decoding run on the device,
+                                             // 2 (default) = scalefactors + Huffman too: the host only walks the frames
     DevBuf<unsigned char> d_arena;           // staging for host PCM (synchronous API)
     DevBuf<unsigned char> d_ingest[2];       // streamed host ingest: two sub-batch arenas, one filling while the other is analysed
     DevBuf<uint32_t> d_album_packs;          // streamed album: one [histogram | peak] pack per sub-batch, folded at the end

@@ -68,4 +68,4 @@ for label, src in (("dense 320k synthetic", ROOT / "tests/golden/mp3/v1_44k_ster
         name = ["host decoder                     ", "split: Huffman on host, B-E on GPU", "split: host walks frames only     "][key6]
         print(f"   rg_analyze_album, {name}: {dt:7.3f} s = {nfiles * audio_s / dt:9.0f}x real time, "
               f"{nfiles * si.frames / dt / 1e6:8.1f} M stereo samples/s, album loudness {res.album_loudness_db:.2f} dB")
-    an.set_tuning(6, 0)
+    an.set_tuning(6, 2)
