@@ -171,6 +171,8 @@ def mp3_end_to_end(an, nfiles: int) -> dict:
                 t0 = time.perf_counter()
                 res = an.analyze_album_files(files)
                 dt = min(dt, time.perf_counter() - t0)
+                if os.environ.get("RG_TRACE_FILES"):
+                    print(f"[bench] mode {mode}: {time.perf_counter() - t0:.3f} s", file=sys.stderr)
             leg["routes"][name] = {"seconds": dt, "value": nfiles * si.frames / dt, "x_real_time": nfiles * si.frames / si.sample_rate / dt,
                                    "album_loudness_db": res.album_loudness_db}
     finally:

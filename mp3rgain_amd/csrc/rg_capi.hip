@@ -251,6 +251,8 @@ extern "C" void rg_destroy(rg_ctx *c) {
     c->d_peak_bits.release();
     c->d_arena.release();
     c->d_wav.release();
+    if (c->file_pool && c->file_pool_free) c->file_pool_free(c->file_pool);
+    c->file_pool = nullptr;
     c->d_mp3_tab.release();
     c->d_mp3_is.release();
     c->d_mp3_units.release();

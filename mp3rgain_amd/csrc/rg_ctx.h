@@ -144,6 +144,10 @@ struct rg_ctx {
     DevBuf<unsigned char> d_mp3_recs;
     DevBuf<unsigned char> d_mp3_main;
     bool mp3_tab_ready = false;
+    // host buffers of the file layer (rg_files.hip), kept between calls: freeing and re-mapping hundreds of MB that
+    // were the source of H2D copies cost more than decoding them (munmap of such pages: 0.4 ms per MB)
+    void *file_pool = nullptr;
+    void (*file_pool_free)(void *) = nullptr;
     int gpu_mp3_decode = 2;                  // tuning key 6: 0 = host decoder, 1 = stages B-E of MP3 decoding run on the device,
                                              // 2 (default) = scalefactors + Huffman too: the host only walks the frames
     DevBuf<unsigned char> d_arena;           // staging for host PCM (synchronous API)

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include <atomic>
+#include <chrono>
 #include <thread>
 
 #include "../../include/mp3rgain_amd.h"
@@ -209,7 +210,27 @@ struct LoadedAudio {
     // tuning key 6 = 2: the host only walks the frames; scalefactors and Huffman run on the device as well
     std::vector<uint8_t> main_stream;
     std::vector<RgMp3HuffRec> recs;
+    std::vector<uint8_t> file_bytes;  // the file as read
+    bool is_mp4 = false;
+    // ready for the next file; the vectors keep their capacity
+    void reset() {
+        wav.clear(); planar.clear(); is.clear(); units.clear(); main_stream.clear(); recs.clear(); file_bytes.clear();
+        sample_rate = channels = 0; frames = 0; n_units = 0; lsf = 0;
+        decoded = split = is_mp4 = false;
+    }
 };
+
+// the context's pool of LoadedAudio (rg_ctx::file_pool): entry i serves the i-th file of a call
+std::vector<LoadedAudio> &file_pool(rg_ctx *c, size_t n) {
+    if (!c->file_pool) {
+        c->file_pool = new std::vector<LoadedAudio>();
+        c->file_pool_free = [](void *p) { delete static_cast<std::vector<LoadedAudio> *>(p); };
+    }
+    std::vector<LoadedAudio> &pool = *static_cast<std::vector<LoadedAudio> *>(c->file_pool);
+    if (pool.size() < n) pool.resize(n);
+    for (size_t i = 0; i < n; ++i) pool[i].reset();
+    return pool;
+}
 
 size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
@@ -261,8 +282,7 @@ int stage_wavs(rg_ctx *c, const void *const *wav, const size_t *wav_len, size_t 
 
 // the same for loaded files: WAV items take the de-interleave route, decoded MP3 items are planar f32 already and go
 // straight into the arena
-int stage_loaded(rg_ctx *c, const std::vector<LoadedAudio> &in, std::vector<rg_track_desc> *descs, size_t *arena_bytes) {
-    const size_t n = in.size();
+int stage_loaded(rg_ctx *c, const std::vector<LoadedAudio> &in, size_t n, std::vector<rg_track_desc> *descs, size_t *arena_bytes) {
     std::vector<WavItem> items(n);
     size_t src_total = 0, dst_total = 0;
     descs->assign(n ? n : 1, rg_track_desc{});
@@ -371,7 +391,8 @@ int load_audio_for(const std::string &decoder_cmd, int gpu_decode, const char *p
     if (!path) return fail(RG_ERR_INVALID_ARG, "null path%s", "");
     FILE *f = fopen(path, "rb");
     if (!f) return fail(RG_ERR_IO, "Failed to open: %s", path);  // src/replaygain.rs:804-805
-    std::vector<uint8_t> bytes;
+    std::vector<uint8_t> &bytes = out->file_bytes;
+    bytes.clear();
     const bool ok = read_all(f, &bytes);
     fclose(f);
     if (!ok) return fail(RG_ERR_IO, "Failed to read: %s", path);
@@ -380,6 +401,7 @@ int load_audio_for(const std::string &decoder_cmd, int gpu_decode, const char *p
         return RG_OK;
     }
     const bool mp4 = bytes.size() >= 8 && memcmp(bytes.data() + 4, "ftyp", 4) == 0;
+    out->is_mp4 = rg_mp4_is_mp4_data(bytes.data(), bytes.size()) != 0;  // detect_file_type, src/replaygain.rs:777-783
     if (!mp4) {
         // the probe (src/replaygain.rs:815-822) and the packet loop (:881-904) for an MPEG audio stream
         rg_mp3_stream_info si;
@@ -455,7 +477,6 @@ int load_one(rg_ctx *c, const char *path, LoadedAudio *out) {
 // about 200 s of stereo audio into PCM per second, the GPU analyses 8 million).  Errors keep the reference's order: the
 // first failing file in input order is the one reported (src/replaygain.rs:1055).
 int load_many(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedAudio> *out) {
-    out->assign(n, LoadedAudio());
     std::vector<int> rcs(n, RG_OK);
     std::vector<std::string> errs(n);
     unsigned workers = std::thread::hardware_concurrency();
@@ -467,7 +488,7 @@ int load_many(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedA
     const std::string cmd = c->decoder_cmd;
     const int gpu_decode = c->gpu_mp3_decode;
     auto work = [&]() {
-        for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) rcs[i] = load_audio_for(cmd, gpu_decode, paths[i], &(*out)[i], &errs[i]);
+        for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) rcs[i] = load_audio_for(cmd, gpu_decode, paths[i], &(*out)[i], &errs[i]);  // (*out) holds >= n entries
     };
     if (workers <= 1) {
         work();
@@ -516,19 +537,19 @@ extern "C" int rg_analyze_wav_batch(rg_ctx *c, const void *const *wav, const siz
 
 extern "C" int rg_analyze_track(rg_ctx *c, const char *path, int32_t track_index, rg_track_result *out) {
     if (!c || !out) return RG_ERR_INVALID_ARG;
-    std::vector<LoadedAudio> in(1);
+    std::vector<LoadedAudio> &in = file_pool(c, 1);
     int rc = load_one(c, path, &in[0]);
     if (rc != RG_OK) return rc;
     rc = check_track_index(c, track_index);
     if (rc != RG_OK) return rc;
     std::vector<rg_track_desc> descs;
     size_t arena_bytes = 0;
-    rc = stage_loaded(c, in, &descs, &arena_bytes);
+    rc = stage_loaded(c, in, 1, &descs, &arena_bytes);
     if (rc == RG_ERR_FORMAT) return rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s", path);  // src/replaygain.rs:815-822
     if (rc != RG_OK) return rc;
     rc = rg_analyze_pcm_batch(c, descs.data(), 1, c->d_arena.p, arena_bytes, 1, out, nullptr);
     if (rc != RG_OK) return rc;
-    out->file_type = file_type_of(path);
+    out->file_type = in[0].is_mp4 ? RG_FILE_AAC : RG_FILE_MP3;
     return RG_OK;
 }
 
@@ -536,36 +557,44 @@ extern "C" int rg_analyze_track(rg_ctx *c, const char *path, int32_t track_index
 extern "C" int rg_analyze_album(rg_ctx *c, const char *const *paths, size_t n, int32_t track_index, rg_track_result *tracks_out,
                                 rg_album_result *album_out) {
     if (!c || (n && (!paths || !tracks_out)) || !album_out) return RG_ERR_INVALID_ARG;
-    std::vector<LoadedAudio> in;
+    std::vector<LoadedAudio> &in = file_pool(c, n);
+    const bool trace = getenv("RG_TRACE_FILES") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     int rc = load_many(c, paths, n, &in);
     if (rc != RG_OK) return rc;
     if (n) {
         rc = check_track_index(c, track_index);
         if (rc != RG_OK) return rc;
     }
+    const double t1 = now();
     std::vector<rg_track_desc> descs;
     size_t arena_bytes = 0;
-    rc = stage_loaded(c, in, &descs, &arena_bytes);
+    rc = stage_loaded(c, in, n, &descs, &arena_bytes);
+    if (trace) fprintf(stderr, "[rg_analyze_album] load %.1f ms, stage + device decode %.1f ms\n", (t1 - t0) * 1e3, (now() - t1) * 1e3);
     if (rc == RG_ERR_FORMAT) {  // "input i ..." -> the reference's text with the file's name
         size_t i = 0;
         if (sscanf(c->err.c_str(), "input %zu", &i) == 1 && i < n) return rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s", paths[i]);
     }
     if (rc != RG_OK) return rc;
+    const double t2 = now();
     rc = rg_analyze_album_pcm(c, descs.data(), n, c->d_arena.p, arena_bytes, 1, tracks_out, album_out, nullptr);
     if (rc != RG_OK) return rc;
-    for (size_t i = 0; i < n; ++i) tracks_out[i].file_type = file_type_of(paths[i]);
+    const double t3 = now();
+    for (size_t i = 0; i < n; ++i) tracks_out[i].file_type = in[i].is_mp4 ? RG_FILE_AAC : RG_FILE_MP3;
+    if (trace) fprintf(stderr, "[rg_analyze_album] analysis %.1f ms\n", (t3 - t2) * 1e3);
     return RG_OK;
 }
 
 // find_peak_amplitude (src/replaygain.rs:1140-1249): max |x| over ALL channels, no loudness analysis
 extern "C" int rg_find_peak_amplitude(rg_ctx *c, const char *path, rg_peak_result *out) {
     if (!c || !out) return RG_ERR_INVALID_ARG;
-    std::vector<LoadedAudio> in(1);
+    std::vector<LoadedAudio> &in = file_pool(c, 1);
     int rc = load_one(c, path, &in[0]);
     if (rc != RG_OK) return rc;
     std::vector<rg_track_desc> descs;
     size_t arena_bytes = 0;
-    rc = stage_loaded(c, in, &descs, &arena_bytes);
+    rc = stage_loaded(c, in, 1, &descs, &arena_bytes);
     if (rc == RG_ERR_FORMAT) return rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s", path);
     if (rc != RG_OK) return rc;
     // the arena was produced on the stream rg_find_peak_pcm uses, so no further ordering is needed
