@@ -106,3 +106,30 @@ def test_file_level_results_do_not_depend_on_the_decoder(_ctx, oracle, tmp_path,
         assert (d.loudness_db, d.peak) == (want["loudness_db"], want["peak"]), f.name
     assert (host_album.album_loudness_db, host_album.album_peak) == (dev_album.album_loudness_db, dev_album.album_peak)
     assert host_peak.peak == dev_peak.peak
+
+
+def test_configs0_one_30_second_mp3_through_analyze_track(_ctx, oracle, tmp_path):
+    """BASELINE configs[0]: analyze() on one 30 s 44.1 kHz stereo MP3 file.  The file is the frames of a golden stream
+    repeated to 30 s behind an ID3v2 tag; rg_analyze_track(path) decodes it itself on each of the three routes and the
+    result is the oracle's on the host decoder's PCM, bin for bin; find_peak_amplitude agrees with the PCM's maximum."""
+    an = _ctx
+    body = (GOLD / "v1_44k_ms_mixed.mp3").read_bytes()
+    one = mp3dec.scan(body)
+    reps = int(30.0 * one.sample_rate / one.frames) + 1
+    data = b"ID3\x03\x00\x00\x00\x00\x00\x0a" + bytes(10) + body * reps
+    f = tmp_path / "thirty seconds.mp3"
+    f.write_bytes(data)
+    pcm, info = mp3dec.decode(data)
+    assert info.sample_rate == 44100 and info.channels == 2 and 30.0 <= info.frames / 44100 < 30.3 and info.id3v2_bytes == 20
+    want, _ = oracle.analyze_pcm(pcm[0], pcm[1], 44100)
+    an.set_kernel(0)
+    try:
+        for route in (2, 1, 0):
+            an.set_tuning(6, route)
+            got = an.analyze_track_file(f)
+            assert (got.loudness_db, got.gain_db, got.peak, got.sample_rate) == (want["loudness_db"], want["gain_db"], want["peak"], 44100), route
+            assert got.windows == int(np.ceil(info.frames / 2205)) - 0 or got.windows <= int(np.ceil(info.frames / 2205))
+            pk = an.find_peak_amplitude_file(f)
+            assert pk.peak == float(np.abs(pcm).max()) and pk.sample_rate == 44100
+    finally:
+        an.set_tuning(6, 2)

@@ -36,7 +36,7 @@ def legal_is_positions(g, lsf, rng):
 # decoders may, and ffmpeg's does, use that a short block's predecessor leaves zeros in the last third of its overlap.
 def build_case(name, rate, mode, mode_ext, nframes, seed, *, block_types=(0,), mixed_prob=0.0, bitrate=None, crc=False,
                gg=(150, 165), big=12, lines=(200, 520), huge_every=0, is_cut=None, sfc_lsf=None, stuffing=True,
-               padding_every=0, sbg=False):
+               padding_every=0, sbg=False, return_specs=False):
     rng = random.Random(seed)
     lsf = rate < 32000
     nch = 1 if mode == 3 else 2
@@ -86,7 +86,7 @@ def build_case(name, rate, mode, mode_ext, nframes, seed, *, block_types=(0,), m
     for attempt in range(40):
         try:
             data = B.write_stream(frames, rate, random.Random(seed + 1), stuffing=stuffing)
-            return data
+            return (data, frames) if return_specs else data
         except ValueError:
             for f in frames:
                 for chans in f.granules:
