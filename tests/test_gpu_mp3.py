@@ -75,6 +75,59 @@ def test_dropped_and_damaged_frames_behave_like_the_host_decoder(_ctx, split_mod
     assert checked >= 30
 
 
+def test_damaged_files_through_the_file_level_entry_point(_ctx, tmp_path):
+    """Mutated and truncated files through rg_analyze_track on the device route and on the host route: both fail, or both
+    return the same result; nothing hangs or crashes, and the context stays usable."""
+    import random
+
+    import mp3rgain_amd as rg
+
+    an = _ctx
+    rng = random.Random(99)
+    srcs = [p.read_bytes() for p in STREAMS if p.stat().st_size < 20000]
+    agree = failed = 0
+    for k in range(40):
+        d = bytearray(rng.choice(srcs))
+        kind = rng.randrange(3)
+        if kind == 0:
+            for _ in range(rng.randint(1, 20)):
+                d[rng.randrange(len(d))] = rng.randrange(256)
+        elif kind == 1:
+            d = d[:rng.randrange(8, len(d))]
+        else:
+            a = rng.randrange(len(d))
+            del d[a:a + rng.randint(1, 900)]
+        f = tmp_path / f"damaged{k}.mp3"
+        f.write_bytes(bytes(d))
+        out = []
+        for route in (2, 0):
+            an.set_tuning(6, route)
+            try:
+                r = an.analyze_track_file(f)
+                out.append((r.loudness_db, r.peak, r.sample_rate, r.windows))
+            except rg.ReplayGainError as ex:
+                out.append(("error", ex.code))
+        an.set_tuning(6, 2)
+        if out[0][0] == "error" or out[1][0] == "error":
+            assert out[0][0] == out[1][0] == "error", (k, out)
+            failed += 1
+            continue
+        # the host route spreads / truncates frames whose channel count differs from the stream's, the device route drops
+        # them: only then may the results differ
+        if out[0] != out[1]:
+            try:
+                hi = mp3dec.decode(bytes(d))[1]
+                di = mp3dec.parse_units(bytes(d))[2]
+            except mp3dec.Mp3DecodeError:
+                raise AssertionError((k, out))
+            assert hi.frames != di.frames, (k, out)
+        else:
+            agree += 1
+    assert agree >= 20
+    good = an.analyze_track_file(FIX / "test_vbr.mp3")  # still alive
+    assert good.sample_rate == 44100
+
+
 def test_file_level_results_do_not_depend_on_the_decoder(_ctx, oracle, tmp_path, split_mode):
     """rg_analyze_track / rg_analyze_album / rg_find_peak_amplitude with tuning key 6: identical results, and they are the
     oracle's on the host decoder's PCM."""
