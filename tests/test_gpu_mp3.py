@@ -186,3 +186,33 @@ def test_configs0_one_30_second_mp3_through_analyze_track(_ctx, oracle, tmp_path
             assert pk.peak == float(np.abs(pcm).max()) and pk.sample_rate == 44100
     finally:
         an.set_tuning(6, 2)
+
+
+def test_album_mixing_wav_and_mp3_files(_ctx, oracle, tmp_path):
+    """An album whose files are partly RIFF/WAVE (de-interleaved on the device) and partly MPEG Layer III (decoded on the
+    device): one arena, one batch; the album is the oracle's merge of the per-file histograms, on either decode route."""
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from wavutil import test_signal, wav_bytes
+
+    an = _ctx
+    an.set_kernel(0)
+    chans = test_signal("s16", 44100, 44100 * 2 + 321, 2, seed=3)
+    wav = tmp_path / "a.wav"
+    wav.write_bytes(wav_bytes(chans, 44100, "s16"))
+    files = [wav, FIX / "test_vbr.mp3", GOLD / "v1_44k_ms_mixed.mp3", wav]
+    per = []
+    for f in files:
+        if f.suffix == ".wav":
+            per.append(oracle.analyze_pcm(np.asarray(chans[0], np.int16), np.asarray(chans[1], np.int16), 44100))
+        else:
+            pcm, _ = mp3dec.decode(f.read_bytes())
+            per.append(oracle.analyze_pcm(pcm[0], pcm[1], 44100))
+    want, _ = oracle.album_from_hists([h for _, h in per], [r["peak"] for r, _ in per])
+    try:
+        for route in (2, 0):
+            an.set_tuning(6, route)
+            got = an.analyze_album_files(files)
+            assert (got.album_loudness_db, got.album_gain_db, got.album_peak) == (want["album_loudness_db"], want["album_gain_db"], want["album_peak"])
+            assert [t.loudness_db for t in got.tracks] == [r["loudness_db"] for r, _ in per]
+    finally:
+        an.set_tuning(6, 2)
