@@ -30,6 +30,7 @@
 
 #include "rg_mp3_tables.h"
 #include "rg_mp3dev.h"
+#include "rg_mp3_math.h"
 
 namespace {
 
@@ -165,7 +166,7 @@ struct Tables {
     float win[4][36];                     // IMDCT windows per block type (2 = short, 12 taps used)
     float imdct36[36][18];
     float imdct12[12][6];
-    float matrix[64][32];                 // synthesis matrixing N[i][k]
+    float sec[32];                        // secants of the 32-point DCT behind the synthesis matrixing (rg_mp3_math.h)
     float D[512];                         // synthesis window
 };
 
@@ -254,8 +255,12 @@ const Tables &tables() {
             for (int k = 0; k < 18; ++k) t->imdct36[i][k] = (float)cos(M_PI / 72.0 * (2.0 * i + 1.0 + 18.0) * (2.0 * k + 1.0));
         for (int i = 0; i < 12; ++i)
             for (int k = 0; k < 6; ++k) t->imdct12[i][k] = (float)cos(M_PI / 24.0 * (2.0 * i + 1.0 + 6.0) * (2.0 * k + 1.0));
-        for (int i = 0; i < 64; ++i)
-            for (int k = 0; k < 32; ++k) t->matrix[i][k] = (float)cos((16.0 + i) * (2.0 * k + 1.0) * M_PI / 64.0);
+        {
+            int at = 0;
+            for (int n = 32; n >= 2; n /= 2)
+                for (int k = 0; k < n / 2; ++k) t->sec[at++] = (float)(1.0 / (2.0 * cos(M_PI * (2.0 * k + 1.0) / (2.0 * n))));
+            t->sec[31] = 0.0f;
+        }
         for (int i = 0; i <= 256; ++i) t->D[i] = (float)((double)kMp3SynthWindowQ16[i] / 65536.0);
         for (int i = 1; i < 256; ++i) t->D[512 - i] = (i & 63) ? -t->D[i] : t->D[i];
         T = t;
@@ -686,10 +691,18 @@ void hybrid(const float xr[576], const Granule &g, ChannelState &cs, const Table
         float raw[36];
         const int bt = (g.block_type == 2 && g.mixed && sb < 2) ? 0 : g.block_type;
         if (bt != 2) {
-            for (int i = 0; i < 36; ++i) {
+            // x[17 - i] = -x[i] and x[35 - j] = x[18 + j]: eighteen dot products give all 36 samples
+            for (int p = 0; p < 18; ++p) {
+                const int i = p < 9 ? p : 9 + p;  // 0..8, 18..26
                 float s = 0.0f;
                 for (int k = 0; k < 18; ++k) s += X[k] * T.imdct36[i][k];
-                raw[i] = s * T.win[bt][i];
+                if (p < 9) {
+                    raw[i] = s * T.win[bt][i];
+                    raw[17 - i] = -s * T.win[bt][17 - i];
+                } else {
+                    raw[i] = s * T.win[bt][i];
+                    raw[53 - i] = s * T.win[bt][53 - i];
+                }
             }
         } else {
             for (int i = 0; i < 36; ++i) raw[i] = 0.0f;
@@ -718,11 +731,12 @@ void synth(const float S[18][32], ChannelState &cs, const Tables &T, float *pcm 
         cs.v_off = (cs.v_off - 64) & 1023;
         float *V = cs.V;
         const int o = cs.v_off;
-        for (int i = 0; i < 64; ++i) {
-            float s = 0.0f;
-            for (int k = 0; k < 32; ++k) s += T.matrix[i][k] * S[t][k];
-            V[(o + i) & 1023] = s;
-        }
+        struct Ring {  // the 64 new entries of the FIFO, at offset o of the 1024-entry ring
+            float *V;
+            int o;
+            float &operator[](int i) { return V[(o + i) & 1023]; }
+        } ring{V, o};
+        rg_mp3_matrixing(S[t], ring, T.sec);
         float *dst = pcm + 32 * t;
         for (int j = 0; j < 32; ++j) {
             float s = 0.0f;
@@ -978,7 +992,7 @@ extern "C" void rg_mp3_fill_device_tables(RgMp3DevTables *o) {
     memcpy(o->win, T.win, sizeof o->win);
     memcpy(o->imdct36, T.imdct36, sizeof o->imdct36);
     memcpy(o->imdct12, T.imdct12, sizeof o->imdct12);
-    memcpy(o->matrix, T.matrix, sizeof o->matrix);
+    memcpy(o->sec, T.sec, sizeof o->sec);
     memcpy(o->D, T.D, sizeof o->D);
     for (int r = 0; r < 9; ++r) {
         for (int b = 0; b < 23; ++b) o->sfb_long[r][b] = T.sfb_long[r][b];

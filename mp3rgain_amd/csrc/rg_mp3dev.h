@@ -8,6 +8,7 @@
 
 #define RG_MP3_GAIN_Q_MIN (-512)   // requantisation gains 2^(q/4) are tabulated for q in [RG_MP3_GAIN_Q_MIN, RG_MP3_GAIN_Q_MAX]
 #define RG_MP3_GAIN_Q_MAX 64
+#define RG_MP3_SYNTH_RUN 6        // consecutive granules of one channel per block of the synthesis kernel
 
 // Every constant the device stages use, built once on the host from the very tables the host decoder uses, so that
 // the two halves work with identical numbers.
@@ -20,7 +21,7 @@ struct RgMp3DevTables {
     float win[4][36];
     float imdct36[36][18];
     float imdct12[12][6];
-    float matrix[64][32];
+    float sec[32];                     // secants of the 32-point DCT behind the matrixing (rg_mp3_math.h)
     float D[512];
     uint16_t sfb_long[9][24];
     uint16_t sfb_short[9][16];
@@ -77,6 +78,8 @@ struct RgMp3DevTrack {
     float *ch0;              // PCM outputs (planar); 576 frames per granule
     float *ch1;
     uint64_t main_base;      // device Huffman stage: byte offset of the track's main-data stream in the chunk buffer
+    uint32_t synth_base;     // first block of the track in the synthesis kernel's grid
+    uint32_t pad_;
 };
 
 #ifdef __cplusplus

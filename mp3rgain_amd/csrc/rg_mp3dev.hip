@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include "rg_mp3dev.h"
+#include "rg_mp3_math.h"
 
 namespace {
 
@@ -267,84 +268,96 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
             X[sb * 18 + i] = b * T->cs[i] + a * T->ca[i];
         }
         __syncthreads();
+        // long blocks: x[17 - i] = -x[i], x[35 - j] = x[18 + j] -- eighteen dot products per subband give all 36 samples
+        // (the host computes exactly these eighteen); short blocks: each of the 36 samples on its own
         for (int o = tid; o < 32 * 36; o += 256) {
-            const int sb = o / 36, i = o % 36;
+            const int sb = o / 36, i36 = o % 36;
             const float *Xs = X + sb * 18;
             const int bt = (u.block_type == 2 && u.mixed && sb < 2) ? 0 : (int)u.block_type;
-            float raw;
             if (bt != 2) {
+                if (i36 >= 18) continue;  // eighteen workers per subband
+                const int p = i36;
+                const int i = p < 9 ? p : 9 + p;  // 0..8, 18..26
                 float s = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 18; ++k) s += Xs[k] * T->imdct36[i][k];
-                raw = s * T->win[bt][i];
+                const int j = p < 9 ? 17 - i : 53 - i;  // the mirrored sample
+                const float a = s * T->win[bt][i];
+                const float b = (p < 9 ? -s : s) * T->win[bt][j];
+                hyb[hyb_index(u0 + c, i < 18 ? 0 : 1, i < 18 ? i : i - 18, sb)] = a;
+                hyb[hyb_index(u0 + c, j < 18 ? 0 : 1, j < 18 ? j : j - 18, sb)] = b;
             } else {
-                raw = 0.0f;
+                const int i = i36;
+                float raw = 0.0f;
 #pragma unroll
                 for (int w = 0; w < 3; ++w) {
                     const int ii = i - 6 - 6 * w;
                     if (ii >= 0 && ii < 12) {
-                        float s = 0.0f;
+                        float s2 = 0.0f;
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) s += Xs[3 * k + w] * T->imdct12[ii][k];
-                        raw += s * T->win[2][ii];
+                        for (int k = 0; k < 6; ++k) s2 += Xs[3 * k + w] * T->imdct12[ii][k];
+                        raw += s2 * T->win[2][ii];
                     }
                 }
+                hyb[hyb_index(u0 + c, i < 18 ? 0 : 1, i < 18 ? i : i - 18, sb)] = raw;
             }
-            hyb[hyb_index(u0 + c, i < 18 ? 0 : 1, i < 18 ? i : i - 18, sb)] = raw;
         }
         __syncthreads();
     }
 }
 
+// One block = up to RG_MP3_SYNTH_RUN consecutive granules of one channel of one track: the fifteen time slots of
+// filterbank history are recomputed once per run instead of once per granule, and every time slot's matrixing is one
+// thread running the 32-point DCT of rg_mp3_math.h (the host runs the same code).
 __global__ void __launch_bounds__(256)
 rg_mp3_synth_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks,
-                    const float *__restrict__ hyb, uint64_t first_unit) {
-    __shared__ float S[33][32];   // subband samples of time slots -15 .. 17 relative to this granule
-    __shared__ float V[33][64];
+                    const float *__restrict__ hyb) {
+    constexpr int R = RG_MP3_SYNTH_RUN, SLOTS = 15 + 18 * R;
+    __shared__ float S[SLOTS][32];   // subband samples of time slots -15 .. 18 R - 1 relative to the run's first granule
+    __shared__ float V[SLOTS][64];
     const int tid = threadIdx.x;
-    const uint64_t unit = first_unit + blockIdx.x;
-    const uint32_t ti = find_by_unit(tracks, n_tracks, unit);
-    const RgMp3DevTrack tr = tracks[ti];
-    const uint64_t local = unit - tr.unit_base;
+    uint32_t lo = 0, hi = n_tracks - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (tracks[mid].synth_base <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const RgMp3DevTrack tr = tracks[lo];
     const int nch = (int)tr.channels;
-    const uint32_t g = (uint32_t)(local / nch);
-    const int c = (int)(local % nch);
+    const uint32_t local = blockIdx.x - tr.synth_base;
+    const uint32_t runs = (tr.n_granules + R - 1) / R;
+    const int c = (int)(local / runs);
+    const uint32_t g0 = (local % runs) * R;
+    const int ng = (int)(tr.n_granules - g0 < (uint32_t)R ? tr.n_granules - g0 : (uint32_t)R);
+    const int nslots = 15 + 18 * ng;
     // ---- overlap-add + frequency inversion (rg_mp3dec.cpp: hybrid, tail) -----------------------------------------
-    for (int e = tid; e < 33 * 32; e += 256) {
+    for (int e = tid; e < nslots * 32; e += 256) {
         const int r = e / 32, sb = e % 32;
-        const int slot = r - 15;
-        float v;
-        int t;
-        if (slot >= 0) {
-            t = slot;
-            const float ov = g >= 1 ? hyb[hyb_index(unit - nch, 1, t, sb)] : 0.0f;
+        const int rel = r - 15;                        // time slot relative to granule g0
+        const long long gg = (long long)g0 + (rel >= 0 ? rel / 18 : -1);
+        const int t = rel >= 0 ? rel % 18 : 18 + rel;
+        float v = 0.0f;
+        if (gg >= 0) {
+            const uint64_t unit = tr.unit_base + (uint64_t)gg * nch + c;
+            const float ov = gg >= 1 ? hyb[hyb_index(unit - nch, 1, t, sb)] : 0.0f;
             v = hyb[hyb_index(unit, 0, t, sb)] + ov;
-        } else {
-            t = 18 + slot;
-            if (g >= 1) {
-                const float ov = g >= 2 ? hyb[hyb_index(unit - 2 * nch, 1, t, sb)] : 0.0f;
-                v = hyb[hyb_index(unit - nch, 0, t, sb)] + ov;
-            } else {
-                v = 0.0f;
-            }
         }
         if ((sb & 1) && (t & 1)) v = -v;
         S[r][sb] = v;
     }
     __syncthreads();
-    // ---- polyphase synthesis: matrixing (rg_mp3dec.cpp: synth) ----------------------------------------------------
-    for (int e = tid; e < 33 * 64; e += 256) {
-        const int r = e / 64, i = e % 64;
-        float s = 0.0f;
+    // ---- polyphase synthesis: matrixing, one time slot per thread (rg_mp3dec.cpp: synth) ---------------------------
+    if (tid < nslots) {
+        float x[32];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) s += T->matrix[i][k] * S[r][k];
-        V[r][i] = s;
+        for (int k = 0; k < 32; ++k) x[k] = S[tid][k];
+        float *row = V[tid];
+        rg_mp3_matrixing(x, row, T->sec);
     }
     __syncthreads();
-    float *__restrict__ dst = (c == 0 ? tr.ch0 : tr.ch1) + (size_t)g * 576;
-    for (int e = tid; e < 576; e += 256) {
-        const int t = e / 32, j = e % 32;
-        const int r = 15 + t;
+    float *__restrict__ dst = (c == 0 ? tr.ch0 : tr.ch1) + (size_t)g0 * 576;
+    for (int e = tid; e < ng * 576; e += 256) {
+        const int slot = e / 32, j = e % 32;   // slot = 18 * granule + t
+        const int r = 15 + slot;
         float s = 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -354,7 +367,6 @@ rg_mp3_synth_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *_
         dst[e] = s;
     }
 }
-
 
 // =====================================================================================================================
 // Stage A's heavy part on the device: scalefactors + Huffman-coded spectrum (rg_mp3dec.cpp: read_scalefactors_v1 /
@@ -554,8 +566,8 @@ extern "C" hipError_t rg_launch_mp3_hybrid(const RgMp3DevTables *d_tab, const Rg
 }
 
 extern "C" hipError_t rg_launch_mp3_synth(const RgMp3DevTables *d_tab, const RgMp3DevTrack *d_tracks, uint32_t n_tracks,
-                                          uint64_t n_units, const float *d_hyb, hipStream_t s) {
-    if (n_units == 0) return hipSuccess;
-    hipLaunchKernelGGL(rg_mp3_synth_kernel, dim3((uint32_t)n_units), dim3(256), 0, s, d_tab, d_tracks, n_tracks, d_hyb, 0ull);
+                                          uint32_t n_blocks, const float *d_hyb, hipStream_t s) {
+    if (n_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(rg_mp3_synth_kernel, dim3(n_blocks), dim3(256), 0, s, d_tab, d_tracks, n_tracks, d_hyb);
     return hipGetLastError();
 }

@@ -12,7 +12,7 @@ hipError_t rg_launch_mp3_huffman(const RgMp3DevTables *, const RgMp3DevHuff *, c
                                  const uint8_t *, rg_mp3_unit *, int16_t *, uint32_t, hipStream_t);
 hipError_t rg_launch_mp3_hybrid(const RgMp3DevTables *, const RgMp3DevTrack *, uint32_t, uint32_t, const rg_mp3_unit *,
                                 const int16_t *, float *, hipStream_t);
-hipError_t rg_launch_mp3_synth(const RgMp3DevTables *, const RgMp3DevTrack *, uint32_t, uint64_t, const float *, hipStream_t);
+hipError_t rg_launch_mp3_synth(const RgMp3DevTables *, const RgMp3DevTrack *, uint32_t, uint32_t, const float *, hipStream_t);
 }
 
 namespace {
@@ -54,7 +54,7 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
         while (last < n && (last == first || units + items[last].n_units <= kChunkUnits)) units += items[last++].n_units;
         std::vector<RgMp3DevTrack> tr(last - first);
         uint64_t ub = 0, mainb = 0;
-        uint32_t gb = 0, fcb = 0;
+        uint32_t gb = 0, fcb = 0, sb = 0;
         bool any_recs = false;
         for (size_t i = first; i < last; ++i) {
             const RgMp3SplitItem &it = items[i];
@@ -69,6 +69,8 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
             t.ch0 = it.d_ch0;
             t.ch1 = it.d_ch1;
             t.fc_base = fcb;
+            t.synth_base = sb;
+            sb += ((t.n_granules + RG_MP3_SYNTH_RUN - 1) / RG_MP3_SYNTH_RUN) * t.channels;  // runs of granules x channels
             t.main_base = mainb;
             ub += it.n_units;
             gb += t.n_granules;
@@ -108,7 +110,7 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
             }
             RG_HIP(c, rg_launch_mp3_hybrid(d_tab, d_tr, (uint32_t)tr.size(), gb, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p),
                                            c->d_mp3_is.p, c->d_mp3_hyb.p, s));
-            RG_HIP(c, rg_launch_mp3_synth(d_tab, d_tr, (uint32_t)tr.size(), ub, c->d_mp3_hyb.p, s));
+            RG_HIP(c, rg_launch_mp3_synth(d_tab, d_tr, (uint32_t)tr.size(), sb, c->d_mp3_hyb.p, s));
             // the chunk buffers (and `tr`) are reused by the next chunk
             RG_HIP(c, hipStreamSynchronize(s));
         }
