@@ -270,8 +270,10 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
         __syncthreads();
         // long blocks: x[17 - i] = -x[i], x[35 - j] = x[18 + j] -- eighteen dot products per subband give all 36 samples
         // (the host computes exactly these eighteen); short blocks: each of the 36 samples on its own
+        // consecutive threads take consecutive subbands of one sample index: the table row is a broadcast, the stores
+        // to hyb[unit][half][t][sb] are whole 128-byte lines
         for (int o = tid; o < 32 * 36; o += 256) {
-            const int sb = o / 36, i36 = o % 36;
+            const int sb = o & 31, i36 = o >> 5;
             const float *Xs = X + sb * 18;
             const int bt = (u.block_type == 2 && u.mixed && sb < 2) ? 0 : (int)u.block_type;
             if (bt != 2) {
