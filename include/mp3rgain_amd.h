@@ -181,7 +181,7 @@ int rg_set_kernel(rg_ctx *ctx, int variant);
  * bit, whichever is chosen): 2 (default) = the host only walks the frames (headers, side information, bit reservoir
  * bookkeeping); scalefactors, Huffman, requantisation, joint stereo, IMDCT and the polyphase filterbank run on the GPU
  * and the PCM is written straight into the analysis arena; 1 = scalefactors + Huffman on the host's cores, the rest on
- * the GPU; 0 = the host decoder.  (An album of 64 three-minute 320 kb/s files: 2.4 s / 0.37 s / 0.10 s for 0 / 1 / 2.) */
+ * the GPU; 0 = the host decoder.  (An album of 64 three-minute 320 kb/s files: 1.0 s / 0.15 s / 0.05 s for 0 / 1 / 2.) */
 int rg_set_tuning(rg_ctx *ctx, int key, int64_t value);
 /* diagnostic (host only): variant 2's design for one rate and segment length.  T_out: [L][12],
  * gram_last_out: [78]; either may be NULL.  RG_ERR_INVALID_ARG when no design exists. */
