@@ -124,3 +124,44 @@ def abort_if_any_failed(local_error: Optional[BaseException], group=None) -> Non
     for r, m in enumerate(msgs):
         if m is not None:
             raise AlbumAborted(f"rank {r}: {m}")
+
+
+def analyze_album_files_sharded(analyzer, files: Sequence, group=None, exchange_even_if_alone: bool = False):
+    """analyze_album_with_index (src/replaygain.rs:1044-1074) over files, sharded across the ranks of `group`.
+
+    Every rank passes the same list.  Files are dealt out by size (a proxy for their length: longest first, each to
+    the least loaded rank); each rank decodes and analyses its own on its GPU (MP3 on the device decoder), the ranks
+    agree that nobody failed, exchange the album histogram / peak over the analyzer's RCCL communicator
+    (Analyzer.comm_init_torch must have been called) and every rank returns the whole album: per-file results in input
+    order, album loudness / gain / peak from the merged histogram."""
+    import os
+
+    import torch.distributed as dist
+
+    from .replaygain import AlbumGainResult, ReplayGainError
+
+    files = [os.fspath(f) for f in files]
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    sizes = []
+    for f in files:
+        try:
+            sizes.append(os.path.getsize(f))
+        except OSError:
+            sizes.append(0)  # the rank that owns it reports "Failed to open"
+    mine = shard_indices(len(files), world, rank, frames=sizes)
+    err, local = None, None
+    try:
+        local = analyzer.analyze_album_files([files[i] for i in mine])
+    except ReplayGainError as ex:
+        err = ex
+    abort_if_any_failed(err, group)
+    if world > 1 or exchange_even_if_alone:
+        analyzer.album_exchange()
+        analyzer.album_result_enqueue()
+        alb = analyzer.album_finish()
+        loud, gain, peak = alb.album_loudness_db, alb.album_gain_db, alb.album_peak
+    else:
+        loud, gain, peak = local.album_loudness_db, local.album_gain_db, local.album_peak
+    tracks = gather_track_results(local.tracks, len(files), group, frames=sizes)
+    return AlbumGainResult(tracks, loud, gain, peak)

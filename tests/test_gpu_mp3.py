@@ -216,3 +216,35 @@ def test_album_mixing_wav_and_mp3_files(_ctx, oracle, tmp_path):
             assert [t.loudness_db for t in got.tracks] == [r["loudness_db"] for r, _ in per]
     finally:
         an.set_tuning(6, 2)
+
+
+def test_sharded_album_over_files_with_the_library_communicator(_ctx, oracle, tmp_path):
+    """album.analyze_album_files_sharded: files dealt out by size, per-rank decode + analysis, agreement that nobody
+    failed, RCCL exchange of the album pack, results gathered in input order.  One GPU hosts a 1-rank communicator: the
+    collective is the identity, the call sequence (sync album call -> exchange -> album result) is the real one."""
+    import torch.distributed as dist
+
+    from mp3rgain_amd import album
+    import mp3rgain_amd as rg
+
+    an = _ctx
+    an.set_kernel(0)
+    files = [FIX / "test_vbr.mp3", GOLD / "v1_44k_ms_mixed.mp3", FIX / "test_mono.mp3", GOLD / "v1_44k_stereo_long.mp3"]
+    plain = an.analyze_album_files(files)
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29591", rank=0, world_size=1)
+    try:
+        an.comm_init_torch()
+        got = album.analyze_album_files_sharded(an, files, exchange_even_if_alone=True)
+        assert (got.album_loudness_db, got.album_gain_db, got.album_peak) == (plain.album_loudness_db, plain.album_gain_db, plain.album_peak)
+        assert [t.loudness_db for t in got.tracks] == [t.loudness_db for t in plain.tracks]
+        # a missing file ends the album on every rank before anyone enters the collective
+        with pytest.raises(album.AlbumAborted, match="Failed to open"):
+            album.analyze_album_files_sharded(an, files + [tmp_path / "missing.mp3"], exchange_even_if_alone=True)
+        again = album.analyze_album_files_sharded(an, files, exchange_even_if_alone=True)  # and the context is fine
+        assert again.album_loudness_db == plain.album_loudness_db
+    finally:
+        an.comm_destroy()
+        if own_group:
+            dist.destroy_process_group()
