@@ -85,6 +85,11 @@ typedef struct rg_mp3_unit {
 int rg_mp3_parse_units(const void *data, size_t len, int16_t *is_out, rg_mp3_unit *units_out, uint64_t capacity_units,
                        uint64_t *n_units, rg_mp3_stream_info *out);
 
+/* The frame walk alone (what the default device route runs on the host): how many units and PCM frames the stream
+ * decodes to, decided from headers and side information only.  Must agree with rg_mp3_parse_units / rg_mp3_decode_f32 on
+ * every input, damaged ones included (tests/test_mp3dec.py fuzzes that). */
+int rg_mp3_index_units(const void *data, size_t len, uint64_t *n_units, rg_mp3_stream_info *out);
+
 /* Text of the last error of the calling thread ("" if none). */
 const char *rg_mp3dec_last_error(void);
 

@@ -1130,3 +1130,12 @@ int rg_mp3_index_stream(const void *data, size_t len, std::vector<uint8_t> *main
     out->frames = produced;
     return RG_MP3DEC_OK;
 }
+
+extern "C" int rg_mp3_index_units(const void *data, size_t len, uint64_t *n_units, rg_mp3_stream_info *out) {
+    if (!n_units) return fail(RG_MP3DEC_ERR_ARG, "null argument");
+    std::vector<uint8_t> main_stream;
+    std::vector<RgMp3HuffRec> recs;
+    const int rc = rg_mp3_index_stream(data, len, &main_stream, &recs, out);
+    if (rc == RG_MP3DEC_OK) *n_units = recs.size();
+    return rc;
+}

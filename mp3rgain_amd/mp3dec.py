@@ -55,6 +55,7 @@ SYMBOLS = [
     ("rg_mp3_scan", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(StreamInfo)]),
     ("rg_mp3_decode_f32", C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(StreamInfo)]),
     ("rg_mp3_parse_units", C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(StreamInfo)]),
+    ("rg_mp3_index_units", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(StreamInfo)]),
     ("rg_mp3dec_last_error", C.c_char_p, []),
 ]
 
@@ -114,3 +115,12 @@ def parse_units(data: bytes):
     buf = (C.c_char * len(data)).from_buffer_copy(data)
     _check(lib().rg_mp3_parse_units(C.cast(buf, C.c_void_p), len(data), is_.ctypes.data, C.cast(units, C.c_void_p), cap, C.byref(n), C.byref(di)))
     return is_[:n.value], units, di
+
+
+def index_units(data: bytes):
+    """The frame walk of the device route -> (units, StreamInfo)."""
+    n = C.c_uint64()
+    di = StreamInfo()
+    buf = (C.c_char * max(1, len(data))).from_buffer_copy(data or b"\0")
+    _check(lib().rg_mp3_index_units(C.cast(buf, C.c_void_p), len(data), C.byref(n), C.byref(di)))
+    return int(n.value), di

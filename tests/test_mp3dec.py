@@ -357,6 +357,44 @@ def test_damaged_streams_never_crash():
         assert pcm.shape[1] == info.frames <= mp3dec.scan(bytes(d)).frames
 
 
+def test_frame_index_agrees_with_the_decoders_on_damaged_streams():
+    """The device route decides on the host, from headers and side information alone, which frames decode
+    (rg_mp3_index_stream); the one-shot decoder and rg_mp3_parse_units decide it while decoding.  They must agree on
+    every input: same number of units, same PCM length, same counts of decoded and dropped frames."""
+    rng = random.Random(4242)
+    srcs = [p.read_bytes() for p in STREAMS]
+    compared = 0
+    for k in range(1500):
+        d = bytearray(rng.choice(srcs))
+        kind = rng.randrange(5)
+        if kind == 0:
+            for _ in range(rng.randint(1, 40)):
+                d[rng.randrange(len(d))] = rng.randrange(256)
+        elif kind == 1:
+            d = d[:rng.randrange(len(d))]
+        elif kind == 2:
+            a = rng.randrange(len(d))
+            del d[a:a + rng.randint(1, 1200)]
+        elif kind == 3:
+            a = rng.randrange(len(d))
+            d[a:a] = bytes(rng.randrange(256) for _ in range(rng.randint(1, 300)))
+        else:  # flip bits inside side information: part2_3_length, big_values, block types, table selects
+            for _ in range(rng.randint(1, 6)):
+                a = rng.randrange(len(d))
+                d[a] ^= 1 << rng.randrange(8)
+        d = bytes(d)
+        try:
+            n_idx, ii = mp3dec.index_units(d)
+        except mp3dec.Mp3DecodeError:
+            with pytest.raises(mp3dec.Mp3DecodeError):
+                mp3dec.parse_units(d)
+            continue
+        is_, _, pi = mp3dec.parse_units(d)
+        assert (n_idx, ii.frames, ii.audio_frames, ii.skipped_frames) == (is_.shape[0], pi.frames, pi.audio_frames, pi.skipped_frames), k
+        compared += 1
+    assert compared > 1000
+
+
 def test_library_exports_every_declared_symbol():
     import ctypes as C
 
