@@ -278,6 +278,12 @@ int rg_analyze_wav_batch(rg_ctx *ctx, const void *const *wav, const size_t *wav_
                          rg_track_result *out, rg_album_result *album_out);
 /* analyze_track_with_index (src/replaygain.rs:935-941); track_index < 0 = None */
 int rg_analyze_track(rg_ctx *ctx, const char *path, int32_t track_index, rg_track_result *out);
+/* `-r` over many files (src/main.rs:1937-2001 runs analyze_track on one file after the other): the files are loaded on
+ * all host cores and decoded + analysed as one GPU batch.  status_out[i] = RG_OK or file i's error code (its text:
+ * rg_tracks_error(ctx, i)); a failing file does not stop the others.  Results are those of rg_analyze_track per file. */
+int rg_analyze_tracks(rg_ctx *ctx, const char *const *paths, size_t n, int32_t track_index, rg_track_result *out,
+                      int32_t *status_out);
+const char *rg_tracks_error(const rg_ctx *ctx, size_t i);
 /* analyze_album_with_index (src/replaygain.rs:1044-1074): results in input order; the first failing file aborts */
 int rg_analyze_album(rg_ctx *ctx, const char *const *paths, size_t n, int32_t track_index,
                      rg_track_result *tracks_out, rg_album_result *album_out);

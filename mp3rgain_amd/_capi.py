@@ -135,6 +135,8 @@ SYMBOLS = [
     ("rg_analyze_wav_batch", _int, [_vp, _P(_vp), _P(_sz), _sz, _int, _P(TrackResult), _P(AlbumResult)]),
     ("rg_analyze_track", _int, [_vp, C.c_char_p, _i32, _P(TrackResult)]),
     ("rg_analyze_album", _int, [_vp, _P(C.c_char_p), _sz, _i32, _P(TrackResult), _P(AlbumResult)]),
+    ("rg_analyze_tracks", _int, [_vp, C.POINTER(C.c_char_p), C.c_size_t, C.c_int32, _P(TrackResult), C.POINTER(C.c_int32)]),
+    ("rg_tracks_error", C.c_char_p, [_vp, C.c_size_t]),
     ("rg_find_peak_amplitude", _int, [_vp, C.c_char_p, _P(PeakResult)]),
     ("rg_mp3_decode_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
 ]

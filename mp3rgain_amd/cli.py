@@ -276,6 +276,7 @@ class Cli:
     def __init__(self, opts: Options, out, err):
         self.o, self.out, self.err = opts, out, err
         self._an: Optional[rgmod.Analyzer] = None
+        self._batch: Optional[dict] = None  # results of the one batched analysis of all files (analyze_track)
 
     # the GPU context is created on first use: byte-level commands never touch a device
     def analyzer(self) -> rgmod.Analyzer:
@@ -285,6 +286,24 @@ class Cli:
             if dec:
                 self._an.set_decoder_command(dec)
         return self._an
+
+    def analyze_track(self, file):
+        """analyze_track for one file of the command line.  With several files the whole list is analysed once, as one GPU
+        batch (rg_analyze_tracks: the files load on all host cores, decode and analysis run on the device), and every file
+        then finds its result -- or the error it would have raised -- here; the reference analyses file by file
+        (src/main.rs:1937-2001), the results are the same."""
+        files = self.o.files
+        # (a file named twice is analysed again after its first occurrence has been patched, as in the reference: no batch)
+        if len(files) > 1 and len({os.fspath(f) for f in files}) == len(files):
+            if self._batch is None:
+                res = self.analyzer().analyze_track_files(files, self.o.track_index)
+                self._batch = {os.fspath(f): r for f, r in zip(files, res)}
+            r = self._batch.get(os.fspath(file))
+            if r is not None:
+                if isinstance(r, rgmod.ReplayGainError):
+                    raise r
+                return r
+        return self.analyzer().analyze_track_file(file, self.o.track_index)
 
     def p(self, *a):
         print(*a, file=self.out)
@@ -622,7 +641,7 @@ class Cli:
         name = _name(file)
         if o.output_format == "tsv":  # mp3gain-compatible TSV (what beets parses): ReplayGain analysis
             try:
-                rg = self.analyzer().analyze_track_file(file, o.track_index)
+                rg = self.analyze_track(file)
             except rgmod.ReplayGainError as ex:
                 self.e(f"{name} - {ex}")
                 return _file_result(file, status="error", error=str(ex))
@@ -734,7 +753,7 @@ class Cli:
         if self.talk:
             self.p(f"  -> {pre}Analyzing {name}...")
         try:
-            rg = self.analyzer().analyze_track_file(file, o.track_index)
+            rg = self.analyze_track(file)
         except rgmod.ReplayGainError as ex:
             if self.talk:
                 self.e(f"  x {name} - {ex}")

@@ -147,6 +147,7 @@ struct rg_ctx {
     // host buffers of the file layer (rg_files.hip), kept between calls: freeing and re-mapping hundreds of MB that
     // were the source of H2D copies cost more than decoding them (munmap of such pages: 0.4 ms per MB)
     void *file_pool = nullptr;
+    std::vector<std::string> file_errors;    // rg_analyze_tracks: message per file of the last call
     void (*file_pool_free)(void *) = nullptr;
     int gpu_mp3_decode = 2;                  // tuning key 6: 0 = host decoder, 1 = stages B-E of MP3 decoding run on the device,
                                              // 2 (default) = scalefactors + Huffman too: the host only walks the frames

@@ -476,7 +476,8 @@ int load_one(rg_ctx *c, const char *path, LoadedAudio *out) {
 // The files of an album, decoded on the host's cores (decode is by far the longest stage of a real run: one core turns
 // about 200 s of stereo audio into PCM per second, the GPU analyses 8 million).  Errors keep the reference's order: the
 // first failing file in input order is the one reported (src/replaygain.rs:1055).
-int load_many(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedAudio> *out) {
+int load_many(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedAudio> *out, std::vector<int> *rcs_out = nullptr,
+              std::vector<std::string> *errs_out = nullptr) {
     std::vector<int> rcs(n, RG_OK);
     std::vector<std::string> errs(n);
     unsigned workers = std::thread::hardware_concurrency();
@@ -496,6 +497,11 @@ int load_many(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedA
         std::vector<std::thread> pool;
         for (unsigned w = 0; w < workers; ++w) pool.emplace_back(work);
         for (auto &t : pool) t.join();
+    }
+    if (rcs_out) {  // per-file outcome wanted: nothing aborts
+        rcs_out->swap(rcs);
+        errs_out->swap(errs);
+        return RG_OK;
     }
     for (size_t i = 0; i < n; ++i)
         if (rcs[i] != RG_OK) return rg_set_err(c, rcs[i], "%s", errs[i].c_str());
@@ -584,6 +590,83 @@ extern "C" int rg_analyze_album(rg_ctx *c, const char *const *paths, size_t n, i
     for (size_t i = 0; i < n; ++i) tracks_out[i].file_type = in[i].is_mp4 ? RG_FILE_AAC : RG_FILE_MP3;
     if (trace) fprintf(stderr, "[rg_analyze_album] analysis %.1f ms\n", (t3 - t2) * 1e3);
     return RG_OK;
+}
+
+// `-r` over many files (src/main.rs:1937-2001 calls analyze_track for one file after the other; the results are
+// independent): all files are loaded on the host's cores, decoded and analysed as ONE batch on the GPU.  A file that
+// fails (cannot be opened, is no audio, has an unsupported rate) gets its status and message and does not stop the rest.
+extern "C" int rg_analyze_tracks(rg_ctx *c, const char *const *paths, size_t n, int32_t track_index, rg_track_result *out,
+                                 int32_t *status_out) {
+    if (!c || (n && (!paths || !out || !status_out))) return RG_ERR_INVALID_ARG;
+    c->file_errors.assign(n, std::string());
+    std::vector<LoadedAudio> &in = file_pool(c, n);
+    std::vector<int> rcs;
+    std::vector<std::string> errs;
+    int rc = load_many(c, paths, n, &in, &rcs, &errs);
+    if (rc != RG_OK) return rc;
+    // the batch holds the files that loaded and whose rate the analysis knows; `slot` maps them back
+    std::vector<size_t> slot;
+    for (size_t i = 0; i < n; ++i) {
+        memset(&out[i], 0, sizeof out[i]);
+        status_out[i] = rcs[i];
+        c->file_errors[i] = errs[i];
+        if (rcs[i] != RG_OK) continue;
+        if (track_index > 0) {
+            char msg[128];
+            snprintf(msg, sizeof msg, "Track index %d out of range (file has 1 audio track(s))", track_index);
+            status_out[i] = RG_ERR_INVALID_ARG;
+            c->file_errors[i] = msg;
+            continue;
+        }
+        uint32_t rate = in[i].sample_rate;
+        if (!in[i].decoded && !in[i].split) {
+            rg_wav_info wi;
+            rate = rg_wav_parse(in[i].wav.data(), in[i].wav.size(), &wi) == RG_OK ? wi.sample_rate : 0;
+            if (rate == 0) {
+                status_out[i] = RG_ERR_FORMAT;
+                c->file_errors[i] = std::string("Failed to probe format: ") + paths[i];
+                continue;
+            }
+        }
+        if (!rg_supported_rate(rate)) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "Unsupported sample rate: %u Hz. Supported rates: 96000, 88200, 64000, 48000, 44100, 32000, 24000, "
+                                      "22050, 16000, 12000, 11025, 8000", rate);
+            status_out[i] = RG_ERR_UNSUPPORTED_RATE;
+            c->file_errors[i] = msg;
+            continue;
+        }
+        slot.push_back(i);
+    }
+    if (slot.empty()) return RG_OK;
+    // compact the good files to the front of the pool (swap keeps every buffer alive for the next call)
+    for (size_t k = 0; k < slot.size(); ++k)
+        if (slot[k] != k) std::swap(in[k], in[slot[k]]);
+    std::vector<rg_track_desc> descs;
+    size_t arena_bytes = 0;
+    rc = stage_loaded(c, in, slot.size(), &descs, &arena_bytes);
+    if (rc == RG_OK) {
+        std::vector<rg_track_result> res(slot.size());
+        rc = rg_analyze_pcm_batch(c, descs.data(), slot.size(), c->d_arena.p, arena_bytes, 1, res.data(), nullptr);
+        if (rc == RG_OK)
+            for (size_t k = 0; k < slot.size(); ++k) {
+                out[slot[k]] = res[k];
+                out[slot[k]].file_type = in[k].is_mp4 ? RG_FILE_AAC : RG_FILE_MP3;
+            }
+    }
+    if (rc != RG_OK) {  // a failure of the batch itself (a WAV of a kind the library cannot stage, a device error): every file in it carries it
+        for (size_t k = 0; k < slot.size(); ++k) {
+            status_out[slot[k]] = rc;
+            c->file_errors[slot[k]] = c->err;
+        }
+        return RG_OK;
+    }
+    return RG_OK;
+}
+
+extern "C" const char *rg_tracks_error(const rg_ctx *c, size_t i) {
+    if (!c || i >= c->file_errors.size()) return "";
+    return c->file_errors[i].c_str();
 }
 
 // find_peak_amplitude (src/replaygain.rs:1140-1249): max |x| over ALL channels, no loudness analysis

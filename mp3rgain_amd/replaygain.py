@@ -282,6 +282,22 @@ class Analyzer:
         return AlbumGainResult([_to_result(out[i], out[i].file_type) for i in range(n)], alb.album_loudness_db,
                                alb.album_gain_db, alb.album_peak)
 
+    def analyze_track_files(self, files, track_index: Optional[int] = None) -> list:
+        """analyze_track for every file, as ONE GPU batch (files loaded on all host cores).  -> per file a
+        ReplayGainResult, or the ReplayGainError analyze_track_file would have raised for it."""
+        n = len(files)
+        paths = (C.c_char_p * max(1, n))(*[os.fsencode(os.fspath(f)) for f in files])
+        out = (_capi.TrackResult * max(1, n))()
+        status = (C.c_int32 * max(1, n))()
+        self._check(self._lib.rg_analyze_tracks(self._ctx, paths, n, -1 if track_index is None else int(track_index), out, status))
+        res = []
+        for i in range(n):
+            if status[i] == 0:
+                res.append(_to_result(out[i], out[i].file_type))
+            else:
+                res.append(ReplayGainError(int(status[i]), self._lib.rg_tracks_error(self._ctx, i).decode("utf-8", "replace")))
+        return res
+
     def find_peak_amplitude_file(self, file_path) -> PeakAmplitudeResult:
         pk = _capi.PeakResult()
         self._check(self._lib.rg_find_peak_amplitude(self._ctx, os.fsencode(os.fspath(file_path)), C.byref(pk)))

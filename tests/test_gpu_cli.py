@@ -229,3 +229,32 @@ def test_m4a_gets_tags_only(box, oracle):
     assert (t.track_gain, t.track_peak, t.album_gain) == ("%+.2f dB" % w["gain_db"], "%.6f" % w["peak"], None)
     rc, out, _ = run("-n", "-r", f)
     assert "(tags only)" in out or "no adjustment needed" in out
+
+
+def test_track_gain_over_several_files_is_one_batch_with_the_same_output(box, oracle):
+    """-r on a list of files analyses them as one GPU batch (rg_analyze_tracks); what is printed, applied and reported
+    is what -r prints file by file -- including a file that cannot be opened in the middle of the list."""
+    from mp3rgain_amd import mp3gain
+
+    run, mp3, tmp = box
+    a, b, c = mp3("one.mp3"), mp3("quiet.mp3", "test_vbr.mp3"), mp3("three.mp3", "test_mono.mp3")
+    missing = tmp / "missing.mp3"
+    rc, out, err = run("-n", "-r", a, missing, b, c)          # dry run: nothing is written
+    assert rc == 0
+    singles = [run("-n", "-r", f) for f in (a, missing, b, c)]
+    head = "[DRY RUN] mp3rgain Analyzing and would apply track gain to {} file(s)\n  Target: 89 dB (ReplayGain 1.0)\n\n"
+    body = lambda text, n: text[len(head.format(n)):].replace("\n[DRY RUN] No files were modified.\n", "")  # noqa: E731
+    assert body(out, 4) == "".join(body(o, 1) for _, o, _ in singles)
+    assert err == "".join(e for _, _, e in singles) and "Failed to open" in err
+    # json: the same per-file records
+    rc, out, _ = run("-n", "-r", "-o", "json", a, missing, b, c)
+    recs = json.loads(out)["files"]
+    one = [json.loads(run("-n", "-r", "-o", "json", f)[1])["files"][0] for f in (a, missing, b, c)]
+    assert recs == one and recs[1]["status"] == "error"
+    # and for real: every file gets its own gain
+    before = [mp3gain.analyze(f).max_gain for f in (a, b, c)]
+    wants = [want_for(oracle, f)[0]["gain_steps"] for f in (a, b, c)]
+    rc, out, err = run("-r", "-c", a, b, c)
+    assert rc == 0
+    after = [mp3gain.analyze(f).max_gain for f in (a, b, c)]
+    assert after == [max(0, min(255, x + w)) for x, w in zip(before, wants)]
