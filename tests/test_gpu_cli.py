@@ -243,7 +243,9 @@ def test_track_gain_over_several_files_is_one_batch_with_the_same_output(box, or
     assert rc == 0
     singles = [run("-n", "-r", f) for f in (a, missing, b, c)]
     head = "[DRY RUN] mp3rgain Analyzing and would apply track gain to {} file(s)\n  Target: 89 dB (ReplayGain 1.0)\n\n"
-    body = lambda text, n: text[len(head.format(n)):].replace("\n[DRY RUN] No files were modified.\n", "")  # noqa: E731
+    tail = "\nNo files were modified.\n"
+    body = lambda text, n: text[len(head.format(n)):-len(tail)]  # noqa: E731
+    assert out.startswith(head.format(4)) and out.endswith(tail) and all(o.startswith(head.format(1)) and o.endswith(tail) for _, o, _ in singles)
     assert body(out, 4) == "".join(body(o, 1) for _, o, _ in singles)
     assert err == "".join(e for _, _, e in singles) and "Failed to open" in err
     # json: the same per-file records
