@@ -248,3 +248,38 @@ def test_sharded_album_over_files_with_the_library_communicator(_ctx, oracle, tm
         an.comm_destroy()
         if own_group:
             dist.destroy_process_group()
+
+
+def test_analyze_tracks_batch_has_per_file_outcomes(_ctx, oracle, tmp_path):
+    """rg_analyze_tracks: one GPU batch, per-file results equal to rg_analyze_track's, and per-file failures with the
+    reference's texts that leave the other files alone."""
+    import mp3rgain_amd as rg
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from wavutil import test_signal, wav_bytes
+
+    an = _ctx
+    an.set_kernel(0)
+    odd = tmp_path / "odd_rate.wav"
+    odd.write_bytes(wav_bytes(test_signal("s16", 44000, 5000, 2, seed=1), 44000, "s16"))
+    ok_wav = tmp_path / "ok.wav"
+    ok_wav.write_bytes(wav_bytes(test_signal("f32", 48000, 48000 * 2, 2, seed=2), 48000, "f32"))
+    junk = tmp_path / "junk.mp3"
+    junk.write_bytes(b"ID3" + bytes(500))
+    files = [FIX / "test_vbr.mp3", tmp_path / "missing.mp3", ok_wav, odd, GOLD / "v2_22k_stereo.mp3", junk, FIX / "test_mono.mp3"]
+    got = an.analyze_track_files(files)
+    assert len(got) == len(files)
+    for f, g in zip(files, got):
+        try:
+            want = an.analyze_track_file(f)
+        except rg.ReplayGainError as ex:
+            assert isinstance(g, rg.ReplayGainError) and g.code == ex.code and str(g) == str(ex), f.name
+            continue
+        assert not isinstance(g, rg.ReplayGainError), (f.name, g)
+        assert (g.loudness_db, g.gain_db, g.peak, g.sample_rate, g.windows, g.file_type) == (want.loudness_db, want.gain_db, want.peak, want.sample_rate, want.windows, want.file_type), f.name
+    assert [isinstance(g, rg.ReplayGainError) for g in got] == [False, True, False, True, False, True, False]
+    assert "Failed to open" in str(got[1]) and "Unsupported sample rate: 44000 Hz" in str(got[3]) and "Failed to probe format" in str(got[5])
+    # track index > 0: every file reports it
+    idx = an.analyze_track_files(files[:1], track_index=1)
+    assert isinstance(idx[0], rg.ReplayGainError) and "Track index 1 out of range" in str(idx[0])
+    assert an.analyze_track_files([]) == []
