@@ -90,6 +90,12 @@ int rg_mp3_parse_units(const void *data, size_t len, int16_t *is_out, rg_mp3_uni
  * every input, damaged ones included (tests/test_mp3dec.py fuzzes that). */
 int rg_mp3_index_units(const void *data, size_t len, uint64_t *n_units, rg_mp3_stream_info *out);
 
+/* Test hook for the default device route (tuning key 6 = 3), where the host only strips headers and side information
+ * from the stream and the device decides which frames decode: runs that route's host half and the frame logic the device
+ * shares with it (mp3rgain_amd/csrc/rg_mp3_frame.h) on the CPU and compares with rg_mp3_index_units' view of the stream.
+ * 0 = identical, 1 = different, < 0 = no audio. */
+int rg_mp3_index_selfcheck(const void *data, size_t len);
+
 /* Text of the last error of the calling thread ("" if none). */
 const char *rg_mp3dec_last_error(void);
 

@@ -31,6 +31,7 @@
 #include "rg_mp3_tables.h"
 #include "rg_mp3dev.h"
 #include "rg_mp3_math.h"
+#include "rg_mp3_frame.h"
 
 namespace {
 
@@ -1033,42 +1034,11 @@ extern "C" void rg_mp3_fill_device_huff(RgMp3DevHuff *o) {
     memcpy(o->quadA, T.quadA, sizeof o->quadA);
 }
 
-namespace {
-// bits of part 2 (the scalefactors) of a granule, from the side information alone
-int part2_bits(const Granule &g, const Header &h, const int scfsi[4], int gr, bool intensity_right) {
-    if (!h.lsf) {
-        const int s1 = kSlen[0][g.scalefac_compress], s2 = kSlen[1][g.scalefac_compress];
-        if (g.block_type == 2) return g.mixed ? 17 * s1 + 18 * s2 : 18 * s1 + 18 * s2;
-        static const int cnt[4] = {6, 5, 5, 5};
-        int bits = 0;
-        for (int k = 0; k < 4; ++k)
-            if (!(gr == 1 && scfsi[k])) bits += cnt[k] * (k < 2 ? s1 : s2);
-        return bits;
-    }
-    int slen[4], set;
-    int sfc = g.scalefac_compress;
-    if (!intensity_right) {
-        if (sfc < 400) { slen[0] = (sfc >> 4) / 5; slen[1] = (sfc >> 4) % 5; slen[2] = (sfc & 15) >> 2; slen[3] = sfc & 3; set = 0; }
-        else if (sfc < 500) { sfc -= 400; slen[0] = (sfc >> 2) / 5; slen[1] = (sfc >> 2) % 5; slen[2] = sfc & 3; slen[3] = 0; set = 1; }
-        else { sfc -= 500; slen[0] = sfc / 3; slen[1] = sfc % 3; slen[2] = 0; slen[3] = 0; set = 2; }
-    } else {
-        sfc >>= 1;
-        if (sfc < 180) { slen[0] = sfc / 36; slen[1] = (sfc % 36) / 6; slen[2] = (sfc % 36) % 6; slen[3] = 0; set = 3; }
-        else if (sfc < 244) { sfc -= 180; slen[0] = (sfc & 0x3F) >> 4; slen[1] = (sfc & 0xF) >> 2; slen[2] = sfc & 3; slen[3] = 0; set = 4; }
-        else { sfc -= 244; slen[0] = sfc / 3; slen[1] = sfc % 3; slen[2] = 0; slen[3] = 0; set = 5; }
-    }
-    const int kind = g.block_type == 2 ? (g.mixed ? 2 : 1) : 0;
-    int bits = 0;
-    for (int k = 0; k < 4; ++k) bits += kLsfPartitions[set][kind][k] * slen[k];
-    return bits;
-}
-}  // namespace
 
 int rg_mp3_index_stream(const void *data, size_t len, std::vector<uint8_t> *main_stream, std::vector<RgMp3HuffRec> *recs,
                         rg_mp3_stream_info *out) {
     if (!data || !main_stream || !recs || !out) return fail(RG_MP3DEC_ERR_ARG, "null argument");
     g_err[0] = 0;
-    const Tables &T = tables();
     main_stream->clear();
     recs->clear();
     uint64_t produced = 0;
@@ -1076,51 +1046,19 @@ int rg_mp3_index_stream(const void *data, size_t len, std::vector<uint8_t> *main
     int stream_channels = 0;
     const int rc = walk_frames((const uint8_t *)data, len, out, [&](const uint8_t *f, const Header &h) {
         if (!stream_channels) stream_channels = h.channels;
+        uint8_t slot[RG_MP3_SLOT_BYTES] = {0};
         const uint8_t *side = f + 4 + (h.crc ? 2 : 0);
-        SideInfo si;
-        const bool side_ok = parse_side_info(side, h, T, &si);
+        memcpy(slot, f, 4);
+        memcpy(slot + 4, side, (size_t)h.side_bytes);
         const uint8_t *main = side + h.side_bytes;
         const int main_len = h.frame_bytes - (int)(main - f);
         const uint64_t have = main_stream->size();
         main_stream->insert(main_stream->end(), main, main + main_len);  // every frame feeds the reservoir
-        bool ok = side_ok && h.channels == stream_channels && (uint64_t)si.main_data_begin <= have;
-        const size_t mark = recs->size();
-        if (ok) {
-            const uint64_t begin = have - (uint64_t)si.main_data_begin;
-            const uint64_t total_bits = ((uint64_t)si.main_data_begin + (uint64_t)main_len) * 8;
-            uint64_t bit = 0;
-            const int ngr = h.lsf ? 1 : 2;
-            for (int gr = 0; gr < ngr && ok; ++gr)
-                for (int c = 0; c < h.channels; ++c) {
-                    const Granule &g = si.g[gr][c];
-                    const bool ir = h.lsf && c == 1 && h.mode == 1 && (h.mode_ext & 1);
-                    if (bit + (uint64_t)g.part2_3_length > total_bits || part2_bits(g, h, si.scfsi[c], gr, ir) > g.part2_3_length) { ok = false; break; }
-                    RgMp3HuffRec r;
-                    memset(&r, 0, sizeof r);
-                    r.bit_off = begin * 8 + bit;
-                    r.frame_end_bit = (have + (uint64_t)main_len) * 8;
-                    r.part2_3_length = (uint16_t)g.part2_3_length;
-                    r.big_values = (uint16_t)g.big_values;
-                    r.scalefac_compress = (uint16_t)g.scalefac_compress;
-                    r.global_gain = (uint8_t)g.global_gain;
-                    r.block_type = (uint8_t)g.block_type;
-                    r.mixed = (uint8_t)g.mixed;
-                    for (int k = 0; k < 3; ++k) { r.table_select[k] = (uint8_t)g.table_select[k]; r.subblock_gain[k] = (uint8_t)g.subblock_gain[k]; }
-                    r.region0_count = (uint8_t)g.region0_count;
-                    r.region1_count = (uint8_t)g.region1_count;
-                    r.preflag = (uint8_t)g.preflag;
-                    r.scalefac_scale = (uint8_t)g.scalefac_scale;
-                    r.count1table = (uint8_t)g.count1table;
-                    r.scfsi = (uint8_t)(si.scfsi[c][0] | (si.scfsi[c][1] << 1) | (si.scfsi[c][2] << 2) | (si.scfsi[c][3] << 3));
-                    r.gr = (uint8_t)gr;
-                    r.mode_ext = (uint8_t)(h.channels == 2 && h.mode == 1 ? h.mode_ext : 0);
-                    r.intensity_right = (uint8_t)(ir ? 1 : 0);
-                    r.intensity_scale = (uint8_t)(si.g[gr][h.channels - 1].scalefac_compress & 1);
-                    recs->push_back(r);
-                    bit += (uint64_t)g.part2_3_length;
-                }
-        }
-        if (!ok) { recs->resize(mark); ++skipped; return; }
+        RgMp3HuffRec r[4];
+        uint32_t mb = 0;
+        const int n = rg_mp3_frame_records(slot, have, stream_channels, r, &mb);  // rg_mp3_frame.h: the device runs the same code
+        if (n == 0) { ++skipped; return; }
+        recs->insert(recs->end(), r, r + n);
         ++decoded;
         produced += (uint64_t)h.samples;
     });
@@ -1129,6 +1067,65 @@ int rg_mp3_index_stream(const void *data, size_t len, std::vector<uint8_t> *main
     out->skipped_frames = skipped;
     out->frames = produced;
     return RG_MP3DEC_OK;
+}
+
+// Tuning key 6 = 3: the host does not look inside the frames at all.  `data` is compacted IN PLACE into the stream's main
+// data (every walked frame's bytes after header, CRC and side information, back to back from data[0]: the destination
+// never overtakes the walk), and each walked frame leaves one slot (rg_mp3_frame.h: header + side information) in `slots`.
+// Which frames decode, and to what, is the device's business (rg_mp3_frames_kernel).
+int rg_mp3_compact_stream(uint8_t *data, size_t len, std::vector<uint8_t> *slots, uint64_t *main_len_out, rg_mp3_stream_info *out) {
+    if (!data || !slots || !main_len_out || !out) return fail(RG_MP3DEC_ERR_ARG, "null argument");
+    g_err[0] = 0;
+    slots->clear();
+    uint64_t at = 0;
+    uint32_t nframes = 0;
+    const int rc = walk_frames(data, len, out, [&](const uint8_t *f, const Header &h) {
+        const size_t so = slots->size();
+        slots->resize(so + RG_MP3_SLOT_BYTES, 0);
+        const uint8_t *side = f + 4 + (h.crc ? 2 : 0);
+        memcpy(slots->data() + so, f, 4);
+        memcpy(slots->data() + so + 4, side, (size_t)h.side_bytes);
+        const uint8_t *main = side + h.side_bytes;
+        const size_t main_len = (size_t)h.frame_bytes - (size_t)(main - f);
+        memmove(data + at, main, main_len);
+        at += main_len;
+        ++nframes;
+    });
+    if (rc != RG_MP3DEC_OK) return rc;
+    *main_len_out = at;
+    out->audio_frames = nframes;                      // walked; the device decides how many of them decode
+    out->frames = (uint64_t)nframes * out->samples_per_frame;  // upper bound
+    return RG_MP3DEC_OK;
+}
+
+// Test hook: the two frame indexers must tell the same story.  Runs rg_mp3_index_stream (slots interpreted during the
+// walk) and rg_mp3_compact_stream + rg_mp3_frame_records over the slots afterwards (what rg_mp3_frames_kernel does on the
+// device) and compares main data and records.  0 = identical, 1 = different, < 0 = the stream has no audio.
+extern "C" int rg_mp3_index_selfcheck(const void *data, size_t len) {
+    std::vector<uint8_t> main_a, slots;
+    std::vector<RgMp3HuffRec> recs_a, recs_b;
+    rg_mp3_stream_info ia, ib;
+    const int rc = rg_mp3_index_stream(data, len, &main_a, &recs_a, &ia);
+    std::vector<uint8_t> copy((const uint8_t *)data, (const uint8_t *)data + len);
+    uint64_t main_len = 0;
+    const int rc2 = rg_mp3_compact_stream(copy.data(), len, &slots, &main_len, &ib);
+    if (rc != rc2) return 1;
+    if (rc != RG_MP3DEC_OK) return rc;
+    if (main_len != main_a.size() || memcmp(copy.data(), main_a.data(), main_len) != 0) return 1;
+    uint64_t have = 0;
+    uint32_t decoded = 0;
+    const size_t nframes = slots.size() / RG_MP3_SLOT_BYTES;
+    for (size_t f = 0; f < nframes; ++f) {
+        RgMp3HuffRec r[4];
+        uint32_t mb = 0;
+        const int n = rg_mp3_frame_records(slots.data() + f * RG_MP3_SLOT_BYTES, have, (int)ib.channels, r, &mb);
+        have += mb;
+        if (n) { recs_b.insert(recs_b.end(), r, r + n); ++decoded; }
+    }
+    if (have != main_len || decoded != ia.audio_frames || recs_a.size() != recs_b.size()) return 1;
+    if (!recs_a.empty() && memcmp(recs_a.data(), recs_b.data(), recs_a.size() * sizeof(RgMp3HuffRec)) != 0) return 1;
+    if (ia.sample_rate != ib.sample_rate || ia.channels != ib.channels || ia.mpeg_version != ib.mpeg_version || ib.audio_frames != nframes) return 1;
+    return 0;
 }
 
 extern "C" int rg_mp3_index_units(const void *data, size_t len, uint64_t *n_units, rg_mp3_stream_info *out) {

@@ -89,6 +89,9 @@ struct RgMp3DevTrack {
 // channel in decode order.  `bit_base` = bit position of main_stream's first byte in the batch buffer.
 int rg_mp3_index_stream(const void *data, size_t len, std::vector<uint8_t> *main_stream, std::vector<RgMp3HuffRec> *recs,
                         rg_mp3_stream_info *info);
+// host (rg_mp3dec.cpp), tuning key 6 = 3: compacts `data` in place into the stream's main data and leaves one slot
+// (rg_mp3_frame.h) per walked frame; info->frames is an upper bound, the device decides which frames decode.
+int rg_mp3_compact_stream(uint8_t *data, size_t len, std::vector<uint8_t> *slots, uint64_t *main_len, rg_mp3_stream_info *info);
 extern "C" {
 #endif
 // host: fill the table blocks (rg_mp3dec.cpp)

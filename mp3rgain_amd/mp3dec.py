@@ -56,6 +56,7 @@ SYMBOLS = [
     ("rg_mp3_decode_f32", C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(StreamInfo)]),
     ("rg_mp3_parse_units", C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(StreamInfo)]),
     ("rg_mp3_index_units", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(StreamInfo)]),
+    ("rg_mp3_index_selfcheck", C.c_int, [C.c_void_p, C.c_size_t]),
     ("rg_mp3dec_last_error", C.c_char_p, []),
 ]
 
@@ -124,3 +125,9 @@ def index_units(data: bytes):
     buf = (C.c_char * max(1, len(data))).from_buffer_copy(data or b"\0")
     _check(lib().rg_mp3_index_units(C.cast(buf, C.c_void_p), len(data), C.byref(n), C.byref(di)))
     return int(n.value), di
+
+
+def index_selfcheck(data: bytes) -> int:
+    """0 when the device route's host half + shared frame logic agree with `index_units` (rg_mp3_index_selfcheck)."""
+    buf = (C.c_char * max(1, len(data))).from_buffer_copy(data or b"\0")
+    return int(lib().rg_mp3_index_selfcheck(C.cast(buf, C.c_void_p), len(data)))

@@ -383,12 +383,17 @@ def test_frame_index_agrees_with_the_decoders_on_damaged_streams():
                 a = rng.randrange(len(d))
                 d[a] ^= 1 << rng.randrange(8)
         d = bytes(d)
+        # the default device route: the host strips headers and side information, the device (here: the same source on
+        # the CPU, rg_mp3_frame.h) decides frame by frame -- the same main data and records as the host's indexer
+        sc = mp3dec.index_selfcheck(d)
         try:
             n_idx, ii = mp3dec.index_units(d)
         except mp3dec.Mp3DecodeError:
+            assert sc < 0, k
             with pytest.raises(mp3dec.Mp3DecodeError):
                 mp3dec.parse_units(d)
             continue
+        assert sc == 0, k
         is_, _, pi = mp3dec.parse_units(d)
         assert (n_idx, ii.frames, ii.audio_frames, ii.skipped_frames) == (is_.shape[0], pi.frames, pi.audio_frames, pi.skipped_frames), k
         compared += 1
