@@ -163,7 +163,7 @@ def mp3_end_to_end(an, nfiles: int) -> dict:
     try:
         for _ in range(8):  # untimed: every pipeline slot's buffers grow to this batch's size once (grow-only allocations)
             an.analyze_album_files(files)
-        for mode, name in ((2, "device: host walks frames only"), (1, "split: Huffman on host"), (0, "host decoder")):
+        for mode, name in ((3, "device: host strips headers only, pipelined"), (2, "device: host parses side info"), (1, "split: Huffman on host"), (0, "host decoder")):
             an.set_tuning(6, mode)
             an.analyze_album_files(files[:2])
             dt = 1e9
@@ -176,7 +176,7 @@ def mp3_end_to_end(an, nfiles: int) -> dict:
             leg["routes"][name] = {"seconds": dt, "value": nfiles * si.frames / dt, "x_real_time": nfiles * si.frames / si.sample_rate / dt,
                                    "album_loudness_db": res.album_loudness_db}
     finally:
-        an.set_tuning(6, 2)
+        an.set_tuning(6, 3)
         for p in files:
             p.unlink()
         tmp.rmdir()

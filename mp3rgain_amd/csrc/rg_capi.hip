@@ -261,6 +261,15 @@ extern "C" void rg_destroy(rg_ctx *c) {
     c->d_mp3_huff.release();
     c->d_mp3_recs.release();
     c->d_mp3_main.release();
+    if (c->mp3_pipe && c->mp3_pipe_free) c->mp3_pipe_free(c->mp3_pipe);
+    c->mp3_pipe = nullptr;
+    c->d_mp3_stage[0].release();
+    c->d_mp3_stage[1].release();
+    c->d_mp3_results.release();
+    c->h_mp3_results.release();
+    if (c->mp3_copy_stream) (void)hipStreamDestroy(c->mp3_copy_stream);
+    for (int k = 0; k < 2; ++k)
+        if (c->mp3_set_free[k]) (void)hipEventDestroy(c->mp3_set_free[k]);
     c->d_ingest[0].release();
     c->d_ingest[1].release();
     c->d_album_packs.release();
@@ -309,7 +318,7 @@ extern "C" int rg_set_tuning(rg_ctx *c, int key, int64_t value) {
         case RG_TUNE_TM_TARGET_LANES: c->tune_tm_target_lanes = (uint64_t)value; return RG_OK;
         case RG_TUNE_TM_WINDOWS: c->tune_tm_windows = (uint32_t)(value > 255 ? 255 : value); return RG_OK;
         case RG_TUNE_INGEST_CHUNK_KIB: c->tune_ingest_chunk_kib = (uint64_t)value; return RG_OK;
-        case RG_TUNE_GPU_MP3_DECODE: c->gpu_mp3_decode = value > 2 ? 2 : (int)value; return RG_OK;
+        case RG_TUNE_GPU_MP3_DECODE: c->gpu_mp3_decode = value > 3 ? 3 : (int)value; return RG_OK;
         case RG_TUNE_PIPELINE_SLOTS: {
             if (sync_all(c) != RG_OK) return RG_ERR_DEVICE;
             c->n_slots = value == 0 ? RG_DEFAULT_SLOTS : (value > RG_MAX_SLOTS ? RG_MAX_SLOTS : (int)value);

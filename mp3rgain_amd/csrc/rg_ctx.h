@@ -144,12 +144,21 @@ struct rg_ctx {
     DevBuf<unsigned char> d_mp3_recs;
     DevBuf<unsigned char> d_mp3_main;
     bool mp3_tab_ready = false;
+    // tuning key 6 = 3 (rg_mp3dev_enqueue_chunk): two device copies of staging blocks, the per-file results
+    DevBuf<unsigned char> d_mp3_stage[2];
+    hipStream_t mp3_copy_stream = nullptr;   // H2D of staging blocks, beside the kernels of the chunk before
+    hipEvent_t mp3_set_free[2] = {nullptr, nullptr};
+    bool mp3_set_used[2] = {false, false};
+    DevBuf<uint32_t> d_mp3_results;
+    PinnedBuf<uint32_t> h_mp3_results;
+    void *mp3_pipe = nullptr;                // rg_files.hip: pinned staging blocks of the loader pipeline
+    void (*mp3_pipe_free)(void *) = nullptr;
     // host buffers of the file layer (rg_files.hip), kept between calls: freeing and re-mapping hundreds of MB that
     // were the source of H2D copies cost more than decoding them (munmap of such pages: 0.4 ms per MB)
     void *file_pool = nullptr;
     std::vector<std::string> file_errors;    // rg_analyze_tracks: message per file of the last call
     void (*file_pool_free)(void *) = nullptr;
-    int gpu_mp3_decode = 2;                  // tuning key 6: 0 = host decoder, 1 = stages B-E of MP3 decoding run on the device,
+    int gpu_mp3_decode = 3;                  // tuning key 6: 0 = host decoder, 1 = stages B-E of MP3 decoding run on the device,
                                              // 2 (default) = scalefactors + Huffman too: the host only walks the frames
     DevBuf<unsigned char> d_arena;           // staging for host PCM (synchronous API)
     DevBuf<unsigned char> d_ingest[2];       // streamed host ingest: two sub-batch arenas, one filling while the other is analysed

@@ -12,15 +12,23 @@
 //     stream to stdout (rg_set_decoder_command, e.g. "ffmpeg -v error -i {} -f wav -c:a pcm_f32le -").
 // Everything after the arena is the same path as rg_analyze_pcm_batch.
 #include <errno.h>
+#include <fcntl.h>
 #include <sched.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <string>
 #include <vector>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <thread>
 
 #include "../../include/mp3rgain_amd.h"
@@ -29,6 +37,7 @@
 #include "rg_ctx.h"
 #include "rg_mp3dev.h"
 #include "rg_mp3dev_host.h"
+#include "rg_mp3_frame.h"
 
 // =================================================================================================
 // WAV container (host)
@@ -212,11 +221,17 @@ struct LoadedAudio {
     std::vector<RgMp3HuffRec> recs;
     std::vector<uint8_t> file_bytes;  // the file as read
     bool is_mp4 = false;
+    // tuning key 6 = 3: the loader pipeline has decoded the stream into the arena already (planar f32 at arena_off);
+    // `frames` is what the device found decodable
+    bool staged = false;
+    uint64_t arena_off = 0;
+    uint32_t walked_frames = 0, result_index = 0;
     // ready for the next file; the vectors keep their capacity
     void reset() {
         wav.clear(); planar.clear(); is.clear(); units.clear(); main_stream.clear(); recs.clear(); file_bytes.clear();
         sample_rate = channels = 0; frames = 0; n_units = 0; lsf = 0;
-        decoded = split = is_mp4 = false;
+        decoded = split = is_mp4 = staged = false;
+        arena_off = 0; walked_frames = result_index = 0;
     }
 };
 
@@ -233,6 +248,27 @@ std::vector<LoadedAudio> &file_pool(rg_ctx *c, size_t n) {
 }
 
 size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
+
+// Grow the arena to `need` bytes without losing its first `keep` bytes (PCM that chunks decoded earlier in the call).
+// The device is idle when this returns from a growth.
+int arena_reserve_keep(rg_ctx *c, size_t need, size_t keep) {
+    if (need <= c->d_arena.cap) return RG_OK;
+    if (keep == 0 || !c->d_arena.p) {
+        RG_HIP(c, c->d_arena.reserve(need));
+        return RG_OK;
+    }
+    RG_HIP(c, hipDeviceSynchronize());
+    unsigned char *fresh = nullptr;
+    const size_t want = need + need / 2 + 16;
+    RG_HIP(c, hipMalloc((void **)&fresh, want));
+    hipError_t e = hipMemcpy(fresh, c->d_arena.p, keep, hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) { (void)hipFree(fresh); RG_HIP(c, e); }
+    (void)hipFree(c->d_arena.p);
+    c->d_arena.p = fresh;
+    c->d_arena.cap = want;
+    return RG_OK;
+}
 
 // parse, copy to HBM, de-interleave: on return `descs` describe the planar arena c->d_arena
 int stage_wavs(rg_ctx *c, const void *const *wav, const size_t *wav_len, size_t n, std::vector<rg_track_desc> *descs, size_t *arena_bytes) {
@@ -284,10 +320,22 @@ int stage_wavs(rg_ctx *c, const void *const *wav, const size_t *wav_len, size_t 
 // straight into the arena
 int stage_loaded(rg_ctx *c, const std::vector<LoadedAudio> &in, size_t n, std::vector<rg_track_desc> *descs, size_t *arena_bytes) {
     std::vector<WavItem> items(n);
-    size_t src_total = 0, dst_total = 0;
+    // streams the loader pipeline has decoded already sit in [0, keep) of the arena; everything else goes behind them
+    size_t keep = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (in[i].staged) keep = std::max(keep, (size_t)align16(in[i].arena_off + (size_t)in[i].walked_frames * in[i].channels * sizeof(float)));
+    size_t src_total = 0, dst_total = keep;
     descs->assign(n ? n : 1, rg_track_desc{});
     for (size_t i = 0; i < n; ++i) {
         rg_track_desc &d = (*descs)[i];
+        if (in[i].staged) {
+            d.offset_bytes = in[i].arena_off;
+            d.frames = in[i].frames;
+            d.sample_rate = in[i].sample_rate;
+            d.channels = (uint16_t)in[i].channels;
+            d.format = RG_FMT_F32_PLANAR;
+            continue;
+        }
         d.offset_bytes = dst_total;
         if (in[i].decoded || in[i].split) {
             d.frames = in[i].frames;
@@ -318,11 +366,13 @@ int stage_loaded(rg_ctx *c, const std::vector<LoadedAudio> &in, size_t n, std::v
     if (rc != RG_OK) return rc;
     for (int s = 0; s < c->n_slots; ++s) RG_HIP(c, hipStreamSynchronize(c->slots[s].stream));
     RG_HIP(c, c->d_wav.reserve(src_total ? src_total : 16));
-    RG_HIP(c, c->d_arena.reserve(dst_total ? dst_total : 16));
+    rc = arena_reserve_keep(c, dst_total ? dst_total : 16, keep);
+    if (rc != RG_OK) return rc;
     hipStream_t fs = c->user_attached ? c->user_stream : c->slot().stream;
     std::vector<RgMp3SplitItem> split;
     for (size_t i = 0; i < n; ++i) {
         unsigned char *dst = c->d_arena.p + (*descs)[i].offset_bytes;
+        if (in[i].staged) continue;
         if (in[i].split) {
             RgMp3SplitItem it{};
             it.is = in[i].is.data();
@@ -466,37 +516,370 @@ int load_audio_for(const std::string &decoder_cmd, int gpu_decode, const char *p
     return RG_OK;
 }
 
-int load_one(rg_ctx *c, const char *path, LoadedAudio *out) {
-    std::string err;
-    const int rc = load_audio_for(c->decoder_cmd, c->gpu_mp3_decode, path, out, &err);
-    if (rc != RG_OK) return rg_set_err(c, rc, "%s", err.c_str());
-    return RG_OK;
+// =================================================================================================
+// The loader pipeline of tuning key 6 = 3 (the default).
+//
+// Host threads do the least an MPEG stream allows: read the file, walk its frame headers, and strip headers and side
+// information from the main data (rg_mp3_compact_stream).  Each stream's main data and slots go into a pinned staging
+// block; a block that is full (or holds enough granules to fill the GPU) is a chunk, and the calling thread sends chunks
+// to the device as they close: one H2D copy on the copy stream, then the frame parser, Huffman, hybrid and synthesis
+// kernels on the file stream, writing PCM straight into the analysis arena.  Three staging blocks and two device copies
+// rotate, so reading files, copying chunk k + 1 and decoding chunk k overlap.  How many frames of a stream decode is the
+// device's finding (rg_mp3_frames_kernel); the arena is laid out for "all of them" and the counts come back at the end.
+struct Mp3Stage {
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+    hipEvent_t staged = nullptr;  // H2D of the block's last chunk
+};
+struct Mp3Scratch {
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+    std::vector<uint8_t> slots;
+};
+struct Mp3Pipe {
+    static constexpr int NSTAGE = 3;
+    Mp3Stage stage[NSTAGE];
+    std::vector<Mp3Scratch> scratch;  // one per loader thread
+    ~Mp3Pipe() {
+        for (Mp3Stage &st : stage) {
+            if (st.p) (void)hipHostFree(st.p);
+            if (st.staged) (void)hipEventDestroy(st.staged);
+        }
+        for (Mp3Scratch &sc : scratch) free(sc.p);
+    }
+};
+Mp3Pipe &mp3_pipe(rg_ctx *c) {
+    if (!c->mp3_pipe) {
+        c->mp3_pipe = new Mp3Pipe();
+        c->mp3_pipe_free = [](void *p) { delete static_cast<Mp3Pipe *>(p); };
+    }
+    return *static_cast<Mp3Pipe *>(c->mp3_pipe);
 }
 
-// The files of an album, decoded on the host's cores (decode is by far the longest stage of a real run: one core turns
-// about 200 s of stereo audio into PCM per second, the GPU analyses 8 million).  Errors keep the reference's order: the
-// first failing file in input order is the one reported (src/replaygain.rs:1055).
-int load_many(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedAudio> *out, std::vector<int> *rcs_out = nullptr,
-              std::vector<std::string> *errs_out = nullptr) {
-    std::vector<int> rcs(n, RG_OK);
-    std::vector<std::string> errs(n);
+constexpr uint64_t kPipeChunkUnits = 1ull << 18;      // granule-channels per chunk: enough blocks for every CU several times over
+constexpr size_t kPipeStageBytes = (size_t)96 << 20;  // staging block (a 3-minute 320 kb/s file is 7.2 MB)
+
+struct PipeChunk {
+    int stage = 0;
+    size_t used = 0;
+    uint64_t units = 0;
+    std::vector<size_t> files;
+    int pending = 0;  // files still being copied into the block
+    bool closed = false, issued = false;
+};
+struct PipeFile {
+    uint64_t main_off = 0, main_len = 0, slots_off = 0;
+    uint32_t n_frames = 0;
+};
+struct PipeRun {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<PipeChunk> chunks;
+    int open = -1;
+    size_t files_done = 0;
+    size_t stage_want = 0;
+    int hip_error = RG_OK;
+    std::string hip_msg;
+};
+
+bool read_whole_file(const char *path, Mp3Scratch *sc, size_t *len) {
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return false;
+    struct stat st;
+    size_t want = (fstat(fd, &st) == 0 && st.st_size > 0) ? (size_t)st.st_size : 0;
+    size_t got = 0;
+    for (;;) {
+        if (sc->cap < got + 65536 + 64 || sc->cap < want + 64) {
+            size_t cap = std::max(std::max(sc->cap * 2, want + 64 + 65536), (size_t)1 << 20);
+            uint8_t *q = static_cast<uint8_t *>(realloc(sc->p, cap));
+            if (!q) { close(fd); return false; }
+            sc->p = q;
+            sc->cap = cap;
+        }
+        const ssize_t k = read(fd, sc->p + got, sc->cap - 64 - got);
+        if (k < 0) {
+            if (errno == EINTR) continue;
+            close(fd);
+            return false;
+        }
+        if (k == 0) break;
+        got += (size_t)k;
+    }
+    close(fd);
+    memset(sc->p + got, 0, 64);
+    *len = got;
+    return true;
+}
+
+// Loads `paths` into `out` (entry i <- file i) with the pipeline: MPEG streams are on their way through the device when
+// this returns and their PCM sits in c->d_arena (LoadedAudio::staged), other inputs are loaded as load_audio_for loads
+// them.  rcs / errs: per-file outcome.
+int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedAudio> *out, std::vector<int> *rcs,
+                        std::vector<std::string> *errs) {
+    int rc = rg_bind_device(c);
+    if (rc != RG_OK) return rc;
+    Mp3Pipe &P = mp3_pipe(c);
     unsigned workers = std::thread::hardware_concurrency();
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof set, &set) == 0) workers = (unsigned)CPU_COUNT(&set);
     if (workers < 1) workers = 1;
     if (workers > n) workers = (unsigned)n;
-    std::atomic<size_t> next{0};
+    if (P.scratch.size() < workers) P.scratch.resize(workers);
+    for (Mp3Stage &st : P.stage)
+        if (!st.staged) RG_HIP(c, hipEventCreateWithFlags(&st.staged, hipEventDisableTiming));
+    // earlier batches may still read the arena and the chunk buffers
+    for (int s = 0; s < c->n_slots; ++s) RG_HIP(c, hipStreamSynchronize(c->slots[s].stream));
+    rc = rg_mp3dev_reserve_results(c, n);
+    if (rc != RG_OK) return rc;
+    hipStream_t fs = c->user_attached ? c->user_stream : c->slot().stream;
+
+    PipeRun R;
+    {   // staging blocks no larger than the call needs: a single album of a dozen files should not pin 3 x 96 MB
+        size_t total = 0;
+        for (size_t i = 0; i < n; ++i) {
+            struct stat st;
+            if (paths[i] && stat(paths[i], &st) == 0 && st.st_size > 0) total += (size_t)st.st_size;
+        }
+        R.stage_want = std::min(kPipeStageBytes, total + total / 8 + ((size_t)1 << 16));
+    }
+    std::vector<PipeFile> pf(n);
     const std::string cmd = c->decoder_cmd;
-    const int gpu_decode = c->gpu_mp3_decode;
-    auto work = [&]() {
-        for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) rcs[i] = load_audio_for(cmd, gpu_decode, paths[i], &(*out)[i], &errs[i]);  // (*out) holds >= n entries
+    const int device = c->device;
+    std::atomic<size_t> next_file{0};
+
+    auto grow_stage = [&](Mp3Stage &st, size_t need) -> bool {  // the block is idle
+        if (st.cap >= need) return true;
+        if (st.p) (void)hipHostFree(st.p);
+        st.p = nullptr;
+        st.cap = 0;
+        const size_t want = need + need / 8;
+        if (hipHostMalloc((void **)&st.p, want, hipHostMallocDefault) != hipSuccess) return false;
+        st.cap = want;
+        return true;
     };
-    if (workers <= 1) {
-        work();
+    auto hip_fail = [&](const char *what) {  // R.m held
+        if (R.hip_error == RG_OK) { R.hip_error = RG_ERR_DEVICE; R.hip_msg = what; }
+    };
+
+    auto load_file = [&](size_t i, Mp3Scratch &sc) {
+        LoadedAudio &la = (*out)[i];
+        std::string &err = (*errs)[i];
+        const char *path = paths[i];
+        char msg[1024];
+        if (!path) { (*rcs)[i] = RG_ERR_INVALID_ARG; err = "null path"; return; }
+        size_t len = 0;
+        if (!read_whole_file(path, &sc, &len)) {
+            snprintf(msg, sizeof msg, "Failed to open: %s", path);  // src/replaygain.rs:804-805
+            (*rcs)[i] = RG_ERR_IO;
+            err = msg;
+            return;
+        }
+        if (len >= 12 && memcmp(sc.p, "RIFF", 4) == 0 && memcmp(sc.p + 8, "WAVE", 4) == 0) {
+            la.wav.assign(sc.p, sc.p + len);
+            return;
+        }
+        const bool mp4 = len >= 8 && memcmp(sc.p + 4, "ftyp", 4) == 0;
+        la.is_mp4 = rg_mp4_is_mp4_data(sc.p, len) != 0;
+        rg_mp3_stream_info si;
+        uint64_t main_len = 0;
+        if (mp4 || rg_mp3_compact_stream(sc.p, len, &sc.slots, &main_len, &si) != RG_MP3DEC_OK || si.audio_frames == 0) {
+            (*rcs)[i] = load_audio_for(cmd, 2, path, &la, &err);  // the decoder command, or the reference's probe error
+            return;
+        }
+        la.sample_rate = si.sample_rate;
+        la.channels = si.channels;
+        la.lsf = si.mpeg_version == 1 ? 0u : 1u;
+        la.walked_frames = (uint32_t)si.frames;  // PCM frames if every walked frame decodes
+        la.frames = si.frames;
+        la.result_index = (uint32_t)i;
+        la.staged = true;
+        const uint64_t units = (uint64_t)si.audio_frames * (la.lsf ? 1u : 2u) * si.channels;
+        const size_t slot_bytes = sc.slots.size();
+        const size_t need = align64((size_t)main_len + 8) + align64(slot_bytes);
+        PipeFile &f = pf[i];
+        f.main_len = main_len;
+        f.n_frames = si.audio_frames;
+        uint8_t *dst = nullptr;
+        PipeChunk *chunk = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(R.m);
+            for (;;) {
+                if (R.open >= 0) {
+                    PipeChunk &ch = R.chunks[(size_t)R.open];
+                    Mp3Stage &st = P.stage[ch.stage];
+                    const size_t with = ch.used + need + rg_mp3dev_track_bytes(ch.files.size() + 1) + 64;
+                    if (with <= st.cap && ch.units + units <= kPipeChunkUnits) break;
+                    if (ch.files.empty()) {  // a stream larger than a block: the block grows (nothing is in flight from it)
+                        if (!grow_stage(st, with)) { hip_fail("hipHostMalloc of a staging block failed"); (*rcs)[i] = RG_ERR_DEVICE; err = "out of pinned memory"; la.staged = false; return; }
+                        break;
+                    }
+                    ch.closed = true;
+                    R.open = -1;
+                    R.cv.notify_all();
+                }
+                const size_t id = R.chunks.size();
+                if (id >= (size_t)Mp3Pipe::NSTAGE && !R.chunks[id - Mp3Pipe::NSTAGE].issued) {  // every block is filling or waiting to be sent
+                    R.cv.wait(lk);
+                    continue;
+                }
+                Mp3Stage &st = P.stage[id % Mp3Pipe::NSTAGE];
+                if (id >= (size_t)Mp3Pipe::NSTAGE) {
+                    (void)hipSetDevice(device);
+                    if (hipEventSynchronize(st.staged) != hipSuccess) hip_fail("waiting for a staging block failed");
+                }
+                if (!grow_stage(st, std::max(R.stage_want, (size_t)4096))) { hip_fail("hipHostMalloc of a staging block failed"); (*rcs)[i] = RG_ERR_DEVICE; err = "out of pinned memory"; la.staged = false; return; }
+                R.chunks.emplace_back();
+                R.chunks.back().stage = (int)(id % Mp3Pipe::NSTAGE);
+                R.open = (int)id;
+            }
+            chunk = &R.chunks[(size_t)R.open];
+            f.main_off = chunk->used;
+            f.slots_off = f.main_off + align64((size_t)main_len + 8);
+            chunk->used = f.slots_off + align64(slot_bytes);
+            chunk->units += units;
+            chunk->files.push_back(i);
+            chunk->pending++;
+            dst = P.stage[chunk->stage].p;
+        }
+        memcpy(dst + f.main_off, sc.p, (size_t)main_len);
+        memset(dst + f.main_off + main_len, 0, (size_t)(f.slots_off - f.main_off - main_len));  // the bit reader looks a few bytes ahead
+        memcpy(dst + f.slots_off, sc.slots.data(), slot_bytes);
+        {
+            std::lock_guard<std::mutex> lk(R.m);
+            chunk->pending--;
+        }
+        R.cv.notify_all();
+    };
+    auto work = [&](unsigned w) {
+        for (size_t i = next_file.fetch_add(1); i < n; i = next_file.fetch_add(1)) {
+            load_file(i, P.scratch[w]);
+            {
+                std::lock_guard<std::mutex> lk(R.m);
+                R.files_done++;
+            }
+            R.cv.notify_all();
+        }
+    };
+
+    // ---- the calling thread: send chunks as they close ---------------------------------------------------------------
+    size_t arena_used = 0;
+    auto issue = [&](PipeChunk &ch, size_t index) -> int {
+        std::vector<RgMp3StreamItem> items(ch.files.size());
+        size_t top = arena_used;
+        for (size_t k = 0; k < ch.files.size(); ++k) {
+            LoadedAudio &la = (*out)[ch.files[k]];
+            la.arena_off = top;
+            top = align16(top + (size_t)la.walked_frames * la.channels * sizeof(float));
+        }
+        int r = arena_reserve_keep(c, top ? top : 16, arena_used);
+        if (r != RG_OK) return r;
+        arena_used = top;
+        for (size_t k = 0; k < ch.files.size(); ++k) {
+            const size_t i = ch.files[k];
+            const LoadedAudio &la = (*out)[i];
+            RgMp3StreamItem &it = items[k];
+            it.main_off = pf[i].main_off;
+            it.slots_off = pf[i].slots_off;
+            it.n_frames = pf[i].n_frames;
+            it.channels = la.channels;
+            it.rate_row = (uint32_t)rg_mp3_rate_row(la.sample_rate);
+            it.lsf = la.lsf;
+            it.result_index = la.result_index;
+            it.d_ch0 = reinterpret_cast<float *>(c->d_arena.p + la.arena_off);
+        }
+        Mp3Stage &st = P.stage[ch.stage];
+        const size_t tracks_off = (ch.used + 7) & ~(size_t)7;
+        return rg_mp3dev_enqueue_chunk(c, (int)(index & 1), st.p, tracks_off + rg_mp3dev_track_bytes(items.size()), tracks_off, st.staged,
+                                       items.data(), items.size(), fs);
+    };
+    auto drive = [&]() -> int {
+        int result = RG_OK;
+        size_t next = 0;
+        std::unique_lock<std::mutex> lk(R.m);
+        for (;;) {
+            R.cv.wait(lk, [&] { return (next < R.chunks.size() && R.chunks[next].closed && R.chunks[next].pending == 0) || R.files_done == n; });
+            if (!(next < R.chunks.size() && R.chunks[next].closed && R.chunks[next].pending == 0)) {
+                if (R.open >= 0) {  // every file is in: the last chunk closes as it is
+                    R.chunks[(size_t)R.open].closed = true;
+                    R.open = -1;
+                    continue;
+                }
+                if (next >= R.chunks.size()) break;
+                continue;
+            }
+            PipeChunk &ch = R.chunks[next];
+            lk.unlock();
+            int r = (result == RG_OK && !ch.files.empty()) ? issue(ch, next) : RG_OK;
+            lk.lock();
+            if (r != RG_OK && result == RG_OK) result = r;
+            if (r != RG_OK || ch.files.empty()) (void)hipEventRecord(P.stage[ch.stage].staged, fs);  // loaders wait on it before refilling the block
+            ch.issued = true;
+            ++next;
+            R.cv.notify_all();
+        }
+        return result;
+    };
+
+    if (n == 1) {  // one stream is one chunk: nothing to overlap
+        work(0);
+        rc = drive();
     } else {
         std::vector<std::thread> pool;
-        for (unsigned w = 0; w < workers; ++w) pool.emplace_back(work);
+        for (unsigned w = 0; w < workers; ++w) pool.emplace_back(work, w);
+        rc = drive();
         for (auto &t : pool) t.join();
+    }
+    if (rc != RG_OK) return rc;
+    if (R.hip_error != RG_OK) return rg_set_err(c, R.hip_error, "%s", R.hip_msg.c_str());
+    // the device's findings: how much of each stream decoded
+    rc = rg_mp3dev_fetch_results(c, n, fs);
+    if (rc != RG_OK) return rc;
+    RG_HIP(c, hipStreamSynchronize(fs));
+    const uint32_t *granules = rg_mp3dev_results(c);
+    for (size_t i = 0; i < n; ++i) {
+        LoadedAudio &la = (*out)[i];
+        if (la.staged) la.frames = (uint64_t)granules[la.result_index] * 576;
+    }
+    if (!c->user_attached) RG_HIP(c, hipEventRecord(c->user_ev, fs));
+    c->user_dirty = true;
+    return RG_OK;
+}
+
+int load_many(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedAudio> *out, std::vector<int> *rcs_out = nullptr,
+              std::vector<std::string> *errs_out = nullptr);
+
+// `out` is entry 0 of the context's pool
+int load_one(rg_ctx *c, const char *path, std::vector<LoadedAudio> *pool) { return load_many(c, &path, 1, pool); }
+
+// The files of an album, decoded on the host's cores (decode is by far the longest stage of a real run: one core turns
+// about 200 s of stereo audio into PCM per second, the GPU analyses 8 million).  Errors keep the reference's order: the
+// first failing file in input order is the one reported (src/replaygain.rs:1055).
+int load_many(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedAudio> *out, std::vector<int> *rcs_out,
+              std::vector<std::string> *errs_out) {
+    std::vector<int> rcs(n, RG_OK);
+    std::vector<std::string> errs(n);
+    if (c->gpu_mp3_decode >= 3 && n) {
+        const int prc = load_many_pipelined(c, paths, n, out, &rcs, &errs);
+        if (prc != RG_OK) return prc;
+    } else {
+        unsigned workers = std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) workers = (unsigned)CPU_COUNT(&set);
+        if (workers < 1) workers = 1;
+        if (workers > n) workers = (unsigned)n;
+        std::atomic<size_t> next{0};
+        const std::string cmd = c->decoder_cmd;
+        const int gpu_decode = c->gpu_mp3_decode;
+        auto work = [&]() {
+            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) rcs[i] = load_audio_for(cmd, gpu_decode, paths[i], &(*out)[i], &errs[i]);  // (*out) holds >= n entries
+        };
+        if (workers <= 1) {
+            work();
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned w = 0; w < workers; ++w) pool.emplace_back(work);
+            for (auto &t : pool) t.join();
+        }
     }
     if (rcs_out) {  // per-file outcome wanted: nothing aborts
         rcs_out->swap(rcs);
@@ -544,7 +927,7 @@ extern "C" int rg_analyze_wav_batch(rg_ctx *c, const void *const *wav, const siz
 extern "C" int rg_analyze_track(rg_ctx *c, const char *path, int32_t track_index, rg_track_result *out) {
     if (!c || !out) return RG_ERR_INVALID_ARG;
     std::vector<LoadedAudio> &in = file_pool(c, 1);
-    int rc = load_one(c, path, &in[0]);
+    int rc = load_one(c, path, &in);
     if (rc != RG_OK) return rc;
     rc = check_track_index(c, track_index);
     if (rc != RG_OK) return rc;
@@ -673,7 +1056,7 @@ extern "C" const char *rg_tracks_error(const rg_ctx *c, size_t i) {
 extern "C" int rg_find_peak_amplitude(rg_ctx *c, const char *path, rg_peak_result *out) {
     if (!c || !out) return RG_ERR_INVALID_ARG;
     std::vector<LoadedAudio> &in = file_pool(c, 1);
-    int rc = load_one(c, path, &in[0]);
+    int rc = load_one(c, path, &in);
     if (rc != RG_OK) return rc;
     std::vector<rg_track_desc> descs;
     size_t arena_bytes = 0;
@@ -690,6 +1073,71 @@ extern "C" int rg_mp3_decode_device(rg_ctx *c, const void *data, size_t len, flo
                                     void *info) {
     rg_mp3_stream_info *out = static_cast<rg_mp3_stream_info *>(info);
     if (!c || !data || !out || !ch0) return RG_ERR_INVALID_ARG;
+    if (c->gpu_mp3_decode >= 3) {  // the default route: the host strips headers and side information, nothing else
+        int rc = rg_bind_device(c);
+        if (rc != RG_OK) return rc;
+        Mp3Pipe &P = mp3_pipe(c);
+        if (P.scratch.empty()) P.scratch.resize(1);
+        Mp3Scratch &sc = P.scratch[0];
+        if (sc.cap < len + 64) {
+            uint8_t *q = static_cast<uint8_t *>(realloc(sc.p, len + 64));
+            if (!q) return rg_set_err(c, RG_ERR_IO, "out of memory");
+            sc.p = q;
+            sc.cap = len + 64;
+        }
+        memcpy(sc.p, data, len);
+        memset(sc.p + len, 0, 64);
+        uint64_t main_len = 0;
+        if (rg_mp3_compact_stream(sc.p, len, &sc.slots, &main_len, out) != RG_MP3DEC_OK)
+            return rg_set_err(c, RG_ERR_FORMAT, "%s", rg_mp3dec_last_error());
+        if (out->frames > capacity) return rg_set_err(c, RG_ERR_INVALID_ARG, "capacity %llu < %llu frames", (unsigned long long)capacity, (unsigned long long)out->frames);
+        if (out->channels == 2 && !ch1) return rg_set_err(c, RG_ERR_INVALID_ARG, "stereo stream needs a second output channel");
+        for (int s = 0; s < c->n_slots; ++s) RG_HIP(c, hipStreamSynchronize(c->slots[s].stream));
+        const size_t bytes = (size_t)out->frames * out->channels * sizeof(float);
+        RG_HIP(c, c->d_arena.reserve(bytes ? bytes : 16));
+        Mp3Stage &st = P.stage[0];
+        if (!st.staged) RG_HIP(c, hipEventCreateWithFlags(&st.staged, hipEventDisableTiming));
+        RgMp3StreamItem it{};
+        it.main_off = 0;
+        it.slots_off = align64((size_t)main_len + 8);
+        const size_t tracks_off = it.slots_off + align64(sc.slots.size());
+        const size_t total = tracks_off + rg_mp3dev_track_bytes(1);
+        if (st.cap < total) {
+            if (st.p) (void)hipHostFree(st.p);
+            st.p = nullptr;
+            st.cap = 0;
+            RG_HIP(c, hipHostMalloc((void **)&st.p, total + total / 8, hipHostMallocDefault));
+            st.cap = total + total / 8;
+        }
+        memcpy(st.p, sc.p, (size_t)main_len);
+        memset(st.p + main_len, 0, (size_t)(it.slots_off - main_len));
+        memcpy(st.p + it.slots_off, sc.slots.data(), sc.slots.size());
+        it.n_frames = out->audio_frames;
+        it.channels = out->channels;
+        it.rate_row = (uint32_t)rg_mp3_rate_row(out->sample_rate);
+        it.lsf = out->mpeg_version == 1 ? 0u : 1u;
+        it.result_index = 0;
+        it.d_ch0 = reinterpret_cast<float *>(c->d_arena.p);
+        hipStream_t fs = c->slot().stream;
+        rc = rg_mp3dev_reserve_results(c, 1);
+        if (rc != RG_OK) return rc;
+        rc = rg_mp3dev_enqueue_chunk(c, 0, st.p, total, tracks_off, st.staged, &it, 1, fs);
+        if (rc != RG_OK) return rc;
+        rc = rg_mp3dev_fetch_results(c, 1, fs);
+        if (rc != RG_OK) return rc;
+        RG_HIP(c, hipStreamSynchronize(fs));
+        const uint32_t granules = rg_mp3dev_results(c)[0];
+        const uint32_t per_frame = it.lsf ? 1u : 2u;
+        const uint32_t walked = out->audio_frames;
+        out->frames = (uint64_t)granules * 576;
+        out->audio_frames = granules / per_frame;
+        out->skipped_frames = walked - out->audio_frames;
+        if (out->frames) {
+            RG_HIP(c, hipMemcpy(ch0, it.d_ch0, (size_t)out->frames * sizeof(float), hipMemcpyDeviceToHost));
+            if (out->channels == 2) RG_HIP(c, hipMemcpy(ch1, it.d_ch0 + out->frames, (size_t)out->frames * sizeof(float), hipMemcpyDeviceToHost));
+        }
+        return RG_OK;
+    }
     rg_mp3_stream_info si;
     if (rg_mp3_scan(data, len, &si) != RG_MP3DEC_OK) return rg_set_err(c, RG_ERR_FORMAT, "%s", rg_mp3dec_last_error());
     const uint64_t cap = (uint64_t)si.audio_frames * (si.mpeg_version == 1 ? 2u : 1u) * si.channels;

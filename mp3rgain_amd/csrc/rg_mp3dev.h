@@ -79,8 +79,14 @@ struct RgMp3DevTrack {
     float *ch1;
     uint64_t main_base;      // device Huffman stage: byte offset of the track's main-data stream in the chunk buffer
     uint32_t synth_base;     // first block of the track in the synthesis kernel's grid
+    uint32_t n_frames;       // tuning key 6 = 3: frames the host walked (slots); the device decides which decode
+    uint64_t slots_base;     //   byte offset of the track's slots (rg_mp3_frame.h) in the chunk buffer
+    uint32_t result_index;   //   where rg_mp3_frames_kernel reports the granules it found decodable
     uint32_t pad_;
 };
+// With the device-side frame parser (rg_mp3_frames_kernel) unit_base / granule_base / fc_base / synth_base and the grids
+// are laid out for the upper bound "every walked frame decodes"; the kernel then overwrites n_granules (and ch1, which
+// follows the decoded length) with what it found, and the later stages skip the units past it.
 
 #ifdef __cplusplus
 #include <vector>

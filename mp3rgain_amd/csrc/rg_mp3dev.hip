@@ -19,6 +19,7 @@
 
 #include "rg_mp3dev.h"
 #include "rg_mp3_math.h"
+#include "rg_mp3_frame.h"
 
 namespace {
 
@@ -91,6 +92,7 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
     const uint32_t ti = find_by_granule(tracks, n_tracks, blockIdx.x);
     const RgMp3DevTrack tr = tracks[ti];
     const uint32_t g = blockIdx.x - tr.granule_base;
+    if (g >= tr.n_granules) return;  // past what the device-side frame parser found decodable (block-uniform)
     const int nch = (int)tr.channels;
     const int rr = (int)tr.rate_row;
     const uint64_t u0 = tr.unit_base + (uint64_t)g * nch;
@@ -327,6 +329,7 @@ rg_mp3_synth_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *_
     const int nch = (int)tr.channels;
     const uint32_t local = blockIdx.x - tr.synth_base;
     const uint32_t runs = (tr.n_granules + R - 1) / R;
+    if (runs == 0 || local >= runs * (uint32_t)nch) return;  // fewer granules decoded than the grid was laid out for
     const int c = (int)(local / runs);
     const uint32_t g0 = (local % runs) * R;
     const int ng = (int)(tr.n_granules - g0 < (uint32_t)R ? tr.n_granules - g0 : (uint32_t)R);
@@ -387,6 +390,7 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
     const int nch = (int)tr.channels, ngr = tr.lsf ? 1 : 2, rr = (int)tr.rate_row;
     const uint32_t f = local / nch;
     const int c = (int)(local % nch);
+    if (f * (uint32_t)ngr >= tr.n_granules) return;
     static const uint8_t kSlen0[16] = {0, 0, 0, 0, 3, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4};
     static const uint8_t kSlen1[16] = {0, 1, 2, 3, 0, 1, 2, 3, 1, 2, 3, 1, 2, 3, 2, 3};
     static const uint8_t kPart[6][3][4] = {
@@ -550,6 +554,78 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
     }
 }
 
+// Tuning key 6 = 3: the frame parser.  One block per track walks the track's slots (header + side information of every
+// frame the host's walk found, rg_mp3_frame.h) 256 frames at a time: a prefix sum of the frames' main-data sizes gives
+// each frame its place in the bit reservoir, rg_mp3_frame_records -- the very code the host route runs -- decides whether
+// it decodes, and a prefix sum of the survivors numbers their granules.  Records go out compacted (a dropped frame
+// leaves no gap in the PCM, exactly as on the host); the track's decoded length replaces the upper bound in its
+// descriptor, the second channel's plane moves up behind the first, and the host reads the count from `results`.
+__global__ void __launch_bounds__(256)
+rg_mp3_frames_kernel(RgMp3DevTrack *__restrict__ tracks, const uint8_t *__restrict__ chunk, RgMp3HuffRec *__restrict__ recs,
+                     uint32_t *__restrict__ results) {
+    __shared__ uint32_t wave_sum[2][4];
+    const RgMp3DevTrack tr = tracks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t *__restrict__ slots = chunk + tr.slots_base;
+    uint64_t have_base = 0;
+    uint32_t unit_run = 0;
+    // exclusive prefix of (a, b) over the block; totals in ta / tb
+    auto scan2 = [&](uint32_t a, uint32_t b, uint32_t *ea, uint32_t *eb, uint32_t *ta, uint32_t *tb) {
+        uint32_t ia = a, ib = b;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t xa = __shfl_up(ia, d), xb = __shfl_up(ib, d);
+            if (lane >= d) { ia += xa; ib += xb; }
+        }
+        __syncthreads();  // the previous tile's totals have been read
+        if (lane == 63) { wave_sum[0][wave] = ia; wave_sum[1][wave] = ib; }
+        __syncthreads();
+        uint32_t oa = 0, ob = 0, sa = 0, sb = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) { oa += wave_sum[0][w]; ob += wave_sum[1][w]; }
+            sa += wave_sum[0][w];
+            sb += wave_sum[1][w];
+        }
+        *ea = oa + ia - a;
+        *eb = ob + ib - b;
+        *ta = sa;
+        *tb = sb;
+    };
+    for (uint32_t f0 = 0; f0 < tr.n_frames; f0 += 256) {
+        const uint32_t f = f0 + (uint32_t)tid;
+        const bool live = f < tr.n_frames;
+        uint64_t raw[RG_MP3_SLOT_BYTES / 8];
+        uint32_t main_bytes = 0;
+        if (live) {
+            const uint64_t *src = reinterpret_cast<const uint64_t *>(slots + (size_t)f * RG_MP3_SLOT_BYTES);  // slots_base is 8-byte aligned
+#pragma unroll
+            for (int k = 0; k < RG_MP3_SLOT_BYTES / 8; ++k) raw[k] = src[k];
+            RgMp3FrameHdr h;
+            if (rg_mp3_frame_header(reinterpret_cast<const uint8_t *>(raw), &h)) main_bytes = rg_mp3_frame_main_bytes(h);
+        }
+        uint32_t have_excl, dummy_e, have_total, dummy_t;
+        scan2(main_bytes, 0u, &have_excl, &dummy_e, &have_total, &dummy_t);
+        RgMp3HuffRec r[4];
+        uint32_t n = 0;
+        if (live) {
+            uint32_t mb;
+            n = (uint32_t)rg_mp3_frame_records(reinterpret_cast<const uint8_t *>(raw), have_base + have_excl, (int)tr.channels, r, &mb);
+        }
+        uint32_t unit_excl, unit_total;
+        scan2(n, 0u, &unit_excl, &dummy_e, &unit_total, &dummy_t);
+        for (uint32_t i = 0; i < n; ++i) recs[tr.unit_base + unit_run + unit_excl + i] = r[i];
+        have_base += have_total;
+        unit_run += unit_total;
+    }
+    if (tid == 0) {
+        const uint32_t granules = unit_run / tr.channels;
+        tracks[blockIdx.x].n_granules = granules;
+        if (tr.channels == 2) tracks[blockIdx.x].ch1 = tr.ch0 + (size_t)granules * 576;
+        results[tr.result_index] = granules;
+    }
+}
+
 extern "C" hipError_t rg_launch_mp3_huffman(const RgMp3DevTables *d_tab, const RgMp3DevHuff *d_huff, const RgMp3DevTrack *d_tracks,
                                             uint32_t n_tracks, const RgMp3HuffRec *d_recs, const uint8_t *d_main, rg_mp3_unit *d_units,
                                             int16_t *d_is, uint32_t total_fc, hipStream_t s) {
@@ -571,5 +647,12 @@ extern "C" hipError_t rg_launch_mp3_synth(const RgMp3DevTables *d_tab, const RgM
                                           uint32_t n_blocks, const float *d_hyb, hipStream_t s) {
     if (n_blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(rg_mp3_synth_kernel, dim3(n_blocks), dim3(256), 0, s, d_tab, d_tracks, n_tracks, d_hyb);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rg_launch_mp3_frames(RgMp3DevTrack *d_tracks, uint32_t n_tracks, const uint8_t *d_chunk, RgMp3HuffRec *d_recs,
+                                           uint32_t *d_results, hipStream_t s) {
+    if (n_tracks == 0) return hipSuccess;
+    hipLaunchKernelGGL(rg_mp3_frames_kernel, dim3(n_tracks), dim3(256), 0, s, d_tracks, d_chunk, d_recs, d_results);
     return hipGetLastError();
 }

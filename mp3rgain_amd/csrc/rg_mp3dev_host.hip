@@ -13,6 +13,7 @@ hipError_t rg_launch_mp3_huffman(const RgMp3DevTables *, const RgMp3DevHuff *, c
 hipError_t rg_launch_mp3_hybrid(const RgMp3DevTables *, const RgMp3DevTrack *, uint32_t, uint32_t, const rg_mp3_unit *,
                                 const int16_t *, float *, hipStream_t);
 hipError_t rg_launch_mp3_synth(const RgMp3DevTables *, const RgMp3DevTrack *, uint32_t, uint32_t, const float *, hipStream_t);
+hipError_t rg_launch_mp3_frames(RgMp3DevTrack *, uint32_t, const uint8_t *, RgMp3HuffRec *, uint32_t *, hipStream_t);
 }
 
 namespace {
@@ -28,9 +29,7 @@ int rg_mp3_rate_row(uint32_t sample_rate) {
     return -1;
 }
 
-int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream_t s) {
-    int rc = rg_bind_device(c);
-    if (rc != RG_OK) return rc;
+static int ensure_tables(rg_ctx *c) {
     if (!c->mp3_tab_ready) {
         RgMp3DevTables *tab = new RgMp3DevTables();
         rg_mp3_fill_device_tables(tab);
@@ -46,6 +45,14 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
         RG_HIP(c, e);
         c->mp3_tab_ready = true;
     }
+    return RG_OK;
+}
+
+int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream_t s) {
+    int rc = rg_bind_device(c);
+    if (rc != RG_OK) return rc;
+    rc = ensure_tables(c);
+    if (rc != RG_OK) return rc;
     const RgMp3DevHuff *d_huff = reinterpret_cast<const RgMp3DevHuff *>(c->d_mp3_huff.p);
     const RgMp3DevTables *d_tab = reinterpret_cast<const RgMp3DevTables *>(c->d_mp3_tab.p);
     for (size_t first = 0; first < n;) {
@@ -116,5 +123,91 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
         }
         first = last;
     }
+    return RG_OK;
+}
+
+// ---- tuning key 6 = 3 ------------------------------------------------------------------------------------------------
+size_t rg_mp3dev_track_bytes(size_t n_items) { return n_items * sizeof(RgMp3DevTrack); }
+
+int rg_mp3dev_reserve_results(rg_ctx *c, size_t n) {
+    RG_HIP(c, c->d_mp3_results.reserve(n ? n : 1));
+    RG_HIP(c, c->h_mp3_results.reserve(n ? n : 1));
+    return RG_OK;
+}
+
+int rg_mp3dev_fetch_results(rg_ctx *c, size_t n, hipStream_t s) {
+    if (n) RG_HIP(c, hipMemcpyAsync(c->h_mp3_results.p, c->d_mp3_results.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    return RG_OK;
+}
+
+const uint32_t *rg_mp3dev_results(rg_ctx *c) { return c->h_mp3_results.p; }
+
+int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, size_t tracks_off, hipEvent_t staged,
+                            const RgMp3StreamItem *items, size_t n, hipStream_t s) {
+    int rc = rg_bind_device(c);
+    if (rc != RG_OK) return rc;
+    rc = ensure_tables(c);
+    if (rc != RG_OK) return rc;
+    if (!c->mp3_copy_stream) RG_HIP(c, hipStreamCreateWithFlags(&c->mp3_copy_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k)
+        if (!c->mp3_set_free[k]) RG_HIP(c, hipEventCreateWithFlags(&c->mp3_set_free[k], hipEventDisableTiming));
+    // the descriptors, laid out for the upper bound "every walked frame decodes"
+    RgMp3DevTrack *tr = reinterpret_cast<RgMp3DevTrack *>(staging + tracks_off);
+    uint64_t ub = 0;
+    uint32_t gb = 0, fcb = 0, sb = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const RgMp3StreamItem &it = items[i];
+        RgMp3DevTrack &t = tr[i];
+        memset(&t, 0, sizeof t);
+        const uint32_t granules = it.n_frames * (it.lsf ? 1u : 2u);
+        t.unit_base = ub;
+        t.granule_base = gb;
+        t.n_granules = granules;
+        t.channels = it.channels;
+        t.rate_row = it.rate_row;
+        t.lsf = it.lsf;
+        t.fc_base = fcb;
+        t.ch0 = it.d_ch0;
+        t.ch1 = it.channels == 2 ? it.d_ch0 + (size_t)granules * 576 : nullptr;
+        t.main_base = it.main_off;
+        t.synth_base = sb;
+        t.n_frames = it.n_frames;
+        t.slots_base = it.slots_off;
+        t.result_index = it.result_index;
+        ub += (uint64_t)granules * it.channels;
+        gb += granules;
+        fcb += it.n_frames * it.channels;
+        sb += ((granules + RG_MP3_SYNTH_RUN - 1) / RG_MP3_SYNTH_RUN) * it.channels;
+    }
+    const size_t total = tracks_off + n * sizeof(RgMp3DevTrack);
+    if (total > bytes) return rg_set_err(c, RG_ERR_INVALID_ARG, "MP3 staging block: descriptors do not fit");
+    // grow-only buffers; growing one frees the old allocation, which waits for the kernels still using it
+    RG_HIP(c, c->d_mp3_stage[set].reserve(bytes + 64));
+    if (ub) {
+        RG_HIP(c, c->d_mp3_is.reserve(ub * 576));
+        RG_HIP(c, c->d_mp3_units.reserve(ub * sizeof(rg_mp3_unit)));
+        RG_HIP(c, c->d_mp3_hyb.reserve(ub * 2 * 576));
+        RG_HIP(c, c->d_mp3_recs.reserve(ub * sizeof(RgMp3HuffRec)));
+    }
+    hipStream_t cs = c->mp3_copy_stream;
+    if (c->mp3_set_used[set]) RG_HIP(c, hipStreamWaitEvent(cs, c->mp3_set_free[set], 0));  // the set's previous chunk has been decoded
+    RG_HIP(c, hipMemcpyAsync(c->d_mp3_stage[set].p, staging, bytes, hipMemcpyHostToDevice, cs));
+    RG_HIP(c, hipEventRecord(staged, cs));
+    RG_HIP(c, hipStreamWaitEvent(s, staged, 0));
+    if (ub) {
+        const uint8_t *d_chunk = c->d_mp3_stage[set].p;
+        RgMp3DevTrack *d_tr = reinterpret_cast<RgMp3DevTrack *>(c->d_mp3_stage[set].p + tracks_off);
+        const RgMp3DevHuff *d_huff = reinterpret_cast<const RgMp3DevHuff *>(c->d_mp3_huff.p);
+        const RgMp3DevTables *d_tab = reinterpret_cast<const RgMp3DevTables *>(c->d_mp3_tab.p);
+        RgMp3HuffRec *d_recs = reinterpret_cast<RgMp3HuffRec *>(c->d_mp3_recs.p);
+        RG_HIP(c, rg_launch_mp3_frames(d_tr, (uint32_t)n, d_chunk, d_recs, c->d_mp3_results.p, s));
+        RG_HIP(c, rg_launch_mp3_huffman(d_tab, d_huff, d_tr, (uint32_t)n, d_recs, d_chunk, reinterpret_cast<rg_mp3_unit *>(c->d_mp3_units.p),
+                                        c->d_mp3_is.p, fcb, s));
+        RG_HIP(c, rg_launch_mp3_hybrid(d_tab, d_tr, (uint32_t)n, gb, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p), c->d_mp3_is.p,
+                                       c->d_mp3_hyb.p, s));
+        RG_HIP(c, rg_launch_mp3_synth(d_tab, d_tr, (uint32_t)n, sb, c->d_mp3_hyb.p, s));
+    }
+    RG_HIP(c, hipEventRecord(c->mp3_set_free[set], s));
+    c->mp3_set_used[set] = true;
     return RG_OK;
 }

@@ -21,13 +21,17 @@ FIX = ROOT / "tests" / "golden" / "fixtures"
 STREAMS = sorted(GOLD.glob("*.mp3")) + sorted(FIX.glob("*.mp3"))
 
 
-# tuning key 6: 1 = scalefactors + Huffman on the host, stages B-E on the device; 2 = the host only walks the frames
-# (headers, side information, where each granule's bits lie), scalefactors and Huffman run on the device as well
-@pytest.fixture(params=[1, 2], ids=["huffman-on-host", "huffman-on-device"])
+# tuning key 6: 1 = scalefactors + Huffman on the host, stages B-E on the device; 2 = the host walks the frames and parses
+# their side information (where each granule's bits lie), scalefactors and Huffman run on the device as well; 3 = the
+# host only strips headers and side information from the stream, the device parses them too
+DEFAULT_ROUTE = 3
+
+
+@pytest.fixture(params=[1, 2, 3], ids=["huffman-on-host", "huffman-on-device", "frames-on-device"])
 def split_mode(_ctx, request):
     _ctx.set_tuning(6, request.param)
     yield request.param
-    _ctx.set_tuning(6, 2)  # the library's default
+    _ctx.set_tuning(6, DEFAULT_ROUTE)  # the library's default
 
 
 @pytest.mark.parametrize("path", STREAMS, ids=lambda p: p.stem)
@@ -100,14 +104,16 @@ def test_damaged_files_through_the_file_level_entry_point(_ctx, tmp_path):
         f = tmp_path / f"damaged{k}.mp3"
         f.write_bytes(bytes(d))
         out = []
-        for route in (2, 0):
+        for route in (3, 2, 0):
             an.set_tuning(6, route)
             try:
                 r = an.analyze_track_file(f)
                 out.append((r.loudness_db, r.peak, r.sample_rate, r.windows))
             except rg.ReplayGainError as ex:
                 out.append(("error", ex.code))
-        an.set_tuning(6, 2)
+        an.set_tuning(6, DEFAULT_ROUTE)
+        assert out[0] == out[1], (k, out)  # the two device routes run the same frame logic (rg_mp3_frame.h)
+        out = out[1:]
         if out[0][0] == "error" or out[1][0] == "error":
             assert out[0][0] == out[1][0] == "error", (k, out)
             failed += 1
@@ -151,7 +157,7 @@ def test_file_level_results_do_not_depend_on_the_decoder(_ctx, oracle, tmp_path,
         dev_album = an.analyze_album_files(files[:3])
         dev_peak = an.find_peak_amplitude_file(files[0])
     finally:
-        an.set_tuning(6, 2)
+        an.set_tuning(6, DEFAULT_ROUTE)
     for f, h, d in zip(files, host, dev):
         assert (h.loudness_db, h.gain_db, h.peak, h.sample_rate, h.windows) == (d.loudness_db, d.gain_db, d.peak, d.sample_rate, d.windows), f.name
         pcm, _ = mp3dec.decode(f.read_bytes())
@@ -177,7 +183,7 @@ def test_configs0_one_30_second_mp3_through_analyze_track(_ctx, oracle, tmp_path
     want, _ = oracle.analyze_pcm(pcm[0], pcm[1], 44100)
     an.set_kernel(0)
     try:
-        for route in (2, 1, 0):
+        for route in (3, 2, 1, 0):
             an.set_tuning(6, route)
             got = an.analyze_track_file(f)
             assert (got.loudness_db, got.gain_db, got.peak, got.sample_rate) == (want["loudness_db"], want["gain_db"], want["peak"], 44100), route
@@ -185,7 +191,7 @@ def test_configs0_one_30_second_mp3_through_analyze_track(_ctx, oracle, tmp_path
             pk = an.find_peak_amplitude_file(f)
             assert pk.peak == float(np.abs(pcm).max()) and pk.sample_rate == 44100
     finally:
-        an.set_tuning(6, 2)
+        an.set_tuning(6, DEFAULT_ROUTE)
 
 
 def test_album_mixing_wav_and_mp3_files(_ctx, oracle, tmp_path):
@@ -209,13 +215,13 @@ def test_album_mixing_wav_and_mp3_files(_ctx, oracle, tmp_path):
             per.append(oracle.analyze_pcm(pcm[0], pcm[1], 44100))
     want, _ = oracle.album_from_hists([h for _, h in per], [r["peak"] for r, _ in per])
     try:
-        for route in (2, 0):
+        for route in (3, 2, 0):
             an.set_tuning(6, route)
             got = an.analyze_album_files(files)
             assert (got.album_loudness_db, got.album_gain_db, got.album_peak) == (want["album_loudness_db"], want["album_gain_db"], want["album_peak"])
             assert [t.loudness_db for t in got.tracks] == [r["loudness_db"] for r, _ in per]
     finally:
-        an.set_tuning(6, 2)
+        an.set_tuning(6, DEFAULT_ROUTE)
 
 
 def test_sharded_album_over_files_with_the_library_communicator(_ctx, oracle, tmp_path):

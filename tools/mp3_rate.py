@@ -59,13 +59,13 @@ for label, src in (("dense 320k synthetic", ROOT / "tests/golden/mp3/v1_44k_ster
     t0 = time.perf_counter(); an.decode_mp3_device(stream); t_split = time.perf_counter() - t0
     print(f"   one file, one host thread: host decoder {t_host * 1e3:8.1f} ms ({audio_s / t_host:7.0f}x real time) | stage A {t_a * 1e3:7.1f} ms "
           f"({audio_s / t_a:7.0f}x) | split decoder incl. copies {t_split * 1e3:7.1f} ms ({audio_s / t_split:7.0f}x)")
-    for key6 in (0, 1, 2):
+    for key6 in (0, 1, 2, 3, 3):
         an.set_tuning(6, key6)
         an.analyze_album_files(files[:2])
         t0 = time.perf_counter()
         res = an.analyze_album_files(files)
         dt = time.perf_counter() - t0
-        name = ["host decoder                     ", "split: Huffman on host, B-E on GPU", "split: host walks frames only     "][key6]
+        name = ["host decoder                     ", "split: Huffman on host, B-E on GPU", "device: host parses side info     ", "device: host strips headers, piped"][key6]
         print(f"   rg_analyze_album, {name}: {dt:7.3f} s = {nfiles * audio_s / dt:9.0f}x real time, "
               f"{nfiles * si.frames / dt / 1e6:8.1f} M stereo samples/s, album loudness {res.album_loudness_db:.2f} dB")
-    an.set_tuning(6, 2)
+    an.set_tuning(6, 3)
