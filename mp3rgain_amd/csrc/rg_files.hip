@@ -413,6 +413,33 @@ int stage_loaded(rg_ctx *c, const std::vector<LoadedAudio> &in, size_t n, std::v
     return RG_OK;
 }
 
+// Host threads this process may really run: the affinity mask, cut by the cgroup CPU quota if there is one (a container
+// with 16 CPUs' worth of quota on a 256-core host sees all 256 in its mask; 256 loader threads then only fight).
+unsigned usable_cores() {
+    unsigned n = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned)CPU_COUNT(&set);
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[64];
+        double period = 0.0;
+        if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0.0) {
+            const double cpus = atof(q) / period;
+            if (cpus >= 1.0 && cpus < (double)n) n = (unsigned)(cpus + 0.5);
+        }
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+        double quota = -1.0, period = 0.0;
+        if (fscanf(g, "%lf", &quota) != 1) quota = -1.0;
+        fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(h, "%lf", &period) != 1) period = 0.0;
+            fclose(h);
+        }
+        if (quota > 0.0 && period > 0.0 && quota / period >= 1.0 && quota / period < (double)n) n = (unsigned)(quota / period + 0.5);
+    }
+    return n < 1 ? 1 : n;
+}
+
 bool read_all(FILE *f, std::vector<uint8_t> *out) {
     uint8_t chunk[1 << 16];
     size_t n;
@@ -619,10 +646,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
     int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
     Mp3Pipe &P = mp3_pipe(c);
-    unsigned workers = std::thread::hardware_concurrency();
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof set, &set) == 0) workers = (unsigned)CPU_COUNT(&set);
-    if (workers < 1) workers = 1;
+    unsigned workers = usable_cores();
     if (workers > n) workers = (unsigned)n;
     if (P.scratch.size() < workers) P.scratch.resize(workers);
     for (Mp3Stage &st : P.stage)
@@ -633,6 +657,9 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
     if (rc != RG_OK) return rc;
     hipStream_t fs = c->user_attached ? c->user_stream : c->slot().stream;
 
+    const bool trace = getenv("RG_TRACE_FILES") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
     PipeRun R;
     {   // staging blocks no larger than the call needs: a single album of a dozen files should not pin 3 x 96 MB
         size_t total = 0;
@@ -643,6 +670,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         R.stage_want = std::min(kPipeStageBytes, total + total / 8 + ((size_t)1 << 16));
     }
     std::vector<PipeFile> pf(n);
+    std::atomic<uint64_t> t_read{0}, t_compact{0}, t_wait{0}, t_copy{0};  // trace: microseconds summed over the loader threads
     const std::string cmd = c->decoder_cmd;
     const int device = c->device;
     std::atomic<size_t> next_file{0};
@@ -668,6 +696,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         char msg[1024];
         if (!path) { (*rcs)[i] = RG_ERR_INVALID_ARG; err = "null path"; return; }
         size_t len = 0;
+        const double tl0 = trace ? now() : 0.0;
         if (!read_whole_file(path, &sc, &len)) {
             snprintf(msg, sizeof msg, "Failed to open: %s", path);  // src/replaygain.rs:804-805
             (*rcs)[i] = RG_ERR_IO;
@@ -682,6 +711,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         la.is_mp4 = rg_mp4_is_mp4_data(sc.p, len) != 0;
         rg_mp3_stream_info si;
         uint64_t main_len = 0;
+        const double tl1 = trace ? now() : 0.0;
         if (mp4 || rg_mp3_compact_stream(sc.p, len, &sc.slots, &main_len, &si) != RG_MP3DEC_OK || si.audio_frames == 0) {
             (*rcs)[i] = load_audio_for(cmd, 2, path, &la, &err);  // the decoder command, or the reference's probe error
             return;
@@ -701,6 +731,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         f.n_frames = si.audio_frames;
         uint8_t *dst = nullptr;
         PipeChunk *chunk = nullptr;
+        const double tl2 = trace ? now() : 0.0;
         {
             std::unique_lock<std::mutex> lk(R.m);
             for (;;) {
@@ -741,9 +772,17 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
             chunk->pending++;
             dst = P.stage[chunk->stage].p;
         }
+        const double tl3 = trace ? now() : 0.0;
         memcpy(dst + f.main_off, sc.p, (size_t)main_len);
         memset(dst + f.main_off + main_len, 0, (size_t)(f.slots_off - f.main_off - main_len));  // the bit reader looks a few bytes ahead
         memcpy(dst + f.slots_off, sc.slots.data(), slot_bytes);
+        if (trace) {
+            const double tl4 = now();
+            t_read += (uint64_t)((tl1 - tl0) * 1e6);
+            t_compact += (uint64_t)((tl2 - tl1) * 1e6);
+            t_wait += (uint64_t)((tl3 - tl2) * 1e6);
+            t_copy += (uint64_t)((tl4 - tl3) * 1e6);
+        }
         {
             std::lock_guard<std::mutex> lk(R.m);
             chunk->pending--;
@@ -808,8 +847,13 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
                 continue;
             }
             PipeChunk &ch = R.chunks[next];
+            const size_t done_now = R.files_done;
             lk.unlock();
+            const double t_i = now();
             int r = (result == RG_OK && !ch.files.empty()) ? issue(ch, next) : RG_OK;
+            if (trace)
+                fprintf(stderr, "[pipeline] chunk %zu: %zu files, %.1f MB, %llu units, ready at %.1f ms (files done %zu), enqueue took %.2f ms\n", next,
+                        ch.files.size(), ch.used / 1e6, (unsigned long long)ch.units, (t_i - t_start) * 1e3, done_now, (now() - t_i) * 1e3);
             lk.lock();
             if (r != RG_OK && result == RG_OK) result = r;
             if (r != RG_OK || ch.files.empty()) (void)hipEventRecord(P.stage[ch.stage].staged, fs);  // loaders wait on it before refilling the block
@@ -832,9 +876,14 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
     if (rc != RG_OK) return rc;
     if (R.hip_error != RG_OK) return rg_set_err(c, R.hip_error, "%s", R.hip_msg.c_str());
     // the device's findings: how much of each stream decoded
+    const double t_issued = now();
     rc = rg_mp3dev_fetch_results(c, n, fs);
     if (rc != RG_OK) return rc;
     RG_HIP(c, hipStreamSynchronize(fs));
+    if (trace)
+        fprintf(stderr, "[pipeline] all chunks enqueued at %.1f ms, device done at %.1f ms; %u loader threads, summed: read %.1f ms, compact %.1f ms, "
+                        "waiting for a block %.1f ms, copy into the block %.1f ms\n", (t_issued - t_start) * 1e3, (now() - t_start) * 1e3, workers,
+                t_read.load() / 1e3, t_compact.load() / 1e3, t_wait.load() / 1e3, t_copy.load() / 1e3);
     const uint32_t *granules = rg_mp3dev_results(c);
     for (size_t i = 0; i < n; ++i) {
         LoadedAudio &la = (*out)[i];
@@ -862,10 +911,7 @@ int load_many(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedA
         const int prc = load_many_pipelined(c, paths, n, out, &rcs, &errs);
         if (prc != RG_OK) return prc;
     } else {
-        unsigned workers = std::thread::hardware_concurrency();
-        cpu_set_t set;
-        if (sched_getaffinity(0, sizeof set, &set) == 0) workers = (unsigned)CPU_COUNT(&set);
-        if (workers < 1) workers = 1;
+        unsigned workers = usable_cores();
         if (workers > n) workers = (unsigned)n;
         std::atomic<size_t> next{0};
         const std::string cmd = c->decoder_cmd;
@@ -1002,7 +1048,7 @@ extern "C" int rg_analyze_tracks(rg_ctx *c, const char *const *paths, size_t n, 
             continue;
         }
         uint32_t rate = in[i].sample_rate;
-        if (!in[i].decoded && !in[i].split) {
+        if (!in[i].decoded && !in[i].split && !in[i].staged) {
             rg_wav_info wi;
             rate = rg_wav_parse(in[i].wav.data(), in[i].wav.size(), &wi) == RG_OK ? wi.sample_rate : 0;
             if (rate == 0) {
