@@ -150,6 +150,7 @@ struct rg_ctx {
     hipEvent_t mp3_set_free[2] = {nullptr, nullptr};
     bool mp3_set_used[2] = {false, false};
     DevBuf<uint32_t> d_mp3_results;
+    DevBuf<uint32_t> d_mp3_tiles;            // frame parser: per tile, granule-channels found and their prefix
     PinnedBuf<uint32_t> h_mp3_results;
     void *mp3_pipe = nullptr;                // rg_files.hip: pinned staging blocks of the loader pipeline
     void (*mp3_pipe_free)(void *) = nullptr;

@@ -562,6 +562,7 @@ struct Mp3Scratch {
     uint8_t *p = nullptr;
     size_t cap = 0;
     std::vector<uint8_t> slots;
+    std::vector<uint64_t> tiles;
 };
 struct Mp3Pipe {
     static constexpr int NSTAGE = 3;
@@ -595,7 +596,7 @@ struct PipeChunk {
     bool closed = false, issued = false;
 };
 struct PipeFile {
-    uint64_t main_off = 0, main_len = 0, slots_off = 0;
+    uint64_t main_off = 0, main_len = 0, slots_off = 0, tiles_off = 0;
     uint32_t n_frames = 0;
 };
 struct PipeRun {
@@ -712,7 +713,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         rg_mp3_stream_info si;
         uint64_t main_len = 0;
         const double tl1 = trace ? now() : 0.0;
-        if (mp4 || rg_mp3_compact_stream(sc.p, len, &sc.slots, &main_len, &si) != RG_MP3DEC_OK || si.audio_frames == 0) {
+        if (mp4 || rg_mp3_compact_stream(sc.p, len, &sc.slots, &sc.tiles, &main_len, &si) != RG_MP3DEC_OK || si.audio_frames == 0) {
             (*rcs)[i] = load_audio_for(cmd, 2, path, &la, &err);  // the decoder command, or the reference's probe error
             return;
         }
@@ -724,8 +725,8 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         la.result_index = (uint32_t)i;
         la.staged = true;
         const uint64_t units = (uint64_t)si.audio_frames * (la.lsf ? 1u : 2u) * si.channels;
-        const size_t slot_bytes = sc.slots.size();
-        const size_t need = align64((size_t)main_len + 8) + align64(slot_bytes);
+        const size_t slot_bytes = sc.slots.size(), tile_bytes = sc.tiles.size() * sizeof(uint64_t);
+        const size_t need = align64((size_t)main_len + 8) + align64(slot_bytes) + align64(tile_bytes);
         PipeFile &f = pf[i];
         f.main_len = main_len;
         f.n_frames = si.audio_frames;
@@ -766,7 +767,8 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
             chunk = &R.chunks[(size_t)R.open];
             f.main_off = chunk->used;
             f.slots_off = f.main_off + align64((size_t)main_len + 8);
-            chunk->used = f.slots_off + align64(slot_bytes);
+            f.tiles_off = f.slots_off + align64(slot_bytes);
+            chunk->used = f.tiles_off + align64(tile_bytes);
             chunk->units += units;
             chunk->files.push_back(i);
             chunk->pending++;
@@ -776,6 +778,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         memcpy(dst + f.main_off, sc.p, (size_t)main_len);
         memset(dst + f.main_off + main_len, 0, (size_t)(f.slots_off - f.main_off - main_len));  // the bit reader looks a few bytes ahead
         memcpy(dst + f.slots_off, sc.slots.data(), slot_bytes);
+        memcpy(dst + f.tiles_off, sc.tiles.data(), tile_bytes);
         if (trace) {
             const double tl4 = now();
             t_read += (uint64_t)((tl1 - tl0) * 1e6);
@@ -819,6 +822,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
             RgMp3StreamItem &it = items[k];
             it.main_off = pf[i].main_off;
             it.slots_off = pf[i].slots_off;
+            it.tiles_off = pf[i].tiles_off;
             it.n_frames = pf[i].n_frames;
             it.channels = la.channels;
             it.rate_row = (uint32_t)rg_mp3_rate_row(la.sample_rate);
@@ -1134,7 +1138,7 @@ extern "C" int rg_mp3_decode_device(rg_ctx *c, const void *data, size_t len, flo
         memcpy(sc.p, data, len);
         memset(sc.p + len, 0, 64);
         uint64_t main_len = 0;
-        if (rg_mp3_compact_stream(sc.p, len, &sc.slots, &main_len, out) != RG_MP3DEC_OK)
+        if (rg_mp3_compact_stream(sc.p, len, &sc.slots, &sc.tiles, &main_len, out) != RG_MP3DEC_OK)
             return rg_set_err(c, RG_ERR_FORMAT, "%s", rg_mp3dec_last_error());
         if (out->frames > capacity) return rg_set_err(c, RG_ERR_INVALID_ARG, "capacity %llu < %llu frames", (unsigned long long)capacity, (unsigned long long)out->frames);
         if (out->channels == 2 && !ch1) return rg_set_err(c, RG_ERR_INVALID_ARG, "stereo stream needs a second output channel");
@@ -1146,7 +1150,8 @@ extern "C" int rg_mp3_decode_device(rg_ctx *c, const void *data, size_t len, flo
         RgMp3StreamItem it{};
         it.main_off = 0;
         it.slots_off = align64((size_t)main_len + 8);
-        const size_t tracks_off = it.slots_off + align64(sc.slots.size());
+        it.tiles_off = it.slots_off + align64(sc.slots.size());
+        const size_t tracks_off = it.tiles_off + align64(sc.tiles.size() * sizeof(uint64_t));
         const size_t total = tracks_off + rg_mp3dev_track_bytes(1);
         if (st.cap < total) {
             if (st.p) (void)hipHostFree(st.p);
@@ -1158,6 +1163,7 @@ extern "C" int rg_mp3_decode_device(rg_ctx *c, const void *data, size_t len, flo
         memcpy(st.p, sc.p, (size_t)main_len);
         memset(st.p + main_len, 0, (size_t)(it.slots_off - main_len));
         memcpy(st.p + it.slots_off, sc.slots.data(), sc.slots.size());
+        memcpy(st.p + it.tiles_off, sc.tiles.data(), sc.tiles.size() * sizeof(uint64_t));
         it.n_frames = out->audio_frames;
         it.channels = out->channels;
         it.rate_row = (uint32_t)rg_mp3_rate_row(out->sample_rate);

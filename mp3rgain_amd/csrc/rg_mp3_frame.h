@@ -15,6 +15,8 @@
 // A frame as the host's walk hands it to the device: the 4 header bytes, then the side information (9 / 17 / 32 bytes;
 // a CRC word between the two is left out), zero padded (the side-information reader looks two bytes ahead).
 #define RG_MP3_SLOT_BYTES 40
+// The device parses the frames in tiles of this many; the host's walk notes where each tile starts in the bit reservoir.
+#define RG_MP3_FRAME_TILE 256
 
 struct RgMp3FrameHdr {
     uint8_t lsf;        // MPEG-2 / 2.5

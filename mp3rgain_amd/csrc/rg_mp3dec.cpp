@@ -1073,13 +1073,16 @@ int rg_mp3_index_stream(const void *data, size_t len, std::vector<uint8_t> *main
 // data (every walked frame's bytes after header, CRC and side information, back to back from data[0]: the destination
 // never overtakes the walk), and each walked frame leaves one slot (rg_mp3_frame.h: header + side information) in `slots`.
 // Which frames decode, and to what, is the device's business (rg_mp3_frames_kernel).
-int rg_mp3_compact_stream(uint8_t *data, size_t len, std::vector<uint8_t> *slots, uint64_t *main_len_out, rg_mp3_stream_info *out) {
-    if (!data || !slots || !main_len_out || !out) return fail(RG_MP3DEC_ERR_ARG, "null argument");
+int rg_mp3_compact_stream(uint8_t *data, size_t len, std::vector<uint8_t> *slots, std::vector<uint64_t> *tiles, uint64_t *main_len_out,
+                          rg_mp3_stream_info *out) {
+    if (!data || !slots || !tiles || !main_len_out || !out) return fail(RG_MP3DEC_ERR_ARG, "null argument");
     g_err[0] = 0;
     slots->clear();
+    tiles->clear();
     uint64_t at = 0;
     uint32_t nframes = 0;
     const int rc = walk_frames(data, len, out, [&](const uint8_t *f, const Header &h) {
+        if (nframes % RG_MP3_FRAME_TILE == 0) tiles->push_back(at);  // where the tile's first frame sits in the bit reservoir
         const size_t so = slots->size();
         slots->resize(so + RG_MP3_SLOT_BYTES, 0);
         const uint8_t *side = f + 4 + (h.crc ? 2 : 0);
@@ -1103,21 +1106,24 @@ int rg_mp3_compact_stream(uint8_t *data, size_t len, std::vector<uint8_t> *slots
 // device) and compares main data and records.  0 = identical, 1 = different, < 0 = the stream has no audio.
 extern "C" int rg_mp3_index_selfcheck(const void *data, size_t len) {
     std::vector<uint8_t> main_a, slots;
+    std::vector<uint64_t> tiles;
     std::vector<RgMp3HuffRec> recs_a, recs_b;
     rg_mp3_stream_info ia, ib;
     const int rc = rg_mp3_index_stream(data, len, &main_a, &recs_a, &ia);
     std::vector<uint8_t> copy((const uint8_t *)data, (const uint8_t *)data + len);
     uint64_t main_len = 0;
-    const int rc2 = rg_mp3_compact_stream(copy.data(), len, &slots, &main_len, &ib);
+    const int rc2 = rg_mp3_compact_stream(copy.data(), len, &slots, &tiles, &main_len, &ib);
     if (rc != rc2) return 1;
     if (rc != RG_MP3DEC_OK) return rc;
     if (main_len != main_a.size() || memcmp(copy.data(), main_a.data(), main_len) != 0) return 1;
     uint64_t have = 0;
     uint32_t decoded = 0;
     const size_t nframes = slots.size() / RG_MP3_SLOT_BYTES;
+    if (tiles.size() != (nframes + RG_MP3_FRAME_TILE - 1) / RG_MP3_FRAME_TILE) return 1;
     for (size_t f = 0; f < nframes; ++f) {
         RgMp3HuffRec r[4];
         uint32_t mb = 0;
+        if (f % RG_MP3_FRAME_TILE == 0 && tiles[f / RG_MP3_FRAME_TILE] != have) return 1;
         const int n = rg_mp3_frame_records(slots.data() + f * RG_MP3_SLOT_BYTES, have, (int)ib.channels, r, &mb);
         have += mb;
         if (n) { recs_b.insert(recs_b.end(), r, r + n); ++decoded; }

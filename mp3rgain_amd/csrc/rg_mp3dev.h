@@ -8,6 +8,7 @@
 
 #define RG_MP3_GAIN_Q_MIN (-512)   // requantisation gains 2^(q/4) are tabulated for q in [RG_MP3_GAIN_Q_MIN, RG_MP3_GAIN_Q_MAX]
 #define RG_MP3_GAIN_Q_MAX 64
+#define RG_MP3_HUFF_LDS_ENTRIES 7808  // room for the flattened Huffman tables in the Huffman kernel's LDS (they have 7752 entries)
 #define RG_MP3_SYNTH_RUN 6        // consecutive granules of one channel per block of the synthesis kernel
 
 // Every constant the device stages use, built once on the host from the very tables the host decoder uses, so that
@@ -81,8 +82,9 @@ struct RgMp3DevTrack {
     uint32_t synth_base;     // first block of the track in the synthesis kernel's grid
     uint32_t n_frames;       // tuning key 6 = 3: frames the host walked (slots); the device decides which decode
     uint64_t slots_base;     //   byte offset of the track's slots (rg_mp3_frame.h) in the chunk buffer
-    uint32_t result_index;   //   where rg_mp3_frames_kernel reports the granules it found decodable
-    uint32_t pad_;
+    uint32_t result_index;   //   where the frame parser reports the granules it found decodable
+    uint32_t tile_base;      //   first tile (RG_MP3_FRAME_TILE frames) of the track in the chunk's tile numbering
+    uint64_t tiles_base;     //   byte offset of the track's tile table (uint64 per tile: main-data bytes before the tile)
 };
 // With the device-side frame parser (rg_mp3_frames_kernel) unit_base / granule_base / fc_base / synth_base and the grids
 // are laid out for the upper bound "every walked frame decodes"; the kernel then overwrites n_granules (and ch1, which
@@ -97,7 +99,9 @@ int rg_mp3_index_stream(const void *data, size_t len, std::vector<uint8_t> *main
                         rg_mp3_stream_info *info);
 // host (rg_mp3dec.cpp), tuning key 6 = 3: compacts `data` in place into the stream's main data and leaves one slot
 // (rg_mp3_frame.h) per walked frame; info->frames is an upper bound, the device decides which frames decode.
-int rg_mp3_compact_stream(uint8_t *data, size_t len, std::vector<uint8_t> *slots, uint64_t *main_len, rg_mp3_stream_info *info);
+// `tiles`: for every RG_MP3_FRAME_TILE frames, the main-data bytes that precede the tile's first frame.
+int rg_mp3_compact_stream(uint8_t *data, size_t len, std::vector<uint8_t> *slots, std::vector<uint64_t> *tiles, uint64_t *main_len,
+                          rg_mp3_stream_info *info);
 extern "C" {
 #endif
 // host: fill the table blocks (rg_mp3dec.cpp)

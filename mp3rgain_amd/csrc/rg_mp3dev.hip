@@ -375,251 +375,373 @@ rg_mp3_synth_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *_
 
 // =====================================================================================================================
 // Stage A's heavy part on the device: scalefactors + Huffman-coded spectrum (rg_mp3dec.cpp: read_scalefactors_v1 /
-// read_scalefactors_lsf / decode_spectrum), one thread per (frame, channel) -- granule 1 of an MPEG-1 frame may reuse
-// granule 0's scalefactors (scfsi), so a thread does its channel's granules in order.  Integer work throughout: the
-// outputs (576 int16 per unit + one rg_mp3_unit) are exactly what rg_mp3_parse_units writes on the host.
-__global__ void __launch_bounds__(64)
-rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *__restrict__ H,
-                      const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks, const RgMp3HuffRec *__restrict__ recs,
-                      const uint8_t *__restrict__ main, rg_mp3_unit *__restrict__ units, int16_t *__restrict__ is, uint32_t total_fc) {
-    const uint32_t fc = blockIdx.x * blockDim.x + threadIdx.x;
-    if (fc >= total_fc) return;
-    const uint32_t ti = find_by_fc(tracks, n_tracks, fc);
-    const RgMp3DevTrack tr = tracks[ti];
-    const uint32_t local = fc - tr.fc_base;
-    const int nch = (int)tr.channels, ngr = tr.lsf ? 1 : 2, rr = (int)tr.rate_row;
-    const uint32_t f = local / nch;
-    const int c = (int)(local % nch);
-    if (f * (uint32_t)ngr >= tr.n_granules) return;
-    static const uint8_t kSlen0[16] = {0, 0, 0, 0, 3, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4};
-    static const uint8_t kSlen1[16] = {0, 1, 2, 3, 0, 1, 2, 3, 1, 2, 3, 1, 2, 3, 2, 3};
-    static const uint8_t kPart[6][3][4] = {
-        {{6, 5, 5, 5}, {9, 9, 9, 9}, {6, 9, 9, 9}},   {{6, 5, 7, 3}, {9, 9, 12, 6}, {6, 9, 12, 6}},
-        {{11, 10, 0, 0}, {18, 18, 0, 0}, {15, 18, 0, 0}}, {{7, 7, 7, 0}, {12, 12, 12, 0}, {6, 15, 12, 0}},
-        {{6, 6, 6, 3}, {12, 9, 9, 6}, {6, 12, 9, 6}},  {{8, 8, 5, 0}, {15, 12, 9, 0}, {6, 18, 9, 0}}};
-    uint8_t sf0[40];  // granule 0's scalefactors (scfsi)
-    for (int gr = 0; gr < ngr; ++gr) {
-        const uint64_t u = tr.unit_base + ((uint64_t)f * ngr + gr) * nch + c;
-        const RgMp3HuffRec r = recs[u];
-        const uint8_t *__restrict__ tmain = main + tr.main_base;  // the records' bit offsets are relative to the track's stream
-        DevBits b{tmain, r.bit_off, r.bit_off + r.part2_3_length, r.frame_end_bit};
-        uint8_t sf[40];
-        uint64_t illegal = 0;
-        int preflag = r.preflag;
-        // ---- band layout and big_values regions (rg_mp3dec.cpp: parse_side_info, derived part) ----
-        int long_end, short_start;
+// read_scalefactors_lsf / decode_spectrum), one thread per granule and channel.  Integer work throughout: the outputs
+// (576 int16 per unit + one rg_mp3_unit) are exactly what rg_mp3_parse_units writes on the host.
+//
+// The decode is a chain of dependent look-ups per symbol, so everything a symbol touches is kept close: the code tables
+// of all 32 table numbers sit in LDS (31 KB, copied once per block of 512 units), the bit stream is read through three
+// registers of 32 bits with the next word always in flight, scalefactors are parsed into an LDS column per thread, and
+// the spectrum leaves in 16-byte stores.  Granule 1 of an MPEG-1 frame may reuse granule 0's scalefactors (scfsi): its
+// thread then parses granule 0's scalefactors first, which is cheaper than chaining the two granules in one thread.
+namespace {
+
+constexpr int kHuffThreads = 512;
+
+// 96 bits of the track's main data around `pos`, big-endian words; bits at or past `limit` (the end of the frame's own
+// main data) read as zero, which is what the host decoder's private copy of the frame's data does.
+struct BitCache {
+    const uint32_t *__restrict__ w;  // the track's main data (4-byte aligned)
+    uint64_t pos, end, limit;
+    uint64_t idx;                    // word index of w0
+    uint32_t w0, w1, w2;
+    __device__ __forceinline__ uint32_t load(uint64_t i) const {
+        const int64_t valid = (int64_t)limit - (int64_t)(i << 5);
+        if (valid <= 0) return 0u;
+        uint32_t x = __builtin_bswap32(w[i]);
+        if (valid < 32) x &= 0xFFFFFFFFu << (32 - (int)valid);
+        return x;
+    }
+    __device__ __forceinline__ void seek(uint64_t p) {
+        pos = p;
+        idx = p >> 5;
+        w0 = load(idx);
+        w1 = load(idx + 1);
+        w2 = load(idx + 2);
+    }
+    __device__ __forceinline__ uint32_t peek(int n) const {  // 1 <= n <= 25
+        const uint64_t two = ((uint64_t)w0 << 32) | (uint64_t)w1;
+        return (uint32_t)((two << (pos & 31)) >> (64 - n));
+    }
+    __device__ __forceinline__ void skip(int n) {  // n <= 32
+        pos += (uint64_t)n;
+        if ((pos >> 5) != idx) {
+            ++idx;
+            w0 = w1;
+            w1 = w2;
+            w2 = load(idx + 2);
+        }
+    }
+    __device__ __forceinline__ uint32_t get(int n) {
+        if (n == 0) return 0;
+        const uint32_t v = peek(n);
+        skip(n);
+        return v;
+    }
+    __device__ __forceinline__ uint32_t get1() { return get(1); }
+};
+
+// Scalefactors of one granule into the thread's LDS column sf[i * kHuffThreads] (rg_mp3dec.cpp: read_scalefactors_v1 /
+// read_scalefactors_lsf).  `reuse` = granule 1 of an MPEG-1 long block whose column already holds granule 0's values:
+// the groups flagged in scfsi keep them.
+__device__ __forceinline__ void huff_scalefactors(BitCache &b, const RgMp3HuffRec &r, bool lsf, bool reuse, uint8_t *__restrict__ sf,
+                                                  uint64_t *illegal, int *preflag) {
+    constexpr int S = kHuffThreads;
+    *illegal = 0;
+    *preflag = r.preflag;
+    if (!lsf) {
+        const int sc = r.scalefac_compress & 15;
+        const int s1 = (int)((0x4433322211130000ull >> (4 * sc)) & 15);   // {0,0,0,0,3,1,1,1,2,2,2,3,3,3,4,4}
+        const int s2 = (int)((0x3232132132103210ull >> (4 * sc)) & 15);   // {0,1,2,3,0,1,2,3,1,2,3,1,2,3,2,3}
         if (r.block_type == 2) {
-            if (r.mixed) { long_end = rr <= 2 ? 8 : 6; short_start = 3; }
-            else { long_end = 0; short_start = 0; }
-        } else { long_end = 22; short_start = 13; }
-        const int bv2 = (int)r.big_values * 2;
-        int r0, r1;
-        if (r.block_type != 0) {
-            r0 = r.block_type == 2 ? 3 * (int)T->sfb_short[rr][3] : (int)T->sfb_long[rr][8];
-            r1 = 576;
-        } else {
-            const int i0 = r.region0_count + 1, i1 = r.region0_count + r.region1_count + 2;
-            r0 = T->sfb_long[rr][i0 > 22 ? 22 : i0];
-            r1 = T->sfb_long[rr][i1 > 22 ? 22 : i1];
-        }
-        const int region_end[3] = {r0 < bv2 ? r0 : bv2, r1 < bv2 ? r1 : bv2, bv2};
-        // ---- scalefactors ----
-        if (!tr.lsf) {
-            const int s1 = kSlen0[r.scalefac_compress & 15], s2 = kSlen1[r.scalefac_compress & 15];
-            if (r.block_type == 2) {
-                int i = 0;
-                if (r.mixed) {
-                    for (; i < 8; ++i) sf[i] = (uint8_t)b.get(s1);
-                    for (int k = 0; k < 9; ++k) sf[i++] = (uint8_t)b.get(s1);
-                    for (int k = 0; k < 18; ++k) sf[i++] = (uint8_t)b.get(s2);
-                } else {
-                    for (int k = 0; k < 18; ++k) sf[i++] = (uint8_t)b.get(s1);
-                    for (int k = 0; k < 18; ++k) sf[i++] = (uint8_t)b.get(s2);
-                }
-                for (; i < 40; ++i) sf[i] = 0;
-            } else {
-                const int lo[5] = {0, 6, 11, 16, 21};
-                for (int k = 0; k < 4; ++k) {
-                    const int bits = k < 2 ? s1 : s2;
-                    if (gr == 1 && ((r.scfsi >> k) & 1)) {
-                        for (int band = lo[k]; band < lo[k + 1]; ++band) sf[band] = sf0[band];
-                    } else {
-                        for (int band = lo[k]; band < lo[k + 1]; ++band) sf[band] = (uint8_t)b.get(bits);
-                    }
-                }
-                for (int i = 21; i < 40; ++i) sf[i] = 0;
-            }
-        } else {
-            int slen[4], set;
-            int sfc = r.scalefac_compress;
-            preflag = 0;
-            if (!r.intensity_right) {
-                if (sfc < 400) { slen[0] = (sfc >> 4) / 5; slen[1] = (sfc >> 4) % 5; slen[2] = (sfc & 15) >> 2; slen[3] = sfc & 3; set = 0; }
-                else if (sfc < 500) { sfc -= 400; slen[0] = (sfc >> 2) / 5; slen[1] = (sfc >> 2) % 5; slen[2] = sfc & 3; slen[3] = 0; set = 1; }
-                else { sfc -= 500; slen[0] = sfc / 3; slen[1] = sfc % 3; slen[2] = 0; slen[3] = 0; set = 2; preflag = 1; }
-            } else {
-                sfc >>= 1;
-                if (sfc < 180) { slen[0] = sfc / 36; slen[1] = (sfc % 36) / 6; slen[2] = (sfc % 36) % 6; slen[3] = 0; set = 3; }
-                else if (sfc < 244) { sfc -= 180; slen[0] = (sfc & 0x3F) >> 4; slen[1] = (sfc & 0xF) >> 2; slen[2] = sfc & 3; slen[3] = 0; set = 4; }
-                else { sfc -= 244; slen[0] = sfc / 3; slen[1] = sfc % 3; slen[2] = 0; slen[3] = 0; set = 5; }
-            }
-            const int kind = r.block_type == 2 ? (r.mixed ? 2 : 1) : 0;
             int i = 0;
-            for (int k = 0; k < 4; ++k) {
-                const int n = kPart[set][kind][k];
-                for (int q = 0; q < n; ++q, ++i) {
-                    const int v = (int)b.get(slen[k]);
-                    sf[i] = (uint8_t)v;
-                    if (r.intensity_right && slen[k] > 0 && v == (1 << slen[k]) - 1) illegal |= 1ull << i;
-                }
-            }
-            for (; i < 40; ++i) sf[i] = 0;
-        }
-        if (gr == 0)
-            for (int i = 0; i < 40; ++i) sf0[i] = sf[i];
-        // ---- Huffman-coded spectrum ----
-        uint32_t *__restrict__ row = reinterpret_cast<uint32_t *>(is + u * 576);  // two int16 per word
-        int line = 0;
-        for (int reg = 0; reg < 3; ++reg) {
-            const int end = region_end[reg];
-            const int t = r.table_select[reg];
-            const int P = H->primary_bits[t];
-            if (P == 0) {
-                for (; line < end; line += 2) row[line >> 1] = 0u;
-                continue;
-            }
-            const uint32_t *__restrict__ E = H->e + H->base[t];
-            const int linbits = H->linbits[t];
-            while (line < end) {
-                if (b.pos >= b.end) { for (; line < end; line += 2) row[line >> 1] = 0u; break; }
-                uint32_t e = E[b.peek(P)];
-                if (e & 0x80000000u) {
-                    b.pos += P;
-                    e = E[((e >> 8) & 0x7FFFFF) + b.peek((int)(e & 0xFF))];
-                }
-                b.pos += e & 0xFF;
-                int x = (int)((e >> 12) & 15), y = (int)((e >> 8) & 15);
-                if (x) {
-                    if (linbits && x == 15) x += (int)b.get(linbits);
-                    if (b.get1()) x = -x;
-                }
-                if (y) {
-                    if (linbits && y == 15) y += (int)b.get(linbits);
-                    if (b.get1()) y = -y;
-                }
-                row[line >> 1] = ((uint32_t)x & 0xFFFFu) | ((uint32_t)y << 16);
-                line += 2;
-            }
-        }
-        while (line <= 572 && b.pos < b.end) {
-            int v;
-            if (r.count1table) {
-                v = (int)(~b.get(4)) & 15;
+            if (r.mixed) {
+                for (; i < 17; ++i) sf[i * S] = (uint8_t)b.get(s1);
+                for (int k = 0; k < 18; ++k) sf[(i++) * S] = (uint8_t)b.get(s2);
             } else {
-                const uint8_t q = H->quadA[b.peek(6)];
-                b.pos += q >> 4;
-                v = q & 15;
+                for (int k = 0; k < 18; ++k) sf[(i++) * S] = (uint8_t)b.get(s1);
+                for (int k = 0; k < 18; ++k) sf[(i++) * S] = (uint8_t)b.get(s2);
             }
-            int q4[4];
-#pragma unroll
+            for (; i < 40; ++i) sf[i * S] = 0;
+        } else {
             for (int k = 0; k < 4; ++k) {
-                q4[k] = (v >> (3 - k)) & 1;
-                if (q4[k] && b.get1()) q4[k] = -1;
+                const int lo = k == 0 ? 0 : 1 + 5 * k, hi = 6 + 5 * k;  // bands 0-5, 6-10, 11-15, 16-20
+                const int bits = k < 2 ? s1 : s2;
+                if (reuse && ((r.scfsi >> k) & 1)) continue;
+                for (int band = lo; band < hi; ++band) sf[band * S] = (uint8_t)b.get(bits);
             }
-            if (b.pos > b.end) break;  // the quadruple ran past the granule's bits: stuffing, not data
-            row[line >> 1] = ((uint32_t)q4[0] & 0xFFFFu) | ((uint32_t)q4[1] << 16);
-            row[(line >> 1) + 1] = ((uint32_t)q4[2] & 0xFFFFu) | ((uint32_t)q4[3] << 16);
-            line += 4;
+            for (int i = 21; i < 40; ++i) sf[i * S] = 0;
         }
-        const int nz = line;
-        for (; line < 576; line += 2) row[line >> 1] = 0u;
-        // ---- the unit ----
-        rg_mp3_unit o;
-#pragma unroll
-        for (int i = 0; i < 40; ++i) o.sf[i] = sf[i];
-        o.illegal = illegal;
-        o.nz = (uint16_t)nz;
-        o.global_gain = r.global_gain;
-        o.block_type = r.block_type;
-        o.mixed = r.mixed;
-        o.subblock_gain[0] = r.subblock_gain[0]; o.subblock_gain[1] = r.subblock_gain[1]; o.subblock_gain[2] = r.subblock_gain[2];
-        o.scalefac_scale = r.scalefac_scale;
-        o.preflag = (uint8_t)preflag;
-        o.long_end = (uint8_t)long_end;
-        o.short_start = (uint8_t)short_start;
-        o.mode_ext = r.mode_ext;
-        o.intensity_scale = r.intensity_scale;
-        o.reserved[0] = o.reserved[1] = 0;
-        units[u] = o;
+    } else {
+        int slen[4], set;
+        int sfc = r.scalefac_compress;
+        *preflag = 0;
+        if (!r.intensity_right) {
+            if (sfc < 400) { slen[0] = (sfc >> 4) / 5; slen[1] = (sfc >> 4) % 5; slen[2] = (sfc & 15) >> 2; slen[3] = sfc & 3; set = 0; }
+            else if (sfc < 500) { sfc -= 400; slen[0] = (sfc >> 2) / 5; slen[1] = (sfc >> 2) % 5; slen[2] = sfc & 3; slen[3] = 0; set = 1; }
+            else { sfc -= 500; slen[0] = sfc / 3; slen[1] = sfc % 3; slen[2] = 0; slen[3] = 0; set = 2; *preflag = 1; }
+        } else {
+            sfc >>= 1;
+            if (sfc < 180) { slen[0] = sfc / 36; slen[1] = (sfc % 36) / 6; slen[2] = (sfc % 36) % 6; slen[3] = 0; set = 3; }
+            else if (sfc < 244) { sfc -= 180; slen[0] = (sfc & 0x3F) >> 4; slen[1] = (sfc & 0xF) >> 2; slen[2] = sfc & 3; slen[3] = 0; set = 4; }
+            else { sfc -= 244; slen[0] = sfc / 3; slen[1] = sfc % 3; slen[2] = 0; slen[3] = 0; set = 5; }
+        }
+        static const uint8_t kPart[6][3][4] = {
+            {{6, 5, 5, 5}, {9, 9, 9, 9}, {6, 9, 9, 9}},   {{6, 5, 7, 3}, {9, 9, 12, 6}, {6, 9, 12, 6}},
+            {{11, 10, 0, 0}, {18, 18, 0, 0}, {15, 18, 0, 0}}, {{7, 7, 7, 0}, {12, 12, 12, 0}, {6, 15, 12, 0}},
+            {{6, 6, 6, 3}, {12, 9, 9, 6}, {6, 12, 9, 6}},  {{8, 8, 5, 0}, {15, 12, 9, 0}, {6, 18, 9, 0}}};
+        const int kind = r.block_type == 2 ? (r.mixed ? 2 : 1) : 0;
+        int i = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int n = kPart[set][kind][k];
+            for (int q = 0; q < n; ++q, ++i) {
+                const int v = (int)b.get(slen[k]);
+                sf[i * S] = (uint8_t)v;
+                if (r.intensity_right && slen[k] > 0 && v == (1 << slen[k]) - 1) *illegal |= 1ull << i;
+            }
+        }
+        for (; i < 40; ++i) sf[i * S] = 0;
     }
 }
 
-// Tuning key 6 = 3: the frame parser.  One block per track walks the track's slots (header + side information of every
-// frame the host's walk found, rg_mp3_frame.h) 256 frames at a time: a prefix sum of the frames' main-data sizes gives
-// each frame its place in the bit reservoir, rg_mp3_frame_records -- the very code the host route runs -- decides whether
-// it decodes, and a prefix sum of the survivors numbers their granules.  Records go out compacted (a dropped frame
-// leaves no gap in the PCM, exactly as on the host); the track's decoded length replaces the upper bound in its
-// descriptor, the second channel's plane moves up behind the first, and the host reads the count from `results`.
-__global__ void __launch_bounds__(256)
-rg_mp3_frames_kernel(RgMp3DevTrack *__restrict__ tracks, const uint8_t *__restrict__ chunk, RgMp3HuffRec *__restrict__ recs,
-                     uint32_t *__restrict__ results) {
-    __shared__ uint32_t wave_sum[2][4];
-    const RgMp3DevTrack tr = tracks[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint8_t *__restrict__ slots = chunk + tr.slots_base;
-    uint64_t have_base = 0;
-    uint32_t unit_run = 0;
-    // exclusive prefix of (a, b) over the block; totals in ta / tb
-    auto scan2 = [&](uint32_t a, uint32_t b, uint32_t *ea, uint32_t *eb, uint32_t *ta, uint32_t *tb) {
-        uint32_t ia = a, ib = b;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t xa = __shfl_up(ia, d), xb = __shfl_up(ib, d);
-            if (lane >= d) { ia += xa; ib += xb; }
+// the spectrum leaves four words (eight lines) at a time
+struct RowOut {
+    uint4 *__restrict__ row;  // the unit's 576 int16 = 72 x 16 bytes
+    uint32_t a, b, c;
+    __device__ __forceinline__ void put(int line, uint32_t word) {  // `line` even; words arrive in order
+        switch ((line >> 1) & 3) {
+            case 0: a = word; break;
+            case 1: b = word; break;
+            case 2: c = word; break;
+            default: row[line >> 3] = make_uint4(a, b, c, word); break;
         }
-        __syncthreads();  // the previous tile's totals have been read
-        if (lane == 63) { wave_sum[0][wave] = ia; wave_sum[1][wave] = ib; }
-        __syncthreads();
-        uint32_t oa = 0, ob = 0, sa = 0, sb = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            if (w < wave) { oa += wave_sum[0][w]; ob += wave_sum[1][w]; }
-            sa += wave_sum[0][w];
-            sb += wave_sum[1][w];
-        }
-        *ea = oa + ia - a;
-        *eb = ob + ib - b;
-        *ta = sa;
-        *tb = sb;
-    };
-    for (uint32_t f0 = 0; f0 < tr.n_frames; f0 += 256) {
-        const uint32_t f = f0 + (uint32_t)tid;
-        const bool live = f < tr.n_frames;
-        uint64_t raw[RG_MP3_SLOT_BYTES / 8];
-        uint32_t main_bytes = 0;
-        if (live) {
-            const uint64_t *src = reinterpret_cast<const uint64_t *>(slots + (size_t)f * RG_MP3_SLOT_BYTES);  // slots_base is 8-byte aligned
-#pragma unroll
-            for (int k = 0; k < RG_MP3_SLOT_BYTES / 8; ++k) raw[k] = src[k];
-            RgMp3FrameHdr h;
-            if (rg_mp3_frame_header(reinterpret_cast<const uint8_t *>(raw), &h)) main_bytes = rg_mp3_frame_main_bytes(h);
-        }
-        uint32_t have_excl, dummy_e, have_total, dummy_t;
-        scan2(main_bytes, 0u, &have_excl, &dummy_e, &have_total, &dummy_t);
-        RgMp3HuffRec r[4];
-        uint32_t n = 0;
-        if (live) {
-            uint32_t mb;
-            n = (uint32_t)rg_mp3_frame_records(reinterpret_cast<const uint8_t *>(raw), have_base + have_excl, (int)tr.channels, r, &mb);
-        }
-        uint32_t unit_excl, unit_total;
-        scan2(n, 0u, &unit_excl, &dummy_e, &unit_total, &dummy_t);
-        for (uint32_t i = 0; i < n; ++i) recs[tr.unit_base + unit_run + unit_excl + i] = r[i];
-        have_base += have_total;
-        unit_run += unit_total;
     }
-    if (tid == 0) {
-        const uint32_t granules = unit_run / tr.channels;
+    // zeros from `line` (even) to the end of the row
+    __device__ __forceinline__ void finish(int line) {
+        for (; (line & 7) != 0 && line < 576; line += 2) put(line, 0u);
+        for (; line < 576; line += 8) row[line >> 3] = make_uint4(0u, 0u, 0u, 0u);
+    }
+};
+
+}  // namespace
+
+__global__ void __launch_bounds__(kHuffThreads)
+rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *__restrict__ H,
+                      const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks, const RgMp3HuffRec *__restrict__ recs,
+                      const uint8_t *__restrict__ main, rg_mp3_unit *__restrict__ units, int16_t *__restrict__ is, uint64_t total_units) {
+    __shared__ uint32_t E_all[RG_MP3_HUFF_LDS_ENTRIES];
+    __shared__ uint32_t t_base[32];
+    __shared__ uint8_t t_pbits[32], t_linbits[32], quadA[64];
+    __shared__ uint8_t sf_all[40 * kHuffThreads];
+    const int tid = threadIdx.x;
+    const uint32_t n_e = H->n_entries;  // <= RG_MP3_HUFF_LDS_ENTRIES: checked when the tables are uploaded
+    for (uint32_t i = tid; i < n_e; i += kHuffThreads) E_all[i] = H->e[i];
+    if (tid < 32) { t_base[tid] = H->base[tid]; t_pbits[tid] = H->primary_bits[tid]; t_linbits[tid] = H->linbits[tid]; }
+    if (tid < 64) quadA[tid] = H->quadA[tid];
+    __syncthreads();
+    const uint64_t u = (uint64_t)blockIdx.x * kHuffThreads + (uint64_t)tid;
+    if (u >= total_units) return;
+    const uint32_t ti = find_by_unit(tracks, n_tracks, u);
+    const RgMp3DevTrack tr = tracks[ti];
+    const int nch = (int)tr.channels, rr = (int)tr.rate_row;
+    const uint64_t local = u - tr.unit_base;
+    if (local >= (uint64_t)tr.n_granules * nch) return;  // past what the frame parser found decodable
+    const RgMp3HuffRec r = recs[u];
+    uint8_t *__restrict__ sf = sf_all + tid;
+    BitCache b;
+    b.w = reinterpret_cast<const uint32_t *>(main + tr.main_base);  // the records' bit offsets are relative to the track's stream
+    uint64_t illegal = 0;
+    int preflag = 0;
+    const bool reuse = !tr.lsf && r.gr == 1 && r.block_type != 2 && r.scfsi != 0;
+    if (reuse) {  // granule 0 of the same frame and channel sits nch units back
+        const RgMp3HuffRec r0 = recs[u - nch];
+        b.end = r0.bit_off + r0.part2_3_length;
+        b.limit = r0.frame_end_bit;
+        b.seek(r0.bit_off);
+        huff_scalefactors(b, r0, false, false, sf, &illegal, &preflag);
+    }
+    b.end = r.bit_off + r.part2_3_length;
+    b.limit = r.frame_end_bit;
+    b.seek(r.bit_off);
+    huff_scalefactors(b, r, tr.lsf != 0, reuse, sf, &illegal, &preflag);
+    // ---- band layout and big_values regions (rg_mp3dec.cpp: parse_side_info, derived part) ----
+    int long_end, short_start;
+    if (r.block_type == 2) {
+        if (r.mixed) { long_end = rr <= 2 ? 8 : 6; short_start = 3; }
+        else { long_end = 0; short_start = 0; }
+    } else { long_end = 22; short_start = 13; }
+    const int bv2 = (int)r.big_values * 2;
+    int r0e, r1e;
+    if (r.block_type != 0) {
+        r0e = r.block_type == 2 ? 3 * (int)T->sfb_short[rr][3] : (int)T->sfb_long[rr][8];
+        r1e = 576;
+    } else {
+        const int i0 = r.region0_count + 1, i1 = r.region0_count + r.region1_count + 2;
+        r0e = T->sfb_long[rr][i0 > 22 ? 22 : i0];
+        r1e = T->sfb_long[rr][i1 > 22 ? 22 : i1];
+    }
+    // ---- Huffman-coded spectrum ----
+    RowOut out{reinterpret_cast<uint4 *>(is + u * 576), 0u, 0u, 0u};
+    int line = 0;
+#pragma unroll 1
+    for (int reg = 0; reg < 3; ++reg) {
+        int end = reg == 0 ? r0e : (reg == 1 ? r1e : bv2);
+        if (end > bv2) end = bv2;
+        const int t = r.table_select[reg];
+        const int P = t_pbits[t];
+        if (P == 0) {
+            for (; line < end; line += 2) out.put(line, 0u);
+            continue;
+        }
+        const uint32_t *__restrict__ E = E_all + t_base[t];
+        const int linbits = t_linbits[t];
+        while (line < end) {
+            if (b.pos >= b.end) { for (; line < end; line += 2) out.put(line, 0u); break; }
+            uint32_t e = E[b.peek(P)];
+            if (e & 0x80000000u) {
+                b.skip(P);
+                e = E[((e >> 8) & 0x7FFFFF) + b.peek((int)(e & 0xFF))];
+            }
+            b.skip((int)(e & 0xFF));
+            int x = (int)((e >> 12) & 15), y = (int)((e >> 8) & 15);
+            if (x) {
+                if (linbits && x == 15) x += (int)b.get(linbits);
+                if (b.get1()) x = -x;
+            }
+            if (y) {
+                if (linbits && y == 15) y += (int)b.get(linbits);
+                if (b.get1()) y = -y;
+            }
+            out.put(line, ((uint32_t)x & 0xFFFFu) | ((uint32_t)y << 16));
+            line += 2;
+        }
+    }
+    while (line <= 572 && b.pos < b.end) {
+        int v;
+        if (r.count1table) {
+            v = (int)(~b.get(4)) & 15;
+        } else {
+            const uint8_t q = quadA[b.peek(6)];
+            b.skip(q >> 4);
+            v = q & 15;
+        }
+        int q4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            q4[k] = (v >> (3 - k)) & 1;
+            if (q4[k] && b.get1()) q4[k] = -1;
+        }
+        if (b.pos > b.end) break;  // the quadruple ran past the granule's bits: stuffing, not data
+        out.put(line, ((uint32_t)q4[0] & 0xFFFFu) | ((uint32_t)q4[1] << 16));
+        out.put(line + 2, ((uint32_t)q4[2] & 0xFFFFu) | ((uint32_t)q4[3] << 16));
+        line += 4;
+    }
+    const int nz = line;
+    out.finish(line);
+    // ---- the unit ----
+    rg_mp3_unit o;
+#pragma unroll
+    for (int i = 0; i < 40; ++i) o.sf[i] = sf[i * kHuffThreads];
+    o.illegal = illegal;
+    o.nz = (uint16_t)nz;
+    o.global_gain = r.global_gain;
+    o.block_type = r.block_type;
+    o.mixed = r.mixed;
+    o.subblock_gain[0] = r.subblock_gain[0]; o.subblock_gain[1] = r.subblock_gain[1]; o.subblock_gain[2] = r.subblock_gain[2];
+    o.scalefac_scale = r.scalefac_scale;
+    o.preflag = (uint8_t)preflag;
+    o.long_end = (uint8_t)long_end;
+    o.short_start = (uint8_t)short_start;
+    o.mode_ext = r.mode_ext;
+    o.intensity_scale = r.intensity_scale;
+    o.reserved[0] = o.reserved[1] = 0;
+    units[u] = o;
+}
+
+// Tuning key 6 = 3: the frame parser.  The host's walk leaves one slot per frame (header + side information,
+// rg_mp3_frame.h) and, per tile of 256 frames, the main-data bytes that precede it.  Three small launches:
+//   count  one block per tile: a prefix sum of the frames' main-data sizes gives each frame its place in the bit
+//          reservoir, rg_mp3_frame_records -- the very code the host route runs -- decides whether it decodes; the tile's
+//          number of decodable granule-channels goes to tile_units
+//   scan   one block per track: prefix sum over the track's tiles; the track's decoded length replaces the upper bound
+//          in its descriptor, the second channel's plane moves up behind the first, the host reads the count from `results`
+//   write  the count pass again, now writing the records compacted (a dropped frame leaves no gap in the PCM, exactly
+//          as on the host)
+namespace {
+__device__ __forceinline__ uint32_t find_by_tile(const RgMp3DevTrack *__restrict__ tr, uint32_t n, uint32_t tile) {
+    uint32_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (tr[mid].tile_base <= tile) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+// exclusive prefix of `a` over a block of 256 threads; total in *ta
+__device__ __forceinline__ uint32_t block_scan256(uint32_t a, uint32_t *ta, uint32_t *wave_sum /* LDS, 4 */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t ia = a;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t xa = __shfl_up(ia, d);
+        if (lane >= d) ia += xa;
+    }
+    __syncthreads();  // an earlier scan's totals have been read
+    if (lane == 63) wave_sum[wave] = ia;
+    __syncthreads();
+    uint32_t off = 0, sum = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) off += wave_sum[w];
+        sum += wave_sum[w];
+    }
+    *ta = sum;
+    return off + ia - a;
+}
+}  // namespace
+
+template <bool WRITE>
+__global__ void __launch_bounds__(RG_MP3_FRAME_TILE)
+rg_mp3_frames_kernel(const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks, const uint8_t *__restrict__ chunk,
+                     uint32_t *__restrict__ tile_units, const uint32_t *__restrict__ tile_unit_base, RgMp3HuffRec *__restrict__ recs) {
+    __shared__ uint32_t wave_sum[4];
+    const uint32_t ti = find_by_tile(tracks, n_tracks, blockIdx.x);
+    const RgMp3DevTrack tr = tracks[ti];
+    const uint32_t tile = blockIdx.x - tr.tile_base;
+    const uint32_t f = tile * RG_MP3_FRAME_TILE + threadIdx.x;
+    const bool live = f < tr.n_frames;
+    uint64_t raw[RG_MP3_SLOT_BYTES / 8];
+    uint32_t main_bytes = 0;
+    if (live) {
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(chunk + tr.slots_base + (size_t)f * RG_MP3_SLOT_BYTES);  // 8-byte aligned
+#pragma unroll
+        for (int k = 0; k < RG_MP3_SLOT_BYTES / 8; ++k) raw[k] = src[k];
+        RgMp3FrameHdr h;
+        if (rg_mp3_frame_header(reinterpret_cast<const uint8_t *>(raw), &h)) main_bytes = rg_mp3_frame_main_bytes(h);
+    }
+    uint32_t total;
+    const uint32_t have_excl = block_scan256(main_bytes, &total, wave_sum);
+    const uint64_t have = reinterpret_cast<const uint64_t *>(chunk + tr.tiles_base)[tile] + have_excl;
+    RgMp3HuffRec r[4];
+    uint32_t n = 0;
+    if (live) {
+        uint32_t mb;
+        n = (uint32_t)rg_mp3_frame_records(reinterpret_cast<const uint8_t *>(raw), have, (int)tr.channels, r, &mb);
+    }
+    const uint32_t unit_excl = block_scan256(n, &total, wave_sum);
+    if (!WRITE) {
+        if (threadIdx.x == 0) tile_units[blockIdx.x] = total;
+    } else {
+        RgMp3HuffRec *__restrict__ dst = recs + tr.unit_base + tile_unit_base[blockIdx.x] + unit_excl;
+        for (uint32_t i = 0; i < n; ++i) dst[i] = r[i];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+rg_mp3_frames_scan_kernel(RgMp3DevTrack *__restrict__ tracks, const uint32_t *__restrict__ tile_units, uint32_t *__restrict__ tile_unit_base,
+                          uint32_t *__restrict__ results) {
+    __shared__ uint32_t wave_sum[4];
+    const RgMp3DevTrack tr = tracks[blockIdx.x];
+    const uint32_t n_tiles = (tr.n_frames + RG_MP3_FRAME_TILE - 1) / RG_MP3_FRAME_TILE;
+    uint32_t run = 0;
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += 256) {
+        const uint32_t t = t0 + threadIdx.x;
+        const uint32_t v = t < n_tiles ? tile_units[tr.tile_base + t] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_scan256(v, &total, wave_sum);
+        if (t < n_tiles) tile_unit_base[tr.tile_base + t] = run + ex;
+        run += total;
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t granules = run / tr.channels;
         tracks[blockIdx.x].n_granules = granules;
         if (tr.channels == 2) tracks[blockIdx.x].ch1 = tr.ch0 + (size_t)granules * 576;
         results[tr.result_index] = granules;
@@ -628,10 +750,10 @@ rg_mp3_frames_kernel(RgMp3DevTrack *__restrict__ tracks, const uint8_t *__restri
 
 extern "C" hipError_t rg_launch_mp3_huffman(const RgMp3DevTables *d_tab, const RgMp3DevHuff *d_huff, const RgMp3DevTrack *d_tracks,
                                             uint32_t n_tracks, const RgMp3HuffRec *d_recs, const uint8_t *d_main, rg_mp3_unit *d_units,
-                                            int16_t *d_is, uint32_t total_fc, hipStream_t s) {
-    if (total_fc == 0) return hipSuccess;
-    hipLaunchKernelGGL(rg_mp3_huffman_kernel, dim3((total_fc + 63) / 64), dim3(64), 0, s, d_tab, d_huff, d_tracks, n_tracks, d_recs,
-                       d_main, d_units, d_is, total_fc);
+                                            int16_t *d_is, uint64_t total_units, hipStream_t s) {
+    if (total_units == 0) return hipSuccess;
+    hipLaunchKernelGGL(rg_mp3_huffman_kernel, dim3((uint32_t)((total_units + kHuffThreads - 1) / kHuffThreads)), dim3(kHuffThreads), 0, s, d_tab,
+                       d_huff, d_tracks, n_tracks, d_recs, d_main, d_units, d_is, total_units);
     return hipGetLastError();
 }
 
@@ -650,9 +772,13 @@ extern "C" hipError_t rg_launch_mp3_synth(const RgMp3DevTables *d_tab, const RgM
     return hipGetLastError();
 }
 
-extern "C" hipError_t rg_launch_mp3_frames(RgMp3DevTrack *d_tracks, uint32_t n_tracks, const uint8_t *d_chunk, RgMp3HuffRec *d_recs,
-                                           uint32_t *d_results, hipStream_t s) {
-    if (n_tracks == 0) return hipSuccess;
-    hipLaunchKernelGGL(rg_mp3_frames_kernel, dim3(n_tracks), dim3(256), 0, s, d_tracks, d_chunk, d_recs, d_results);
+// tile_scratch: 2 x n_tiles words
+extern "C" hipError_t rg_launch_mp3_frames(RgMp3DevTrack *d_tracks, uint32_t n_tracks, uint32_t n_tiles, const uint8_t *d_chunk, uint32_t *tile_scratch,
+                                           RgMp3HuffRec *d_recs, uint32_t *d_results, hipStream_t s) {
+    if (n_tracks == 0 || n_tiles == 0) return hipSuccess;
+    uint32_t *units = tile_scratch, *base = tile_scratch + n_tiles;
+    hipLaunchKernelGGL((rg_mp3_frames_kernel<false>), dim3(n_tiles), dim3(RG_MP3_FRAME_TILE), 0, s, d_tracks, n_tracks, d_chunk, units, base, d_recs);
+    hipLaunchKernelGGL(rg_mp3_frames_scan_kernel, dim3(n_tracks), dim3(256), 0, s, d_tracks, units, base, d_results);
+    hipLaunchKernelGGL((rg_mp3_frames_kernel<true>), dim3(n_tiles), dim3(RG_MP3_FRAME_TILE), 0, s, d_tracks, n_tracks, d_chunk, units, base, d_recs);
     return hipGetLastError();
 }

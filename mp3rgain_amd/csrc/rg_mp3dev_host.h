@@ -32,6 +32,7 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
 struct RgMp3StreamItem {
     uint64_t main_off;     // staging block: the stream's main data (8 readable bytes follow it)
     uint64_t slots_off;    // staging block: n_frames slots of RG_MP3_SLOT_BYTES, 8-byte aligned
+    uint64_t tiles_off;    // staging block: one uint64 per RG_MP3_FRAME_TILE frames (rg_mp3_compact_stream's `tiles`)
     uint32_t n_frames;     // frames the host walked
     uint32_t channels, rate_row, lsf;
     uint32_t result_index; // h_mp3_results[result_index] = granules decoded, valid once stream `s` has been synchronised

@@ -6,14 +6,15 @@
 #include "rg_ctx.h"
 #include "rg_mp3dev.h"
 #include "rg_mp3dev_host.h"
+#include "rg_mp3_frame.h"
 
 extern "C" {
 hipError_t rg_launch_mp3_huffman(const RgMp3DevTables *, const RgMp3DevHuff *, const RgMp3DevTrack *, uint32_t, const RgMp3HuffRec *,
-                                 const uint8_t *, rg_mp3_unit *, int16_t *, uint32_t, hipStream_t);
+                                 const uint8_t *, rg_mp3_unit *, int16_t *, uint64_t, hipStream_t);
 hipError_t rg_launch_mp3_hybrid(const RgMp3DevTables *, const RgMp3DevTrack *, uint32_t, uint32_t, const rg_mp3_unit *,
                                 const int16_t *, float *, hipStream_t);
 hipError_t rg_launch_mp3_synth(const RgMp3DevTables *, const RgMp3DevTrack *, uint32_t, uint32_t, const float *, hipStream_t);
-hipError_t rg_launch_mp3_frames(RgMp3DevTrack *, uint32_t, const uint8_t *, RgMp3HuffRec *, uint32_t *, hipStream_t);
+hipError_t rg_launch_mp3_frames(RgMp3DevTrack *, uint32_t, uint32_t, const uint8_t *, uint32_t *, RgMp3HuffRec *, uint32_t *, hipStream_t);
 }
 
 namespace {
@@ -39,6 +40,11 @@ static int ensure_tables(rg_ctx *c) {
         RG_HIP(c, e);
         RgMp3DevHuff *hf = new RgMp3DevHuff();
         rg_mp3_fill_device_huff(hf);
+        if (hf->n_entries > RG_MP3_HUFF_LDS_ENTRIES) {
+            const uint32_t ne = hf->n_entries;
+            delete hf;
+            return rg_set_err(c, RG_ERR_DEVICE, "Huffman tables (%u entries) do not fit the kernel's LDS image", ne);
+        }
         e = c->d_mp3_huff.reserve(sizeof(RgMp3DevHuff));
         if (e == hipSuccess) e = hipMemcpy(c->d_mp3_huff.p, hf, sizeof(RgMp3DevHuff), hipMemcpyHostToDevice);
         delete hf;
@@ -113,7 +119,7 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
             if (any_recs) {
                 // a chunk is all of one kind (the file layer never mixes them); the Huffman stage fills d_mp3_is / d_mp3_units
                 RG_HIP(c, rg_launch_mp3_huffman(d_tab, d_huff, d_tr, (uint32_t)tr.size(), reinterpret_cast<const RgMp3HuffRec *>(c->d_mp3_recs.p),
-                                                c->d_mp3_main.p, reinterpret_cast<rg_mp3_unit *>(c->d_mp3_units.p), c->d_mp3_is.p, fcb, s));
+                                                c->d_mp3_main.p, reinterpret_cast<rg_mp3_unit *>(c->d_mp3_units.p), c->d_mp3_is.p, ub, s));
             }
             RG_HIP(c, rg_launch_mp3_hybrid(d_tab, d_tr, (uint32_t)tr.size(), gb, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p),
                                            c->d_mp3_is.p, c->d_mp3_hyb.p, s));
@@ -154,12 +160,15 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
     // the descriptors, laid out for the upper bound "every walked frame decodes"
     RgMp3DevTrack *tr = reinterpret_cast<RgMp3DevTrack *>(staging + tracks_off);
     uint64_t ub = 0;
-    uint32_t gb = 0, fcb = 0, sb = 0;
+    uint32_t gb = 0, fcb = 0, sb = 0, tb = 0;
     for (size_t i = 0; i < n; ++i) {
         const RgMp3StreamItem &it = items[i];
         RgMp3DevTrack &t = tr[i];
         memset(&t, 0, sizeof t);
         const uint32_t granules = it.n_frames * (it.lsf ? 1u : 2u);
+        t.tile_base = tb;
+        t.tiles_base = it.tiles_off;
+        tb += (it.n_frames + RG_MP3_FRAME_TILE - 1) / RG_MP3_FRAME_TILE;
         t.unit_base = ub;
         t.granule_base = gb;
         t.n_granules = granules;
@@ -188,6 +197,7 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
         RG_HIP(c, c->d_mp3_units.reserve(ub * sizeof(rg_mp3_unit)));
         RG_HIP(c, c->d_mp3_hyb.reserve(ub * 2 * 576));
         RG_HIP(c, c->d_mp3_recs.reserve(ub * sizeof(RgMp3HuffRec)));
+        RG_HIP(c, c->d_mp3_tiles.reserve((size_t)tb * 2));
     }
     hipStream_t cs = c->mp3_copy_stream;
     if (c->mp3_set_used[set]) RG_HIP(c, hipStreamWaitEvent(cs, c->mp3_set_free[set], 0));  // the set's previous chunk has been decoded
@@ -200,9 +210,9 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
         const RgMp3DevHuff *d_huff = reinterpret_cast<const RgMp3DevHuff *>(c->d_mp3_huff.p);
         const RgMp3DevTables *d_tab = reinterpret_cast<const RgMp3DevTables *>(c->d_mp3_tab.p);
         RgMp3HuffRec *d_recs = reinterpret_cast<RgMp3HuffRec *>(c->d_mp3_recs.p);
-        RG_HIP(c, rg_launch_mp3_frames(d_tr, (uint32_t)n, d_chunk, d_recs, c->d_mp3_results.p, s));
+        RG_HIP(c, rg_launch_mp3_frames(d_tr, (uint32_t)n, tb, d_chunk, c->d_mp3_tiles.p, d_recs, c->d_mp3_results.p, s));
         RG_HIP(c, rg_launch_mp3_huffman(d_tab, d_huff, d_tr, (uint32_t)n, d_recs, d_chunk, reinterpret_cast<rg_mp3_unit *>(c->d_mp3_units.p),
-                                        c->d_mp3_is.p, fcb, s));
+                                        c->d_mp3_is.p, ub, s));
         RG_HIP(c, rg_launch_mp3_hybrid(d_tab, d_tr, (uint32_t)n, gb, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p), c->d_mp3_is.p,
                                        c->d_mp3_hyb.p, s));
         RG_HIP(c, rg_launch_mp3_synth(d_tab, d_tr, (uint32_t)n, sb, c->d_mp3_hyb.p, s));
