@@ -289,3 +289,24 @@ def test_analyze_tracks_batch_has_per_file_outcomes(_ctx, oracle, tmp_path):
     idx = an.analyze_track_files(files[:1], track_index=1)
     assert isinstance(idx[0], rg.ReplayGainError) and "Track index 1 out of range" in str(idx[0])
     assert an.analyze_track_files([]) == []
+
+
+@pytest.mark.parametrize("src", ["v1_44k_ms_mixed.mp3", "v2_22k_stereo.mp3", "v1_44k_mono_crc_reservoir.mp3"])
+def test_long_streams_carry_the_filterbank_state_across_groups(_ctx, src):
+    """The fused kernel's blocks take runs of several groups of six granules when a chunk is large (the overlap and the
+    filterbank history then stay in LDS from group to group) and rebuild that state from the two granules before a run that
+    starts inside the track: a twelve-minute stream exercises both, and must still be the host decoder's PCM bit for bit."""
+    body = (GOLD / src).read_bytes()
+    one = mp3dec.scan(body)
+    reps = int(12 * 60 * one.sample_rate / one.frames) + 1
+    data = body * reps
+    want, wi = mp3dec.decode(data)
+    assert wi.frames / wi.sample_rate > 11 * 60
+    for route in (3, 2):
+        _ctx.set_tuning(6, route)
+        try:
+            got, gi = _ctx.decode_mp3_device(data)
+        finally:
+            _ctx.set_tuning(6, DEFAULT_ROUTE)
+        assert (gi.frames, gi.audio_frames, gi.skipped_frames) == (wi.frames, wi.audio_frames, wi.skipped_frames)
+        assert np.array_equal(got, want), (route, int(np.count_nonzero(got != want)))
