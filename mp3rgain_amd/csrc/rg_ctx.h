@@ -138,7 +138,7 @@ struct rg_ctx {
     DevBuf<unsigned char> d_mp3_tab;
     DevBuf<int16_t> d_mp3_is;
     DevBuf<unsigned char> d_mp3_units;
-    DevBuf<float> d_mp3_hyb;
+    DevBuf<float> d_mp3_hyb;                 // subband samples between the hybrid and the synthesis kernel
     DevBuf<unsigned char> d_mp3_tracks;
     DevBuf<unsigned char> d_mp3_huff;        // Huffman look-up tables (device Huffman stage)
     DevBuf<unsigned char> d_mp3_recs;

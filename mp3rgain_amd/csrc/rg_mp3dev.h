@@ -75,7 +75,7 @@ struct RgMp3DevTrack {
     uint32_t channels;
     uint32_t rate_row;
     uint32_t lsf;
-    uint32_t fc_base;        // first (frame, channel) pair of the track: one Huffman-stage thread each
+    uint32_t reserved_;
     float *ch0;              // PCM outputs (planar); 576 frames per granule
     float *ch1;
     uint64_t main_base;      // device Huffman stage: byte offset of the track's main-data stream in the chunk buffer

@@ -1,16 +1,19 @@
-// rg_mp3dev.hip -- the device half of the split MP3 decoder: stages B-E of rg_mp3dec.cpp on gfx950.
+// rg_mp3dev.hip -- the device half of the MP3 decoder: everything of rg_mp3dec.cpp after the frame walk, on gfx950.
 //
-//   rg_mp3_hybrid_kernel   one block per granule (both channels): requantisation, joint stereo (mid/side, intensity in
-//                          the MPEG-1 and the LSF form), short-block reordering, alias reduction, IMDCT + windowing.
-//                          Writes the two halves of every subband's 36 windowed samples: `first` overlaps with the
-//                          previous granule's `second`.
-//   rg_mp3_synth_kernel    one block per granule and channel: overlap-add + frequency inversion, then the polyphase
-//                          synthesis filterbank (matrixing into 64-vectors, 512-tap window over sixteen of them) ->
-//                          576 PCM samples, planar f32, straight into the analysis arena.
+//   rg_mp3_frames_kernel   (tuning key 6 = 3) headers + side information -> the records the Huffman stage works from:
+//                          which frames decode, where each granule's bits are (the code of rg_mp3_frame.h, shared with
+//                          the host)
+//   rg_mp3_huffman_kernel  scalefactors + Huffman-coded spectrum, one thread per granule and channel
+//   rg_mp3_hybrid_kernel   six granules per block (both channels): requantisation, joint stereo (mid/side, intensity in
+//                          the MPEG-1 and the LSF form), short-block reordering, alias reduction, IMDCT + windowing,
+//                          overlap-add, frequency inversion -> subband samples
+//   rg_mp3_synth_kernel    six granules of one channel per block: the polyphase synthesis filterbank (matrixing into
+//                          64-vectors, 512-tap window over sixteen of them) -> 576 PCM samples per granule, planar f32,
+//                          straight into the analysis arena
 //
-// Nothing here is recursive across granules: the overlap is a read of the previous granule's second half, the
-// filterbank's FIFO a read of the previous fifteen time slots' subband samples (recomputed from the previous granule's
-// halves), so every granule of every track of a batch is independent work.
+// Nothing here is recursive across granules: the overlap is the previous granule's second IMDCT half (a block computes
+// the granule before its own once more), the filterbank's FIFO the previous fifteen time slots' subband samples (read
+// again), so every granule of every track of a batch is independent work.
 //
 // Bit-identical to the host decoder by construction: compiled with -ffp-contract=off, every sum in the host's order
 // (sequential, from 0.0f), every constant from the host's own tables (rg_mp3_fill_device_tables), the data-dependent
@@ -40,14 +43,6 @@ __device__ __forceinline__ uint32_t find_by_unit(const RgMp3DevTrack *__restrict
     return lo;
 }
 
-__device__ __forceinline__ uint32_t find_by_fc(const RgMp3DevTrack *__restrict__ tr, uint32_t n, uint32_t fc) {
-    uint32_t lo = 0, hi = n - 1;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi + 1) >> 1;
-        if (tr[mid].fc_base <= fc) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
 
 // Bit reader over the batch's main-data buffer; bits at or past `limit` (the end of the frame's own main data) read
 // as zero, which is what the host decoder's private copy of the frame's data does.
@@ -72,6 +67,9 @@ struct DevBits {
     __device__ __forceinline__ uint32_t get1() { return get(1); }
 };
 
+}  // namespace
+
+namespace {
 // hyb[unit][half][t][sb]
 __device__ __forceinline__ size_t hyb_index(uint64_t unit, int half, int t, int sb) {
     return (((size_t)unit * 2 + (size_t)half) * 18 + (size_t)t) * 32 + (size_t)sb;
@@ -372,435 +370,6 @@ rg_mp3_synth_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *_
             s += V[r - 2 * i - 1][32 + j] * T->D[i * 64 + 32 + j];
         }
         dst[e] = s;
-    }
-}
-
-// =====================================================================================================================
-// Stages B-E fused: one block = a run of consecutive granules of one track (both channels), worked off six granules at a
-// time.  Nothing but the quantised spectrum comes in from memory and nothing but PCM goes out:
-//   requantisation, joint stereo, short-block reordering, alias reduction      over the group's 6 x 2 x 576 lines in LDS
-//   IMDCT + windowing        one thread per (granule, channel, subband): the 18 spectral lines in registers, the eighteen
-//                            dot products of rg_mp3dec.cpp one after the other; the first halves go to the subband-sample
-//                            array S, the second halves are added to the next granule's rows (overlap-add)
-//   matrixing                one thread per time slot: the 32-point DCT of rg_mp3_math.h (the host runs the same code)
-//   windowing                four adjacent PCM samples per thread, 16-byte reads of V and 16-byte stores of PCM
-// The only recursion across granules -- the overlap and the filterbank's fifteen slots of history -- stays in LDS from
-// one group of six to the next; a run that does not start at the track's first granule first rebuilds that state from
-// the two granules before it.  Every sum keeps the host decoder's order (and -ffp-contract=off its roundings), so the
-// PCM is the host's bit for bit.
-namespace {
-constexpr int kGR = 6;                    // granules per group
-constexpr int kSlots = 15 + 18 * kGR;     // time slots per group: 15 of history + 18 per granule
-constexpr int kSStride = 33;              // S row: 32 subbands + 1 (a thread per row walks its row: no common bank)
-constexpr int kVStride = 68;              // V row: 64 + 4 (16-byte aligned rows for the windowing's reads)
-constexpr int kNT = 384;                 // threads: one per (granule, channel, subband) of a stereo group
-constexpr int kKeep = (kGR * 2 * 576 + kNT - 1) / kNT;
-
-struct GroupLds {
-    float S[2][kSlots][kSStride];
-    alignas(16) float XV[kSlots * kVStride];  // xr[kGR][2][576] while the spectrum is worked on, then V of one channel
-    float O[2][18][32];                   // second halves of the last granule done: the next granule's overlap
-    rg_mp3_unit U[kGR][2];
-    float gain_long[kGR][2][22], gain_short[kGR][2][39];
-    int band_nz[kGR][64];
-    short band_mode[kGR][64];
-    float imdct36[18][18];                // the eighteen rows the long-block IMDCT uses: samples 0..8 and 18..26
-    float imdct12[12][6];
-    float win[4][36];
-};
-}  // namespace
-
-__global__ void __launch_bounds__(kNT, 3)
-rg_mp3_granule_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks,
-                      const rg_mp3_unit *__restrict__ units, const int16_t *__restrict__ is, uint32_t groups_per_run) {
-    __shared__ GroupLds L;
-    const int tid = threadIdx.x;
-    uint32_t lo = 0, hi = n_tracks - 1;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi + 1) >> 1;
-        if (tracks[mid].synth_base <= blockIdx.x) lo = mid; else hi = mid - 1;
-    }
-    const RgMp3DevTrack tr = tracks[lo];
-    const int nch = (int)tr.channels;
-    const int rr = (int)tr.rate_row;
-    const uint32_t run_len = (uint32_t)kGR * groups_per_run;
-    const uint64_t g_begin64 = (uint64_t)(blockIdx.x - tr.synth_base) * run_len;
-    if (g_begin64 >= tr.n_granules) return;  // fewer granules decoded than the grid was laid out for (block-uniform)
-    const uint32_t g_begin = (uint32_t)g_begin64;
-    const uint32_t g_end = tr.n_granules - g_begin < run_len ? tr.n_granules : g_begin + run_len;
-    float (*xr)[2][576] = reinterpret_cast<float (*)[2][576]>(L.XV);
-
-    for (int e = tid; e < 18 * 18; e += kNT) L.imdct36[e / 18][e % 18] = T->imdct36[e / 18 < 9 ? e / 18 : e / 18 + 9][e % 18];
-    if (tid < 72) L.imdct12[tid / 6][tid % 6] = T->imdct12[tid / 6][tid % 6];
-    if (tid < 144) L.win[tid / 36][tid % 36] = T->win[tid / 36][tid % 36];
-    // no history before the track's first granule
-    for (int e = tid; e < 2 * 15 * kSStride; e += kNT) L.S[e / (15 * kSStride)][(e / kSStride) % 15][e % kSStride] = 0.0f;
-    for (int e = tid; e < 2 * 18 * 32; e += kNT) (&L.O[0][0][0])[e] = 0.0f;
-
-    // One group: granules [g_first, g_first + ng) of the track.  `row0` = S row of the first granule's time slot 0 (15 in
-    // the main loop; negative while the state before a run is rebuilt: rows < 0 are not kept).
-    auto spectrum_and_imdct = [&](uint32_t g_first, int ng, int row0) {
-        __syncthreads();  // whatever used XV / U / S before is done
-        if (tid < ng * nch) L.U[tid / nch][tid % nch] = units[tr.unit_base + (uint64_t)g_first * nch + tid];
-        for (int e = tid; e < kGR * 64; e += kNT) { L.band_nz[e >> 6][e & 63] = 0; L.band_mode[e >> 6][e & 63] = 0; }
-        __syncthreads();
-        // ---- stage B: requantisation (rg_mp3dec.cpp: requantize) -------------------------------------------------
-        // gains per band: 2^(e), e = (global_gain - 210)/4 - mult (sf + preflag pretab) [- 2 subblock_gain], a multiple
-        // of 1/4 exactly: the table is indexed by 4e
-        for (int e = tid; e < ng * nch * 61; e += kNT) {
-            const int qc = e / 61, k = e % 61, q = qc / nch, c = qc % nch;
-            const rg_mp3_unit &u = L.U[q][c];
-            const int m4 = u.scalefac_scale ? 4 : 2;  // 4 * mult
-            const int base4 = (int)u.global_gain - 210;
-            if (k < 22) {
-                const int qq = base4 - m4 * ((int)u.sf[k] + (u.preflag ? (int)T->pretab[k] : 0));
-                L.gain_long[q][c][k] = T->gain[qq - RG_MP3_GAIN_Q_MIN];
-            } else {
-                const int ks = k - 22;  // (band - short_start) * 3 + window
-                const int band = (int)u.short_start + ks / 3, w = ks % 3;
-                float gv = 0.0f;
-                if (band < 13) {
-                    const int s = band < 12 ? (int)u.sf[(int)u.long_end + ks] : 0;
-                    const int qq = base4 - 8 * (int)u.subblock_gain[w] - m4 * s;
-                    gv = T->gain[qq - RG_MP3_GAIN_Q_MIN];
-                }
-                L.gain_short[q][c][ks] = gv;
-            }
-        }
-        __syncthreads();
-        for (int e = tid; e < ng * nch * 576; e += kNT) {
-            const int qc = e / 576, line = e % 576, q = qc / nch, c = qc % nch;
-            const rg_mp3_unit &u = L.U[q][c];
-            const int long_lines = (int)T->sfb_long[rr][u.long_end];  // 0 when long_end == 0
-            float gv;
-            if (u.block_type != 2 || line < long_lines) {
-                gv = L.gain_long[q][c][T->long_band_of_line[rr][line]];
-            } else {
-                const int short_off = 3 * (int)T->sfb_short[rr][u.short_start < 13 ? u.short_start : 13];
-                const int k = (int)T->short_idx_of_line[rr][line - long_lines + short_off] - 3 * (int)u.short_start;
-                gv = L.gain_short[q][c][k];
-            }
-            const int v = is[(tr.unit_base + (uint64_t)(g_first + q) * nch + c) * 576 + line];
-            const int a = v < 0 ? -v : v;
-            const float m = T->pow43[a] * gv;
-            xr[q][c][line] = v < 0 ? -m : m;
-        }
-        __syncthreads();
-        // ---- stage C: joint stereo (rg_mp3dec.cpp: stereo) -------------------------------------------------------
-        if (nch == 2) {
-            const float isq2 = 0.70710678118654752440f;
-            // stereo band of a line: short bands 0..38 = (band - short_start) * 3 + window, long bands 39 + band
-            auto band_of = [&](const rg_mp3_unit &u1, int line) -> int {
-                const int long_lines = (int)T->sfb_long[rr][u1.long_end];
-                if (u1.block_type != 2 || line < long_lines) return 39 + (int)T->long_band_of_line[rr][line];
-                const int short_off = 3 * (int)T->sfb_short[rr][u1.short_start < 13 ? u1.short_start : 13];
-                return (int)T->short_idx_of_line[rr][line - long_lines + short_off] - 3 * (int)u1.short_start;
-            };
-            bool any_intensity = false;
-            for (int q = 0; q < ng; ++q) any_intensity |= (L.U[q][0].mode_ext & 1) != 0;
-            if (any_intensity) {
-                for (int e = tid; e < ng * 576; e += kNT) {
-                    const int q = e / 576, line = e % 576;
-                    if ((L.U[q][0].mode_ext & 1) && xr[q][1][line] != 0.0f) L.band_nz[q][band_of(L.U[q][1], line)] = 1;
-                }
-                __syncthreads();
-                if (tid < ng && (L.U[tid][0].mode_ext & 1)) {
-                    // walk the bands from the top: a band is intensity coded while every band above it (of the same
-                    // window, for short blocks) has an all-zero right channel and its own position is legal
-                    const int q = tid;
-                    const rg_mp3_unit &u1 = L.U[q][1];
-                    const bool ms = (L.U[q][0].mode_ext & 2) != 0;
-                    const bool lsf = tr.lsf != 0;
-                    bool found[3] = {false, false, false};
-                    bool found_long = false;
-                    if (u1.block_type == 2) {
-                        for (int b = 12; b >= (int)u1.short_start; --b) {
-                            const int sb = b == 12 ? 11 : b;
-                            for (int w = 2; w >= 0; --w) {
-                                const int k = (b - (int)u1.short_start) * 3 + w;
-                                const int idx = (int)u1.long_end + 3 * (sb - (int)u1.short_start) + w;
-                                bool intensity = false;
-                                int mode = 0;
-                                if (!found[w]) {
-                                    if (L.band_nz[q][k]) {
-                                        found[w] = true;
-                                    } else {
-                                        const int p = u1.sf[idx];
-                                        intensity = lsf ? !((u1.illegal >> idx) & 1ull) : p < 7;
-                                        if (intensity) mode = 2 + p;
-                                    }
-                                }
-                                if (!intensity && ms) mode = 1;
-                                L.band_mode[q][k] = (short)mode;
-                            }
-                        }
-                        found_long = found[0] || found[1] || found[2];
-                    }
-                    if (!(u1.block_type == 2 && !u1.mixed)) {
-                        for (int b = (int)u1.long_end - 1; b >= 0; --b) {
-                            const int sb = b == 21 ? 20 : b;
-                            bool intensity = false;
-                            int mode = 0;
-                            if (!found_long) {
-                                if (L.band_nz[q][39 + b]) {
-                                    found_long = true;
-                                } else {
-                                    const int p = u1.sf[sb];
-                                    intensity = lsf ? !((u1.illegal >> sb) & 1ull) : p < 7;
-                                    if (intensity) mode = 2 + p;
-                                }
-                            }
-                            if (!intensity && ms) mode = 1;
-                            L.band_mode[q][39 + b] = (short)mode;
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-            for (int e = tid; e < ng * 576; e += kNT) {
-                const int q = e / 576, line = e % 576;
-                const int mx = L.U[q][0].mode_ext;
-                if (mx == 0) continue;
-                int mode;
-                if (!(mx & 1)) {  // mid/side alone: up to the last line either channel has
-                    const int n = L.U[q][0].nz > L.U[q][1].nz ? L.U[q][0].nz : L.U[q][1].nz;
-                    mode = line < n ? 1 : 0;
-                } else {
-                    mode = L.band_mode[q][band_of(L.U[q][1], line)];
-                }
-                if (mode == 1) {
-                    const float a = xr[q][0][line], b = xr[q][1][line];
-                    xr[q][0][line] = (a + b) * isq2;
-                    xr[q][1][line] = (a - b) * isq2;
-                } else if (mode >= 2) {
-                    const int pos = mode - 2;
-                    const int scale = L.U[q][1].intensity_scale & 1;
-                    float kl, kr;
-                    if (!tr.lsf) {
-                        kl = T->is_l[pos];
-                        kr = T->is_r[pos];
-                    } else if (pos == 0) {
-                        kl = kr = 1.0f;
-                    } else if (pos & 1) {
-                        kl = T->lsf_is[scale][(pos + 1) >> 1];
-                        kr = 1.0f;
-                    } else {
-                        kl = 1.0f;
-                        kr = T->lsf_is[scale][pos >> 1];
-                    }
-                    const float v = xr[q][0][line];
-                    xr[q][0][line] = v * kl;
-                    xr[q][1][line] = v * kr;
-                }
-            }
-            __syncthreads();
-        }
-        // ---- stage D: reorder (short blocks), alias reduction ----------------------------------------------------
-        {
-            bool any_short = false;
-            for (int q = 0; q < ng; ++q)
-                for (int c = 0; c < nch; ++c) any_short |= L.U[q][c].block_type == 2;
-            if (any_short) {
-                float keep[kKeep];
-#pragma unroll
-                for (int k = 0; k < kKeep; ++k) {
-                    const int e = tid + kNT * k;
-                    keep[k] = 0.0f;
-                    if (e < ng * nch * 576) {
-                        const int qc = e / 576, line = e % 576, q = qc / nch, c = qc % nch;
-                        const rg_mp3_unit &u = L.U[q][c];
-                        if (u.block_type == 2) {
-                            const int long_lines = u.mixed ? (int)T->sfb_long[rr][u.long_end] : 0;
-                            const int short_off = 3 * (int)T->sfb_short[rr][u.short_start];
-                            keep[k] = line < long_lines ? xr[q][c][line]
-                                                        : xr[q][c][(int)T->short_reorder_src[rr][line - long_lines + short_off] - short_off + long_lines];
-                        }
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int k = 0; k < kKeep; ++k) {
-                    const int e = tid + kNT * k;
-                    if (e < ng * nch * 576) {
-                        const int qc = e / 576, line = e % 576, q = qc / nch, c = qc % nch;
-                        if (L.U[q][c].block_type == 2) xr[q][c][line] = keep[k];
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        for (int e = tid; e < ng * nch * 248; e += kNT) {
-            const int qc = e / 248, r = e % 248, q = qc / nch, c = qc % nch;
-            const rg_mp3_unit &u = L.U[q][c];
-            const int boundaries = u.block_type == 2 ? (u.mixed ? 1 : 0) : 31;
-            if (r < boundaries * 8) {
-                float *X = xr[q][c];
-                const int sb = 1 + r / 8, i = r % 8;
-                const float a = X[sb * 18 - 1 - i], b = X[sb * 18 + i];
-                X[sb * 18 - 1 - i] = a * T->cs[i] - b * T->ca[i];
-                X[sb * 18 + i] = b * T->cs[i] + a * T->ca[i];
-            }
-        }
-        __syncthreads();
-        // ---- IMDCT + window, overlap-add into S (rg_mp3dec.cpp: hybrid) -----------------------------------------
-        // long blocks: x[17 - i] = -x[i], x[35 - j] = x[18 + j] -- eighteen dot products per subband give all 36 samples
-        // (the host computes exactly these eighteen); short blocks: each of the 36 samples on its own
-        float second[18];
-        const int task = tid;  // kNT = kGR * 2 * 32: one task per thread at most
-        if (task < ng * nch * 32) {
-            const int sb = task & 31, qc = task >> 5, q = qc / nch, c = qc % nch;
-            const rg_mp3_unit &u = L.U[q][c];
-            float x[18];
-#pragma unroll
-            for (int k = 0; k < 18; ++k) x[k] = xr[q][c][sb * 18 + k];
-            const int bt = (u.block_type == 2 && u.mixed && sb < 2) ? 0 : (int)u.block_type;
-            const int rb = row0 + 18 * q;
-            const bool track_start = g_first + (uint32_t)q == 0;
-            // a first-half sample: + the overlap the previous group left (zeros at the track's start) for the group's
-            // first granule; the later granules' overlaps are added below
-            auto put_first = [&](int t, float v) {
-                const int row = rb + t;
-                if (row < 0) return;
-                if (q == 0) v = v + L.O[c][t][sb];
-                else if (track_start) v = v + 0.0f;
-                L.S[c][row][sb] = v;
-            };
-            if (bt != 2) {
-                const float *__restrict__ wn = L.win[bt];
-#pragma unroll 1
-                for (int p = 0; p < 9; ++p) {  // samples p and 17 - p
-                    const float *__restrict__ cf = L.imdct36[p];
-                    float s = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < 18; ++k) s += x[k] * cf[k];
-                    put_first(p, s * wn[p]);
-                    put_first(17 - p, -s * wn[17 - p]);
-                }
-#pragma unroll
-                for (int p = 9; p < 18; ++p) {  // samples 9 + p and 44 - p
-                    const float *__restrict__ cf = L.imdct36[p];
-                    float s = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < 18; ++k) s += x[k] * cf[k];
-                    second[p - 9] = s * wn[9 + p];
-                    second[26 - p] = s * wn[44 - p];
-                }
-            } else {
-#pragma unroll 1
-                for (int i = 0; i < 18; ++i) {
-                    float raw = 0.0f;
-#pragma unroll
-                    for (int w = 0; w < 3; ++w) {
-                        const int ii = i - 6 - 6 * w;
-                        if (ii >= 0 && ii < 12) {
-                            float s2 = 0.0f;
-#pragma unroll
-                            for (int k = 0; k < 6; ++k) s2 += x[3 * k + w] * L.imdct12[ii][k];
-                            raw += s2 * L.win[2][ii];
-                        }
-                    }
-                    put_first(i, raw);
-                }
-#pragma unroll
-                for (int i = 18; i < 36; ++i) {
-                    float raw = 0.0f;
-#pragma unroll
-                    for (int w = 0; w < 3; ++w) {
-                        const int ii = i - 6 - 6 * w;
-                        if (ii >= 0 && ii < 12) {
-                            float s2 = 0.0f;
-#pragma unroll
-                            for (int k = 0; k < 6; ++k) s2 += x[3 * k + w] * L.imdct12[ii][k];
-                            raw += s2 * L.win[2][ii];
-                        }
-                    }
-                    second[i - 18] = raw;
-                }
-            }
-        }
-        __syncthreads();
-        if (task < ng * nch * 32) {
-            const int sb = task & 31, qc = task >> 5, q = qc / nch, c = qc % nch;
-            if (q == ng - 1) {
-#pragma unroll
-                for (int t = 0; t < 18; ++t) L.O[c][t][sb] = second[t];
-            } else {
-                const int rb = row0 + 18 * (q + 1);
-#pragma unroll
-                for (int t = 0; t < 18; ++t) {
-                    const int row = rb + t;
-                    if (row >= 0) L.S[c][row][sb] += second[t];
-                }
-            }
-        }
-        __syncthreads();
-    };
-
-    // ---- the state a run starts from: overlap of granule g_begin - 1, subband samples of its last fifteen time slots --
-    if (g_begin >= 2) spectrum_and_imdct(g_begin - 2, 2, -21);
-    else if (g_begin == 1) spectrum_and_imdct(0, 1, -3);
-
-    for (uint32_t gs = g_begin; gs < g_end; gs += kGR) {
-        const int ng = (int)(g_end - gs < (uint32_t)kGR ? g_end - gs : (uint32_t)kGR);
-        const int nslots = 15 + 18 * ng;
-        spectrum_and_imdct(gs, ng, 15);
-        for (int c = 0; c < nch; ++c) {
-            // ---- polyphase synthesis: matrixing, one time slot per thread (rg_mp3dec.cpp: synth) ---------------------
-            if (tid < nslots) {
-                float x[32];
-                const int t = tid >= 15 ? (tid - 15) % 18 : tid + 3;  // the slot's place in its granule
-#pragma unroll
-                for (int k = 0; k < 32; ++k) {
-                    const float v = L.S[c][tid][k];
-                    x[k] = ((k & 1) && (t & 1)) ? -v : v;  // frequency inversion
-                }
-                float *row = L.XV + tid * kVStride;
-                rg_mp3_matrixing(x, row, T->sec);
-            }
-            __syncthreads();
-            // ---- windowing: four adjacent samples of one time slot per thread -----------------------------------------
-            {
-                const int jg = (tid & 7) * 4;
-                asm volatile("" ::: "memory");  // the window coefficients are loaded here, not hoisted over the whole run (64 registers)
-                float4 D0[8], D1[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float *d0 = &T->D[i * 64 + jg], *d1 = &T->D[i * 64 + 32 + jg];
-                    D0[i] = make_float4(d0[0], d0[1], d0[2], d0[3]);
-                    D1[i] = make_float4(d1[0], d1[1], d1[2], d1[3]);
-                }
-                float *__restrict__ dst = (c == 0 ? tr.ch0 : tr.ch1) + (size_t)gs * 576;
-                for (int e = tid; e < ng * 18 * 8; e += kNT) {
-                    const int slot = e >> 3;
-                    const int r = 15 + slot;
-                    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float4 va = *reinterpret_cast<const float4 *>(L.XV + (r - 2 * i) * kVStride + jg);
-                        const float4 vb = *reinterpret_cast<const float4 *>(L.XV + (r - 2 * i - 1) * kVStride + 32 + jg);
-                        s.x += va.x * D0[i].x; s.y += va.y * D0[i].y; s.z += va.z * D0[i].z; s.w += va.w * D0[i].w;
-                        s.x += vb.x * D1[i].x; s.y += vb.y * D1[i].y; s.z += vb.z * D1[i].z; s.w += vb.w * D1[i].w;
-                    }
-                    *reinterpret_cast<float4 *>(dst + slot * 32 + jg) = s;
-                }
-            }
-            __syncthreads();
-        }
-        // the last fifteen time slots are the next group's history
-        if (gs + kGR < g_end) {
-            float h[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int e = tid + kNT * k;  // 2 x 15 x 32 = 960 values
-                h[k] = e < 960 ? L.S[e / 480][nslots - 15 + (e % 480) / 32][e % 32] : 0.0f;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int e = tid + kNT * k;
-                if (e < 960) L.S[e / 480][(e % 480) / 32][e % 32] = h[k];
-            }
-        }
     }
 }
 
@@ -1211,12 +780,5 @@ extern "C" hipError_t rg_launch_mp3_frames(RgMp3DevTrack *d_tracks, uint32_t n_t
     hipLaunchKernelGGL((rg_mp3_frames_kernel<false>), dim3(n_tiles), dim3(RG_MP3_FRAME_TILE), 0, s, d_tracks, n_tracks, d_chunk, units, base, d_recs);
     hipLaunchKernelGGL(rg_mp3_frames_scan_kernel, dim3(n_tracks), dim3(256), 0, s, d_tracks, units, base, d_results);
     hipLaunchKernelGGL((rg_mp3_frames_kernel<true>), dim3(n_tiles), dim3(RG_MP3_FRAME_TILE), 0, s, d_tracks, n_tracks, d_chunk, units, base, d_recs);
-    return hipGetLastError();
-}
-
-extern "C" hipError_t rg_launch_mp3_granules(const RgMp3DevTables *d_tab, const RgMp3DevTrack *d_tracks, uint32_t n_tracks, uint32_t n_blocks,
-                                             uint32_t groups_per_run, const rg_mp3_unit *d_units, const int16_t *d_is, hipStream_t s) {
-    if (n_blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(rg_mp3_granule_kernel, dim3(n_blocks), dim3(kNT), 0, s, d_tab, d_tracks, n_tracks, d_units, d_is, groups_per_run);
     return hipGetLastError();
 }

@@ -1,4 +1,5 @@
 // rg_mp3dev_host.hip -- host orchestration of the split MP3 decoder's device half (rg_mp3dev.hip).
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -14,18 +15,10 @@ hipError_t rg_launch_mp3_huffman(const RgMp3DevTables *, const RgMp3DevHuff *, c
 hipError_t rg_launch_mp3_hybrid(const RgMp3DevTables *, const RgMp3DevTrack *, uint32_t, uint32_t, const rg_mp3_unit *,
                                 const int16_t *, float *, hipStream_t);
 hipError_t rg_launch_mp3_synth(const RgMp3DevTables *, const RgMp3DevTrack *, uint32_t, uint32_t, const float *, hipStream_t);
-hipError_t rg_launch_mp3_granules(const RgMp3DevTables *, const RgMp3DevTrack *, uint32_t, uint32_t, uint32_t, const rg_mp3_unit *, const int16_t *,
-                                  hipStream_t);
 hipError_t rg_launch_mp3_frames(RgMp3DevTrack *, uint32_t, uint32_t, const uint8_t *, uint32_t *, RgMp3HuffRec *, uint32_t *, hipStream_t);
 }
 
 namespace {
-// The fused kernel's blocks take runs of 6 x groups granules; a run pays for two extra granules of IMDCT at its start, so
-// runs are as long as still leaves every CU several blocks.
-uint32_t groups_per_run(uint64_t total_granules) {
-    const uint64_t g = total_granules / (6ull * 1024ull);
-    return (uint32_t)(g < 1 ? 1 : (g > 8 ? 8 : g));
-}
 // units per chunk: 4.6 KB of IMDCT halves + 1.2 KB of input each (256 K units = 1.5 GB); a longer single track gets a
 // chunk of its own size
 const uint64_t kChunkUnits = 1ull << 18;
@@ -75,11 +68,8 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
         while (last < n && (last == first || units + items[last].n_units <= kChunkUnits)) units += items[last++].n_units;
         std::vector<RgMp3DevTrack> tr(last - first);
         uint64_t ub = 0, mainb = 0;
-        uint32_t gb = 0, fcb = 0, sb = 0;
+        uint32_t gb = 0, sb = 0;
         bool any_recs = false;
-        uint64_t chunk_granules = 0;
-        for (size_t i = first; i < last; ++i) chunk_granules += items[i].channels ? items[i].n_units / items[i].channels : 0;
-        const uint32_t gpr = groups_per_run(chunk_granules), run_len = 6u * gpr;
         for (size_t i = first; i < last; ++i) {
             const RgMp3SplitItem &it = items[i];
             RgMp3DevTrack &t = tr[i - first];
@@ -92,18 +82,17 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
             t.lsf = it.lsf;
             t.ch0 = it.d_ch0;
             t.ch1 = it.d_ch1;
-            t.fc_base = fcb;
             t.synth_base = sb;
-            sb += (t.n_granules + run_len - 1) / run_len;  // blocks of the fused kernel: runs of granules
+            sb += ((t.n_granules + RG_MP3_SYNTH_RUN - 1) / RG_MP3_SYNTH_RUN) * t.channels;  // runs of granules x channels
             t.main_base = mainb;
             ub += it.n_units;
             gb += t.n_granules;
-            fcb += (uint32_t)(it.n_units / (it.lsf ? 1u : 2u));  // one Huffman-stage thread per (frame, channel)
             if (it.recs) { any_recs = true; mainb += (it.main_len + 15) & ~(uint64_t)15; }
         }
         if (units) {
             RG_HIP(c, c->d_mp3_is.reserve(units * 576));
             RG_HIP(c, c->d_mp3_units.reserve(units * sizeof(rg_mp3_unit)));
+            RG_HIP(c, c->d_mp3_hyb.reserve(units * 2 * 576));
             RG_HIP(c, c->d_mp3_tracks.reserve(tr.size() * sizeof(RgMp3DevTrack)));
             if (any_recs) {
                 RG_HIP(c, c->d_mp3_recs.reserve(units * sizeof(RgMp3HuffRec)));
@@ -131,8 +120,9 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
                 RG_HIP(c, rg_launch_mp3_huffman(d_tab, d_huff, d_tr, (uint32_t)tr.size(), reinterpret_cast<const RgMp3HuffRec *>(c->d_mp3_recs.p),
                                                 c->d_mp3_main.p, reinterpret_cast<rg_mp3_unit *>(c->d_mp3_units.p), c->d_mp3_is.p, ub, s));
             }
-            RG_HIP(c, rg_launch_mp3_granules(d_tab, d_tr, (uint32_t)tr.size(), sb, gpr, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p),
-                                             c->d_mp3_is.p, s));
+            RG_HIP(c, rg_launch_mp3_hybrid(d_tab, d_tr, (uint32_t)tr.size(), gb, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p),
+                                           c->d_mp3_is.p, c->d_mp3_hyb.p, s));
+            RG_HIP(c, rg_launch_mp3_synth(d_tab, d_tr, (uint32_t)tr.size(), sb, c->d_mp3_hyb.p, s));
             // the chunk buffers (and `tr`) are reused by the next chunk
             RG_HIP(c, hipStreamSynchronize(s));
         }
@@ -169,10 +159,7 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
     // the descriptors, laid out for the upper bound "every walked frame decodes"
     RgMp3DevTrack *tr = reinterpret_cast<RgMp3DevTrack *>(staging + tracks_off);
     uint64_t ub = 0;
-    uint32_t gb = 0, fcb = 0, sb = 0, tb = 0;
-    uint64_t chunk_granules = 0;
-    for (size_t i = 0; i < n; ++i) chunk_granules += (uint64_t)items[i].n_frames * (items[i].lsf ? 1u : 2u);
-    const uint32_t gpr = groups_per_run(chunk_granules), run_len = 6u * gpr;
+    uint32_t gb = 0, sb = 0, tb = 0;
     for (size_t i = 0; i < n; ++i) {
         const RgMp3StreamItem &it = items[i];
         RgMp3DevTrack &t = tr[i];
@@ -187,7 +174,6 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
         t.channels = it.channels;
         t.rate_row = it.rate_row;
         t.lsf = it.lsf;
-        t.fc_base = fcb;
         t.ch0 = it.d_ch0;
         t.ch1 = it.channels == 2 ? it.d_ch0 + (size_t)granules * 576 : nullptr;
         t.main_base = it.main_off;
@@ -197,8 +183,7 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
         t.result_index = it.result_index;
         ub += (uint64_t)granules * it.channels;
         gb += granules;
-        fcb += it.n_frames * it.channels;
-        sb += (granules + run_len - 1) / run_len;
+        sb += ((granules + RG_MP3_SYNTH_RUN - 1) / RG_MP3_SYNTH_RUN) * it.channels;
     }
     const size_t total = tracks_off + n * sizeof(RgMp3DevTrack);
     if (total > bytes) return rg_set_err(c, RG_ERR_INVALID_ARG, "MP3 staging block: descriptors do not fit");
@@ -207,6 +192,7 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
     if (ub) {
         RG_HIP(c, c->d_mp3_is.reserve(ub * 576));
         RG_HIP(c, c->d_mp3_units.reserve(ub * sizeof(rg_mp3_unit)));
+        RG_HIP(c, c->d_mp3_hyb.reserve(ub * 2 * 576));
         RG_HIP(c, c->d_mp3_recs.reserve(ub * sizeof(RgMp3HuffRec)));
         RG_HIP(c, c->d_mp3_tiles.reserve((size_t)tb * 2));
     }
@@ -224,7 +210,9 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
         RG_HIP(c, rg_launch_mp3_frames(d_tr, (uint32_t)n, tb, d_chunk, c->d_mp3_tiles.p, d_recs, c->d_mp3_results.p, s));
         RG_HIP(c, rg_launch_mp3_huffman(d_tab, d_huff, d_tr, (uint32_t)n, d_recs, d_chunk, reinterpret_cast<rg_mp3_unit *>(c->d_mp3_units.p),
                                         c->d_mp3_is.p, ub, s));
-        RG_HIP(c, rg_launch_mp3_granules(d_tab, d_tr, (uint32_t)n, sb, gpr, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p), c->d_mp3_is.p, s));
+        RG_HIP(c, rg_launch_mp3_hybrid(d_tab, d_tr, (uint32_t)n, gb, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p), c->d_mp3_is.p,
+                                       c->d_mp3_hyb.p, s));
+        RG_HIP(c, rg_launch_mp3_synth(d_tab, d_tr, (uint32_t)n, sb, c->d_mp3_hyb.p, s));
     }
     RG_HIP(c, hipEventRecord(c->mp3_set_free[set], s));
     c->mp3_set_used[set] = true;
