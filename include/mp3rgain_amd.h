@@ -178,10 +178,12 @@ int rg_set_kernel(rg_ctx *ctx, int variant);
  * HOST arena larger than this are cut at track boundaries into sub-batches; two device arenas of that size take turns,
  * the copy of one sub-batch running under the kernels of the previous, so an arena larger than HBM is fine,
  * key 6 = how MPEG Layer III files of the file-level entry points are decoded (mp3rgain_amd_dec.h; identical PCM, bit for
- * bit, whichever is chosen): 2 (default) = the host only walks the frames (headers, side information, bit reservoir
- * bookkeeping); scalefactors, Huffman, requantisation, joint stereo, IMDCT and the polyphase filterbank run on the GPU
- * and the PCM is written straight into the analysis arena; 1 = scalefactors + Huffman on the host's cores, the rest on
- * the GPU; 0 = the host decoder.  (An album of 64 three-minute 320 kb/s files: 1.0 s / 0.15 s / 0.05 s for 0 / 1 / 2.) */
+ * bit, whichever is chosen): 3 (default) = the host only finds the frames and strips headers and side information from
+ * the stream; side-information parsing (which frames decode), scalefactors, Huffman, requantisation, joint stereo, IMDCT
+ * and the polyphase filterbank run on the GPU, file reads, copies and decode overlap chunk by chunk, and the PCM is
+ * written straight into the analysis arena; 2 = the host parses the side information too; 1 = scalefactors + Huffman on
+ * the host's cores, the rest on the GPU; 0 = the host decoder.  (An album of 64 three-minute 320 kb/s files:
+ * 0.96 s / 0.25 s / 0.063 s / 0.025 s for 0 / 1 / 2 / 3.) */
 int rg_set_tuning(rg_ctx *ctx, int key, int64_t value);
 /* diagnostic (host only): variant 2's design for one rate and segment length.  T_out: [L][12],
  * gram_last_out: [78]; either may be NULL.  RG_ERR_INVALID_ARG when no design exists. */
