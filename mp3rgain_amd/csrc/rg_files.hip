@@ -668,7 +668,12 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
             struct stat st;
             if (paths[i] && stat(paths[i], &st) == 0 && st.st_size > 0) total += (size_t)st.st_size;
         }
-        R.stage_want = std::min(kPipeStageBytes, total + total / 8 + ((size_t)1 << 16));
+        size_t cap = kPipeStageBytes;
+        if (const char *e = getenv("RG_MP3_STAGE_BYTES")) {  // tests: tiny blocks, so that a handful of small files exercises the whole rotation
+            const long long v = atoll(e);
+            if (v >= 4096) cap = (size_t)v;
+        }
+        R.stage_want = std::min(cap, total + total / 8 + ((size_t)1 << 16));
     }
     std::vector<PipeFile> pf(n);
     std::atomic<uint64_t> t_read{0}, t_compact{0}, t_wait{0}, t_copy{0};  // trace: microseconds summed over the loader threads

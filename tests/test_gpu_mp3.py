@@ -310,3 +310,40 @@ def test_long_streams_carry_the_filterbank_state_across_groups(_ctx, src):
             _ctx.set_tuning(6, DEFAULT_ROUTE)
         assert (gi.frames, gi.audio_frames, gi.skipped_frames) == (wi.frames, wi.audio_frames, wi.skipped_frames)
         assert np.array_equal(got, want), (route, int(np.count_nonzero(got != want)))
+
+
+def test_loader_pipeline_with_tiny_staging_blocks(oracle, tmp_path, monkeypatch):
+    """The default route's pipeline (loader threads -> pinned staging blocks -> chunks -> device) with staging blocks of
+    48 KB: 60 small files become dozens of chunks, so blocks are refilled while earlier chunks are still in flight, a file
+    larger than a block makes its block grow, and the arena of a fresh context grows chunk by chunk with its contents
+    kept.  Results must be those of the host-indexed route, file by file, and the album's."""
+    import mp3rgain_amd as rg
+
+    monkeypatch.setenv("RG_MP3_STAGE_BYTES", "49152")
+    srcs = [p for p in STREAMS if p.stat().st_size < 60000]
+    big = (GOLD / "v1_44k_ms_mixed.mp3").read_bytes()
+    one = mp3dec.scan(big)
+    long_file = tmp_path / "longer_than_a_block.mp3"
+    long_file.write_bytes(big * (int(20 * one.sample_rate / one.frames) + 1))  # 20 s: several blocks' worth
+    files = []
+    for k in range(60):
+        f = tmp_path / f"f{k:02d}.mp3"
+        f.write_bytes(srcs[k % len(srcs)].read_bytes())
+        files.append(f)
+    files.insert(17, long_file)
+    with rg.Analyzer(0) as an:  # fresh context: nothing is allocated yet
+        an.set_kernel(0)
+        got = an.analyze_album_files(files)
+        again = an.analyze_album_files(files)
+        an.set_tuning(6, 2)
+        want = an.analyze_album_files(files)
+    for a, b, c, f in zip(got.tracks, want.tracks, again.tracks, files):
+        assert (a.loudness_db, a.gain_db, a.peak, a.sample_rate, a.windows) == (b.loudness_db, b.gain_db, b.peak, b.sample_rate, b.windows), f.name
+        assert (c.loudness_db, c.peak, c.windows) == (b.loudness_db, b.peak, b.windows), f.name
+    assert (got.album_loudness_db, got.album_gain_db, got.album_peak) == (want.album_loudness_db, want.album_gain_db, want.album_peak)
+    assert (again.album_loudness_db, again.album_peak) == (want.album_loudness_db, want.album_peak)
+    # and against the oracle on the host decoder's PCM for a few of them
+    for f, a in list(zip(files, got.tracks))[:6] + [(long_file, got.tracks[17])]:
+        pcm, info = mp3dec.decode(f.read_bytes())
+        ref, _ = oracle.analyze_pcm(pcm[0], pcm[1] if info.channels == 2 else None, info.sample_rate)
+        assert (a.loudness_db, a.peak) == (ref["loudness_db"], ref["peak"]), f.name
