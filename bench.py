@@ -141,7 +141,7 @@ def roofline_block(frames_per_launch: int, k_ms_sum: float, k_launches: int, k_s
 
 def mp3_end_to_end(an, nfiles: int) -> dict:
     """rg_analyze_album over `nfiles` three-minute MP3 files (the frames of tests/golden/mp3/v1_44k_stereo_long.mp3, a
-    dense 320 kb/s 44.1 kHz stereo stream, repeated), with each of the library's three decode routes (tuning key 6)."""
+    dense 320 kb/s 44.1 kHz stereo stream, repeated), with each of the library's four decode routes (tuning key 6)."""
     import tempfile
 
     from mp3rgain_amd import mp3dec

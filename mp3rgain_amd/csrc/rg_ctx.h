@@ -160,7 +160,8 @@ struct rg_ctx {
     std::vector<std::string> file_errors;    // rg_analyze_tracks: message per file of the last call
     void (*file_pool_free)(void *) = nullptr;
     int gpu_mp3_decode = 3;                  // tuning key 6: 0 = host decoder, 1 = stages B-E of MP3 decoding run on the device,
-                                             // 2 (default) = scalefactors + Huffman too: the host only walks the frames
+                                             // 2 = scalefactors + Huffman too, 3 (default) = side-information parsing too: the host
+                                             // only finds the frames and strips their headers (loader pipeline, rg_files.hip)
     DevBuf<unsigned char> d_arena;           // staging for host PCM (synchronous API)
     DevBuf<unsigned char> d_ingest[2];       // streamed host ingest: two sub-batch arenas, one filling while the other is analysed
     DevBuf<uint32_t> d_album_packs;          // streamed album: one [histogram | peak] pack per sub-batch, folded at the end

@@ -225,13 +225,14 @@ struct LoadedAudio {
     // `frames` is what the device found decodable
     bool staged = false;
     uint64_t arena_off = 0;
-    uint32_t walked_frames = 0, result_index = 0;
+    uint64_t walked_frames = 0;  // PCM frames if every walked frame decodes: what the arena is laid out for
+    uint32_t result_index = 0;
     // ready for the next file; the vectors keep their capacity
     void reset() {
         wav.clear(); planar.clear(); is.clear(); units.clear(); main_stream.clear(); recs.clear(); file_bytes.clear();
         sample_rate = channels = 0; frames = 0; n_units = 0; lsf = 0;
         decoded = split = is_mp4 = staged = false;
-        arena_off = 0; walked_frames = result_index = 0;
+        arena_off = 0; walked_frames = 0; result_index = 0;
     }
 };
 
@@ -725,7 +726,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         la.sample_rate = si.sample_rate;
         la.channels = si.channels;
         la.lsf = si.mpeg_version == 1 ? 0u : 1u;
-        la.walked_frames = (uint32_t)si.frames;  // PCM frames if every walked frame decodes
+        la.walked_frames = si.frames;
         la.frames = si.frames;
         la.result_index = (uint32_t)i;
         la.staged = true;

@@ -73,6 +73,12 @@ template <> struct Fmt<RG_FMT_F32_PLANAR> {
     // 32-bit LDS word <-> sample
     static __device__ __forceinline__ uint32_t word(float v) { return __float_as_uint(v); }
     static __device__ __forceinline__ double cvt_word(uint32_t w, float &pk) { return cvt(__uint_as_float(w), pk); }
+    // the peak over a 4-frame piece in two v_max3_f32 instead of four v_max_f32 (fmaxf drops NaNs either way)
+    static __device__ __forceinline__ void peak4(const uint32_t (&f)[4], float &pk) {
+        pk = fmaxf(fmaxf(pk, fabsf(__uint_as_float(f[0]))), fabsf(__uint_as_float(f[1])));
+        pk = fmaxf(fmaxf(pk, fabsf(__uint_as_float(f[2]))), fabsf(__uint_as_float(f[3])));
+    }
+    static __device__ __forceinline__ double word_value(uint32_t w) { return (double)__uint_as_float(w); }
 };
 template <> struct Fmt<RG_FMT_S16_PLANAR> {
     typedef int16_t elem;
@@ -86,6 +92,11 @@ template <> struct Fmt<RG_FMT_S16_PLANAR> {
     static __device__ __forceinline__ double peak_norm(uint32_t pk) { return (double)pk / 32768.0; }
     static __device__ __forceinline__ uint32_t word(int16_t v) { return (uint32_t)(int32_t)v; }
     static __device__ __forceinline__ double cvt_word(uint32_t w, uint32_t &pk) { return cvt((int16_t)(int32_t)w, pk); }
+    static __device__ __forceinline__ void peak4(const uint32_t (&f)[4], uint32_t &pk) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) (void)cvt_word(f[u], pk);
+    }
+    static __device__ __forceinline__ double word_value(uint32_t w) { return (double)(int32_t)w; }
 };
 template <> struct Fmt<RG_FMT_S32_PLANAR> {
     typedef int32_t elem;
@@ -98,6 +109,11 @@ template <> struct Fmt<RG_FMT_S32_PLANAR> {
     static __device__ __forceinline__ double peak_norm(uint32_t pk) { return (double)pk / 2147483648.0; }
     static __device__ __forceinline__ uint32_t word(int32_t v) { return (uint32_t)v; }
     static __device__ __forceinline__ double cvt_word(uint32_t w, uint32_t &pk) { return cvt((int32_t)w, pk); }
+    static __device__ __forceinline__ void peak4(const uint32_t (&f)[4], uint32_t &pk) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) (void)cvt_word(f[u], pk);
+    }
+    static __device__ __forceinline__ double word_value(uint32_t w) { return (double)(int32_t)w; }
 };
 
 template <typename T>
@@ -149,13 +165,14 @@ typedef short __attribute__((ext_vector_type(4), aligned(2))) rg_s16x4u;     // 
 //   G2  z,  w_1 = bb_1 y + t_1,  w_2 = bb_2 y + c          (need y, issued 10 slots earlier)
 //   G3  s_i = u_i - a_{i+1} y                              (10, need y and u_i)
 //   G4  t_0, t_1, A, B_j                                   (need z, issued 10 slots earlier)
-template <int FMT, int NX, bool MASK>
+template <int FMT, int NX, bool MASK, bool PEAK = true>
 __device__ __forceinline__ void tm_frame(TmLane<1> &st, const uint32_t wbits, typename Fmt<FMT>::peak_t &pk,
                                          const double *__restrict__ tr /* NX values; unused when NX == 0 */, const RgTmCoef &K,
                                          const uint32_t n, const uint32_t len) {
     double (&s)[10] = st.s[0];
     double (&t)[2] = st.t[0];
-    const double x = Fmt<FMT>::cvt_word(wbits, pk);  // also tracks the peak; frames past the end were staged as zeros
+    // frames past the end were staged as zeros; the peak is tracked here or, for whole pieces, by the caller (peak4)
+    const double x = PEAK ? Fmt<FMT>::cvt_word(wbits, pk) : Fmt<FMT>::word_value(wbits);
     const double y = fma(K.b[0], x, s[0]);
     double u[10];
 #pragma unroll
@@ -284,15 +301,16 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
         auto piece = [&](const int p, const uint4 v) {
             const uint32_t f[4] = {v.x, v.y, v.z, v.w};
             const uint32_t n = n0 + 4u * p;
+            F::peak4(f, pk);
             if (MODE == 3 || MODE == 4) {  // cascade and energy only
 #pragma unroll
-                for (int u = 0; u < 4; ++u) tm_frame<FMT, 0, TAIL>(st, f[u], pk, nullptr, K, n + u, len);
+                for (int u = 0; u < 4; ++u) tm_frame<FMT, 0, TAIL, false>(st, f[u], pk, nullptr, K, n + u, len);
             } else if (MODE == 1 || (MODE == 0 && n < H)) {  // all 12 transient moments live (H is a multiple of 4, or the whole segment)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     double row[12];
                     tm_load_row<12>(row, T12 + (size_t)(n + u) * 12);
-                    tm_frame<FMT, 12, TAIL>(st, f[u], pk, row, K, n + u, len);
+                    tm_frame<FMT, 12, TAIL, false>(st, f[u], pk, row, K, n + u, len);
                 }
             } else {  // only the slow (Butterworth) pair
                 double rows[8];
@@ -301,7 +319,7 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const double tr[2] = {rows[2 * u], rows[2 * u + 1]};
-                    tm_frame<FMT, 2, TAIL>(st, f[u], pk, tr, K, n + u, len);
+                    tm_frame<FMT, 2, TAIL, false>(st, f[u], pk, tr, K, n + u, len);
                 }
             }
         };
