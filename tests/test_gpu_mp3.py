@@ -272,7 +272,11 @@ def test_analyze_tracks_batch_has_per_file_outcomes(_ctx, oracle, tmp_path):
     ok_wav.write_bytes(wav_bytes(test_signal("f32", 48000, 48000 * 2, 2, seed=2), 48000, "f32"))
     junk = tmp_path / "junk.mp3"
     junk.write_bytes(b"ID3" + bytes(500))
-    files = [FIX / "test_vbr.mp3", tmp_path / "missing.mp3", ok_wav, odd, GOLD / "v2_22k_stereo.mp3", junk, FIX / "test_mono.mp3"]
+    empty = tmp_path / "empty.mp3"
+    empty.write_bytes(b"")
+    tiny = tmp_path / "tiny.mp3"
+    tiny.write_bytes(b"\xff\xfb\x90")
+    files = [FIX / "test_vbr.mp3", tmp_path / "missing.mp3", ok_wav, odd, GOLD / "v2_22k_stereo.mp3", junk, FIX / "test_mono.mp3", empty, tiny]
     got = an.analyze_track_files(files)
     assert len(got) == len(files)
     for f, g in zip(files, got):
@@ -283,7 +287,8 @@ def test_analyze_tracks_batch_has_per_file_outcomes(_ctx, oracle, tmp_path):
             continue
         assert not isinstance(g, rg.ReplayGainError), (f.name, g)
         assert (g.loudness_db, g.gain_db, g.peak, g.sample_rate, g.windows, g.file_type) == (want.loudness_db, want.gain_db, want.peak, want.sample_rate, want.windows, want.file_type), f.name
-    assert [isinstance(g, rg.ReplayGainError) for g in got] == [False, True, False, True, False, True, False]
+    assert [isinstance(g, rg.ReplayGainError) for g in got] == [False, True, False, True, False, True, False, True, True]
+    assert "Failed to probe format" in str(got[7]) and "Failed to probe format" in str(got[8])
     assert "Failed to open" in str(got[1]) and "Unsupported sample rate: 44000 Hz" in str(got[3]) and "Failed to probe format" in str(got[5])
     # track index > 0: every file reports it
     idx = an.analyze_track_files(files[:1], track_index=1)
