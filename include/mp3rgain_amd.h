@@ -282,7 +282,9 @@ int rg_analyze_wav_batch(rg_ctx *ctx, const void *const *wav, const size_t *wav_
 int rg_analyze_track(rg_ctx *ctx, const char *path, int32_t track_index, rg_track_result *out);
 /* `-r` over many files (src/main.rs:1937-2001 runs analyze_track on one file after the other): the files are loaded on
  * all host cores and decoded + analysed as one GPU batch.  status_out[i] = RG_OK or file i's error code (its text:
- * rg_tracks_error(ctx, i)); a failing file does not stop the others.  Results are those of rg_analyze_track per file. */
+ * rg_tracks_error(ctx, i)); a failing file does not stop the others.  Results are those of rg_analyze_track per file.
+ * A long list is taken in groups whose PCM fits a third of the free device memory (at most 64 GB): a whole library can be
+ * passed in one call.  (rg_analyze_album needs the album's PCM resident at once: about 4000 three-minute tracks per GPU.) */
 int rg_analyze_tracks(rg_ctx *ctx, const char *const *paths, size_t n, int32_t track_index, rg_track_result *out,
                       int32_t *status_out);
 const char *rg_tracks_error(const rg_ctx *ctx, size_t i);

@@ -1034,10 +1034,12 @@ extern "C" int rg_analyze_album(rg_ctx *c, const char *const *paths, size_t n, i
 // `-r` over many files (src/main.rs:1937-2001 calls analyze_track for one file after the other; the results are
 // independent): all files are loaded on the host's cores, decoded and analysed as ONE batch on the GPU.  A file that
 // fails (cannot be opened, is no audio, has an unsupported rate) gets its status and message and does not stop the rest.
-extern "C" int rg_analyze_tracks(rg_ctx *c, const char *const *paths, size_t n, int32_t track_index, rg_track_result *out,
-                                 int32_t *status_out) {
-    if (!c || (n && (!paths || !out || !status_out))) return RG_ERR_INVALID_ARG;
-    c->file_errors.assign(n, std::string());
+// one group of rg_analyze_tracks: files [first, first + n) of the call; file_errors is indexed by the call's numbering
+static int analyze_tracks_group(rg_ctx *c, const char *const *paths, size_t first, size_t n, int32_t track_index, rg_track_result *out,
+                                int32_t *status_out) {
+    paths += first;
+    out += first;
+    status_out += first;
     std::vector<LoadedAudio> &in = file_pool(c, n);
     std::vector<int> rcs;
     std::vector<std::string> errs;
@@ -1048,13 +1050,13 @@ extern "C" int rg_analyze_tracks(rg_ctx *c, const char *const *paths, size_t n, 
     for (size_t i = 0; i < n; ++i) {
         memset(&out[i], 0, sizeof out[i]);
         status_out[i] = rcs[i];
-        c->file_errors[i] = errs[i];
+        c->file_errors[first + i] = errs[i];
         if (rcs[i] != RG_OK) continue;
         if (track_index > 0) {
             char msg[128];
             snprintf(msg, sizeof msg, "Track index %d out of range (file has 1 audio track(s))", track_index);
             status_out[i] = RG_ERR_INVALID_ARG;
-            c->file_errors[i] = msg;
+            c->file_errors[first + i] = msg;
             continue;
         }
         uint32_t rate = in[i].sample_rate;
@@ -1063,7 +1065,7 @@ extern "C" int rg_analyze_tracks(rg_ctx *c, const char *const *paths, size_t n, 
             rate = rg_wav_parse(in[i].wav.data(), in[i].wav.size(), &wi) == RG_OK ? wi.sample_rate : 0;
             if (rate == 0) {
                 status_out[i] = RG_ERR_FORMAT;
-                c->file_errors[i] = std::string("Failed to probe format: ") + paths[i];
+                c->file_errors[first + i] = std::string("Failed to probe format: ") + paths[i];
                 continue;
             }
         }
@@ -1072,7 +1074,7 @@ extern "C" int rg_analyze_tracks(rg_ctx *c, const char *const *paths, size_t n, 
             snprintf(msg, sizeof msg, "Unsupported sample rate: %u Hz. Supported rates: 96000, 88200, 64000, 48000, 44100, 32000, 24000, "
                                       "22050, 16000, 12000, 11025, 8000", rate);
             status_out[i] = RG_ERR_UNSUPPORTED_RATE;
-            c->file_errors[i] = msg;
+            c->file_errors[first + i] = msg;
             continue;
         }
         slot.push_back(i);
@@ -1096,9 +1098,41 @@ extern "C" int rg_analyze_tracks(rg_ctx *c, const char *const *paths, size_t n, 
     if (rc != RG_OK) {  // a failure of the batch itself (a WAV of a kind the library cannot stage, a device error): every file in it carries it
         for (size_t k = 0; k < slot.size(); ++k) {
             status_out[slot[k]] = rc;
-            c->file_errors[slot[k]] = c->err;
+            c->file_errors[first + slot[k]] = c->err;
         }
         return RG_OK;
+    }
+    return RG_OK;
+}
+
+// `-r` over a whole library must not need the whole library's PCM in HBM at once: the files are taken in groups whose
+// PCM is estimated (24 bytes of planar f32 per byte of file: a 128 kb/s stereo MP3; denser files decode to less) to stay
+// within a third of the free device memory, at most 64 GB.  Tracks are independent, so the groups are too.
+extern "C" int rg_analyze_tracks(rg_ctx *c, const char *const *paths, size_t n, int32_t track_index, rg_track_result *out,
+                                 int32_t *status_out) {
+    if (!c || (n && (!paths || !out || !status_out))) return RG_ERR_INVALID_ARG;
+    c->file_errors.assign(n, std::string());
+    int rc = rg_bind_device(c);
+    if (rc != RG_OK) return rc;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)48 << 30;
+    size_t budget = std::min((size_t)64 << 30, (free_b + c->d_arena.cap) / 3);
+    if (const char *e = getenv("RG_TRACKS_GROUP_BYTES")) {  // tests: small groups
+        const long long v = atoll(e);
+        if (v > 0) budget = (size_t)v;
+    }
+    for (size_t first = 0; first < n;) {
+        size_t last = first, est = 0;
+        while (last < n) {
+            struct stat st;
+            const size_t sz = (paths[last] && stat(paths[last], &st) == 0 && st.st_size > 0) ? (size_t)st.st_size : 0;
+            if (last > first && est + sz * 24 > budget) break;
+            est += sz * 24;
+            ++last;
+        }
+        rc = analyze_tracks_group(c, paths, first, last - first, track_index, out, status_out);
+        if (rc != RG_OK) return rc;
+        first = last;
     }
     return RG_OK;
 }

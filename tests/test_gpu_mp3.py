@@ -352,3 +352,29 @@ def test_loader_pipeline_with_tiny_staging_blocks(oracle, tmp_path, monkeypatch)
         pcm, info = mp3dec.decode(f.read_bytes())
         ref, _ = oracle.analyze_pcm(pcm[0], pcm[1] if info.channels == 2 else None, info.sample_rate)
         assert (a.loudness_db, a.peak) == (ref["loudness_db"], ref["peak"]), f.name
+
+
+def test_analyze_tracks_in_groups_bounded_by_memory(_ctx, tmp_path, monkeypatch):
+    """`-r` over a whole library is taken in groups whose PCM fits the device (rg_analyze_tracks): with the group size forced
+    down to a few files, results and per-file errors are those of the single batch."""
+    import mp3rgain_amd as rg
+
+    an = _ctx
+    an.set_kernel(0)
+    files = []
+    srcs = [p for p in STREAMS if p.stat().st_size < 60000]
+    for k in range(23):
+        f = tmp_path / f"g{k:02d}.mp3"
+        f.write_bytes(srcs[k % len(srcs)].read_bytes())
+        files.append(f)
+    files.insert(5, tmp_path / "nope.mp3")
+    whole = an.analyze_track_files(files)
+    monkeypatch.setenv("RG_TRACKS_GROUP_BYTES", str(24 * 70000))  # two or three files per group
+    grouped = an.analyze_track_files(files)
+    assert len(whole) == len(grouped) == len(files)
+    for f, a, b in zip(files, whole, grouped):
+        if isinstance(a, rg.ReplayGainError):
+            assert isinstance(b, rg.ReplayGainError) and (a.code, str(a)) == (b.code, str(b)), f.name
+        else:
+            assert (a.loudness_db, a.gain_db, a.peak, a.sample_rate, a.windows) == (b.loudness_db, b.gain_db, b.peak, b.sample_rate, b.windows), f.name
+    assert isinstance(whole[5], rg.ReplayGainError) and sum(isinstance(x, rg.ReplayGainError) for x in whole) == 1
