@@ -284,11 +284,12 @@ int rg_analyze_track(rg_ctx *ctx, const char *path, int32_t track_index, rg_trac
  * all host cores and decoded + analysed as one GPU batch.  status_out[i] = RG_OK or file i's error code (its text:
  * rg_tracks_error(ctx, i)); a failing file does not stop the others.  Results are those of rg_analyze_track per file.
  * A long list is taken in groups whose PCM fits a third of the free device memory (at most 64 GB): a whole library can be
- * passed in one call.  (rg_analyze_album needs the album's PCM resident at once: about 4000 three-minute tracks per GPU.) */
+ * passed in one call. */
 int rg_analyze_tracks(rg_ctx *ctx, const char *const *paths, size_t n, int32_t track_index, rg_track_result *out,
                       int32_t *status_out);
 const char *rg_tracks_error(const rg_ctx *ctx, size_t i);
-/* analyze_album_with_index (src/replaygain.rs:1044-1074): results in input order; the first failing file aborts */
+/* analyze_album_with_index (src/replaygain.rs:1044-1074): results in input order; the first failing file aborts.  An album
+ * whose PCM does not fit the device at once is analysed in parts whose histograms and peaks are folded: same result. */
 int rg_analyze_album(rg_ctx *ctx, const char *const *paths, size_t n, int32_t track_index,
                      rg_track_result *tracks_out, rg_album_result *album_out);
 /* find_peak_amplitude (src/replaygain.rs:1140-1249) */

@@ -805,6 +805,39 @@ extern "C" int rg_analyze_album_pcm(rg_ctx *c, const rg_track_desc *tracks, size
     return rg_album_finish(c, album_out, album_hist_out);
 }
 
+// rg_ctx.h: an album in parts (the file layer's albums larger than the device); same folding as the streamed host ingest
+int rg_album_part(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *d_base, size_t bytes, size_t index, size_t parts,
+                  rg_track_result *out) {
+    if (index == 0) {
+        int rc = sync_all(c);
+        if (rc != RG_OK) return rc;
+        RG_HIP(c, c->d_album_packs.reserve(parts * (size_t)RG_ALBUM_PACK_WORDS));
+    }
+    int rc = rg_enqueue_impl(c, tracks, n, d_base, bytes, 1);
+    if (rc != RG_OK) return rc;
+    rc = rg_collect(c, out, nullptr);
+    if (rc != RG_OK) return rc;
+    if (needs_exact_pass(c, out, n)) {
+        ExactPass exact(c);
+        rc = rg_enqueue_impl(c, tracks, n, d_base, bytes, 1);
+        if (rc != RG_OK) return rc;
+        rc = rg_collect(c, out, nullptr);
+        if (rc != RG_OK) return rc;
+    }
+    RgSlot &S = c->slot();
+    RG_HIP(c, hipMemcpyAsync(c->d_album_packs.p + index * (size_t)RG_ALBUM_PACK_WORDS, S.d_album_hist.p,
+                             (size_t)RG_ALBUM_PACK_WORDS * sizeof(uint32_t), hipMemcpyDeviceToDevice, S.stream));
+    RG_HIP(c, hipStreamSynchronize(S.stream));  // the arena is the next part's
+    return RG_OK;
+}
+
+int rg_album_parts_finish(rg_ctx *c, size_t parts, rg_album_result *album_out) {
+    RgSlot &S = c->slot();
+    RG_HIP(c, rg_launch_album_reduce_gathered(c->d_album_packs.p, (uint32_t)parts, S.d_album_hist.p, S.d_album_peak.p, S.stream));
+    S.album_ready = true;
+    return rg_album_finish(c, album_out, nullptr);
+}
+
 extern "C" int rg_find_peak_pcm(rg_ctx *c, const rg_track_desc *track, const void *pcm_base, size_t pcm_bytes,
                                 int on_device, rg_peak_result *out) {
     if (!c || !track || !out) return RG_ERR_INVALID_ARG;

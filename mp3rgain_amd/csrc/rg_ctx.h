@@ -189,6 +189,12 @@ int rg_bind_device(rg_ctx *c);
 int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *d_pcm_base, size_t pcm_bytes,
                     int album);
 void rg_tm_tables_release(rg_ctx *c);
+// An album whose PCM comes to the device part by part (rg_files.hip: more files than fit): rg_album_part analyses part
+// `index` of `parts` from a device arena (per-track results in `out`, exact repeat included) and keeps its
+// [histogram | peak] pack; rg_album_parts_finish folds the packs and produces the album result.
+int rg_album_part(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *d_base, size_t bytes, size_t index, size_t parts,
+                  rg_track_result *out);
+int rg_album_parts_finish(rg_ctx *c, size_t parts, rg_album_result *album_out);
 int rg_validate_batch(rg_ctx *c, const rg_track_desc *tracks, size_t n, size_t pcm_bytes);  // argument checks of an enqueue
 
 #define RG_HIP(ctx, call)                                                                          \

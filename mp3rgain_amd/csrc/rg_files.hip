@@ -998,42 +998,74 @@ extern "C" int rg_analyze_track(rg_ctx *c, const char *path, int32_t track_index
     return RG_OK;
 }
 
-// analyze_album_with_index (src/replaygain.rs:1044-1074): the first failing file aborts the album (:1055)
+// Files of a long list in groups whose PCM is estimated (24 bytes of planar f32 per byte of file: a 128 kb/s stereo MP3;
+// denser files decode to less) to stay within a third of the free device memory, at most 64 GB.
+static void file_groups(rg_ctx *c, const char *const *paths, size_t n, std::vector<std::pair<size_t, size_t>> *groups) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)48 << 30;
+    size_t budget = std::min((size_t)64 << 30, (free_b + c->d_arena.cap) / 3);
+    if (const char *e = getenv("RG_TRACKS_GROUP_BYTES")) {  // tests: small groups
+        const long long v = atoll(e);
+        if (v > 0) budget = (size_t)v;
+    }
+    groups->clear();
+    for (size_t first = 0; first < n;) {
+        size_t last = first, est = 0;
+        while (last < n) {
+            struct stat st;
+            const size_t sz = (paths[last] && stat(paths[last], &st) == 0 && st.st_size > 0) ? (size_t)st.st_size : 0;
+            if (last > first && est + sz * 24 > budget) break;
+            est += sz * 24;
+            ++last;
+        }
+        groups->push_back(std::make_pair(first, last - first));
+        first = last;
+    }
+}
+
+// analyze_album_with_index (src/replaygain.rs:1044-1074): the first failing file aborts the album (:1055).  An album
+// whose PCM does not fit the device at once is analysed in parts and the parts' histograms and peaks are folded (u32
+// adds commute: the result does not depend on the partition).
 extern "C" int rg_analyze_album(rg_ctx *c, const char *const *paths, size_t n, int32_t track_index, rg_track_result *tracks_out,
                                 rg_album_result *album_out) {
     if (!c || (n && (!paths || !tracks_out)) || !album_out) return RG_ERR_INVALID_ARG;
-    std::vector<LoadedAudio> &in = file_pool(c, n);
+    int rc = rg_bind_device(c);
+    if (rc != RG_OK) return rc;
+    std::vector<std::pair<size_t, size_t>> groups;
+    file_groups(c, paths, n, &groups);
     const bool trace = getenv("RG_TRACE_FILES") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = now();
-    int rc = load_many(c, paths, n, &in);
-    if (rc != RG_OK) return rc;
-    if (n) {
-        rc = check_track_index(c, track_index);
+    for (size_t g = 0; g < std::max<size_t>(groups.size(), 1); ++g) {
+        const size_t first = groups.empty() ? 0 : groups[g].first, cnt = groups.empty() ? 0 : groups[g].second;
+        std::vector<LoadedAudio> &in = file_pool(c, cnt);
+        const double t0 = now();
+        rc = load_many(c, paths + first, cnt, &in);
         if (rc != RG_OK) return rc;
+        if (cnt) {
+            rc = check_track_index(c, track_index);
+            if (rc != RG_OK) return rc;
+        }
+        const double t1 = now();
+        std::vector<rg_track_desc> descs;
+        size_t arena_bytes = 0;
+        rc = stage_loaded(c, in, cnt, &descs, &arena_bytes);
+        if (trace) fprintf(stderr, "[rg_analyze_album] load %.1f ms, stage + device decode %.1f ms\n", (t1 - t0) * 1e3, (now() - t1) * 1e3);
+        if (rc == RG_ERR_FORMAT) {  // "input i ..." -> the reference's text with the file's name
+            size_t i = 0;
+            if (sscanf(c->err.c_str(), "input %zu", &i) == 1 && i < cnt) return rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s", paths[first + i]);
+        }
+        if (rc != RG_OK) return rc;
+        const double t2 = now();
+        if (groups.size() <= 1) rc = rg_analyze_album_pcm(c, descs.data(), cnt, c->d_arena.p, arena_bytes, 1, tracks_out, album_out, nullptr);
+        else rc = rg_album_part(c, descs.data(), cnt, c->d_arena.p, arena_bytes, g, groups.size(), tracks_out + first);
+        if (rc != RG_OK) return rc;
+        for (size_t i = 0; i < cnt; ++i) tracks_out[first + i].file_type = in[i].is_mp4 ? RG_FILE_AAC : RG_FILE_MP3;
+        if (trace) fprintf(stderr, "[rg_analyze_album] analysis %.1f ms\n", (now() - t2) * 1e3);
     }
-    const double t1 = now();
-    std::vector<rg_track_desc> descs;
-    size_t arena_bytes = 0;
-    rc = stage_loaded(c, in, n, &descs, &arena_bytes);
-    if (trace) fprintf(stderr, "[rg_analyze_album] load %.1f ms, stage + device decode %.1f ms\n", (t1 - t0) * 1e3, (now() - t1) * 1e3);
-    if (rc == RG_ERR_FORMAT) {  // "input i ..." -> the reference's text with the file's name
-        size_t i = 0;
-        if (sscanf(c->err.c_str(), "input %zu", &i) == 1 && i < n) return rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s", paths[i]);
-    }
-    if (rc != RG_OK) return rc;
-    const double t2 = now();
-    rc = rg_analyze_album_pcm(c, descs.data(), n, c->d_arena.p, arena_bytes, 1, tracks_out, album_out, nullptr);
-    if (rc != RG_OK) return rc;
-    const double t3 = now();
-    for (size_t i = 0; i < n; ++i) tracks_out[i].file_type = in[i].is_mp4 ? RG_FILE_AAC : RG_FILE_MP3;
-    if (trace) fprintf(stderr, "[rg_analyze_album] analysis %.1f ms\n", (t3 - t2) * 1e3);
+    if (groups.size() > 1) return rg_album_parts_finish(c, groups.size(), album_out);
     return RG_OK;
 }
 
-// `-r` over many files (src/main.rs:1937-2001 calls analyze_track for one file after the other; the results are
-// independent): all files are loaded on the host's cores, decoded and analysed as ONE batch on the GPU.  A file that
-// fails (cannot be opened, is no audio, has an unsupported rate) gets its status and message and does not stop the rest.
 // one group of rg_analyze_tracks: files [first, first + n) of the call; file_errors is indexed by the call's numbering
 static int analyze_tracks_group(rg_ctx *c, const char *const *paths, size_t first, size_t n, int32_t track_index, rg_track_result *out,
                                 int32_t *status_out) {
@@ -1105,34 +1137,19 @@ static int analyze_tracks_group(rg_ctx *c, const char *const *paths, size_t firs
     return RG_OK;
 }
 
-// `-r` over a whole library must not need the whole library's PCM in HBM at once: the files are taken in groups whose
-// PCM is estimated (24 bytes of planar f32 per byte of file: a 128 kb/s stereo MP3; denser files decode to less) to stay
-// within a third of the free device memory, at most 64 GB.  Tracks are independent, so the groups are too.
+// `-r` over a whole library must not need the whole library's PCM in HBM at once: the files are taken in groups
+// (file_groups).  Tracks are independent, so the groups are too.
 extern "C" int rg_analyze_tracks(rg_ctx *c, const char *const *paths, size_t n, int32_t track_index, rg_track_result *out,
                                  int32_t *status_out) {
     if (!c || (n && (!paths || !out || !status_out))) return RG_ERR_INVALID_ARG;
     c->file_errors.assign(n, std::string());
     int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)48 << 30;
-    size_t budget = std::min((size_t)64 << 30, (free_b + c->d_arena.cap) / 3);
-    if (const char *e = getenv("RG_TRACKS_GROUP_BYTES")) {  // tests: small groups
-        const long long v = atoll(e);
-        if (v > 0) budget = (size_t)v;
-    }
-    for (size_t first = 0; first < n;) {
-        size_t last = first, est = 0;
-        while (last < n) {
-            struct stat st;
-            const size_t sz = (paths[last] && stat(paths[last], &st) == 0 && st.st_size > 0) ? (size_t)st.st_size : 0;
-            if (last > first && est + sz * 24 > budget) break;
-            est += sz * 24;
-            ++last;
-        }
-        rc = analyze_tracks_group(c, paths, first, last - first, track_index, out, status_out);
+    std::vector<std::pair<size_t, size_t>> groups;
+    file_groups(c, paths, n, &groups);
+    for (const auto &g : groups) {
+        rc = analyze_tracks_group(c, paths, g.first, g.second, track_index, out, status_out);
         if (rc != RG_OK) return rc;
-        first = last;
     }
     return RG_OK;
 }

@@ -378,3 +378,29 @@ def test_analyze_tracks_in_groups_bounded_by_memory(_ctx, tmp_path, monkeypatch)
         else:
             assert (a.loudness_db, a.gain_db, a.peak, a.sample_rate, a.windows) == (b.loudness_db, b.gain_db, b.peak, b.sample_rate, b.windows), f.name
     assert isinstance(whole[5], rg.ReplayGainError) and sum(isinstance(x, rg.ReplayGainError) for x in whole) == 1
+
+
+def test_album_larger_than_the_device_is_analysed_in_parts(_ctx, oracle, tmp_path, monkeypatch):
+    """rg_analyze_album on a file list whose PCM would not fit the device at once: the list is cut into parts, each part is
+    an album enqueue of its own, and the parts' histograms and peaks are folded.  With the part size forced down to a few
+    files the album and every track are those of the single-batch album (and of the oracle's merge)."""
+    an = _ctx
+    an.set_kernel(0)
+    srcs = [p for p in STREAMS if p.stat().st_size < 60000]
+    files = []
+    for k in range(19):
+        f = tmp_path / f"a{k:02d}.mp3"
+        f.write_bytes(srcs[(3 * k) % len(srcs)].read_bytes())
+        files.append(f)
+    whole = an.analyze_album_files(files)
+    monkeypatch.setenv("RG_TRACKS_GROUP_BYTES", str(24 * 70000))
+    parts = an.analyze_album_files(files)
+    assert (parts.album_loudness_db, parts.album_gain_db, parts.album_peak) == (whole.album_loudness_db, whole.album_gain_db, whole.album_peak)
+    for a, b in zip(whole.tracks, parts.tracks):
+        assert (a.loudness_db, a.gain_db, a.peak, a.sample_rate, a.windows, a.file_type) == (b.loudness_db, b.gain_db, b.peak, b.sample_rate, b.windows, b.file_type)
+    per = []
+    for f in files:
+        pcm, info = mp3dec.decode(f.read_bytes())
+        per.append(oracle.analyze_pcm(pcm[0], pcm[1] if info.channels == 2 else None, info.sample_rate))
+    want, _ = oracle.album_from_hists([h for _, h in per], [r["peak"] for r, _ in per])
+    assert (parts.album_loudness_db, parts.album_gain_db, parts.album_peak) == (want["album_loudness_db"], want["album_gain_db"], want["album_peak"])
