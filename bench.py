@@ -165,16 +165,17 @@ def mp3_end_to_end(an, nfiles: int) -> dict:
             an.analyze_album_files(files)
         for mode, name in ((3, "device: host strips headers only, pipelined"), (2, "device: host parses side info"), (1, "split: Huffman on host"), (0, "host decoder")):
             an.set_tuning(6, mode)
-            an.analyze_album_files(files[:2])
+            sub = files if mode >= 2 else files[:min(nfiles, 64)]  # the host-bound routes on fewer files: they take seconds
+            an.analyze_album_files(sub[:2])
             dt = 1e9
             for _ in range(2 if mode else 1):
                 t0 = time.perf_counter()
-                res = an.analyze_album_files(files)
+                res = an.analyze_album_files(sub)
                 dt = min(dt, time.perf_counter() - t0)
                 if os.environ.get("RG_TRACE_FILES"):
                     print(f"[bench] mode {mode}: {time.perf_counter() - t0:.3f} s", file=sys.stderr)
-            leg["routes"][name] = {"seconds": dt, "value": nfiles * si.frames / dt, "x_real_time": nfiles * si.frames / si.sample_rate / dt,
-                                   "album_loudness_db": res.album_loudness_db}
+            leg["routes"][name] = {"files": len(sub), "seconds": dt, "value": len(sub) * si.frames / dt,
+                                   "x_real_time": len(sub) * si.frames / si.sample_rate / dt, "album_loudness_db": res.album_loudness_db}
     finally:
         an.set_tuning(6, 3)
         for p in files:
@@ -207,7 +208,7 @@ def main() -> int:
     ap.add_argument("--parity-tracks", type=int, default=16, help="tracks of the batch whose full histogram is compared with the oracle")
     ap.add_argument("--no-configs1", action="store_true", help="skip the secondary configs[1] measurement")
     ap.add_argument("--no-mp3", action="store_true", help="skip the MP3 end-to-end leg (decode + analysis from compressed files)")
-    ap.add_argument("--mp3-files", type=int, default=64, help="files of the MP3 end-to-end leg (3-minute 320 kb/s streams)")
+    ap.add_argument("--mp3-files", type=int, default=256, help="files of the MP3 end-to-end leg (3-minute 320 kb/s streams; the two host-bound routes run on the first 64)")
     ap.add_argument("--configs1-steps", type=int, default=300)
     ap.add_argument("--pre-roll", type=float, default=PRE_ROLL_SECONDS, help="untimed pre-roll before the warm-up steps, seconds of work")
     args = ap.parse_args()
