@@ -387,33 +387,44 @@ namespace {
 
 constexpr int kHuffThreads = 512;
 
-// 96 bits of the track's main data around `pos`, big-endian words; bits at or past `limit` (the end of the frame's own
-// main data) read as zero, which is what the host decoder's private copy of the frame's data does.
+// 96 bits of the track's main data around the read position, big-endian words; bits at or past `limit` (the end of the
+// frame's own main data) read as zero, which is what the host decoder's private copy of the frame's data does.  All
+// positions are 32-bit bit counts from the 32-bit word the granule starts in (a granule is at most 4095 bits long, its
+// frame's data ends at most a few thousand bits later).
 struct BitCache {
-    const uint32_t *__restrict__ w;  // the track's main data (4-byte aligned)
-    uint64_t pos, end, limit;
-    uint64_t idx;                    // word index of w0
+    const uint32_t *__restrict__ w;  // the word the granule starts in (the track's main data is 4-byte aligned)
+    uint32_t pos, end;               // read position, end of the granule's bits
+    int32_t limit;                   // end of the frame's own data; may lie before `pos` in damaged streams
+    uint32_t idx;                    // word index of w0
     uint32_t w0, w1, w2;
-    __device__ __forceinline__ uint32_t load(uint64_t i) const {
-        const int64_t valid = (int64_t)limit - (int64_t)(i << 5);
+    __device__ __forceinline__ uint32_t load(uint32_t i) const {
+        const int32_t valid = limit - (int32_t)(i << 5);
         if (valid <= 0) return 0u;
         uint32_t x = __builtin_bswap32(w[i]);
-        if (valid < 32) x &= 0xFFFFFFFFu << (32 - (int)valid);
+        if (valid < 32) x &= 0xFFFFFFFFu << (32 - valid);
         return x;
     }
-    __device__ __forceinline__ void seek(uint64_t p) {
-        pos = p;
-        idx = p >> 5;
-        w0 = load(idx);
-        w1 = load(idx + 1);
-        w2 = load(idx + 2);
+    // granule at absolute bit `bit_off` of the stream `base`, `length` bits long, frame data ending at `frame_end_bit`
+    __device__ __forceinline__ void open(const uint8_t *base, uint64_t bit_off, uint32_t length, uint64_t frame_end_bit) {
+        const uint64_t word0 = bit_off >> 5;
+        w = reinterpret_cast<const uint32_t *>(base) + word0;
+        pos = (uint32_t)(bit_off & 31);
+        end = pos + length;
+        const int64_t lim = (int64_t)frame_end_bit - (int64_t)(word0 << 5);
+        limit = lim < -(1 << 30) ? -(1 << 30) : (lim > (1 << 30) ? (1 << 30) : (int32_t)lim);
+        idx = 0;
+        w0 = load(0);
+        w1 = load(1);
+        w2 = load(2);
     }
-    __device__ __forceinline__ uint32_t peek(int n) const {  // 1 <= n <= 25
+    // the 32 bits at the read position
+    __device__ __forceinline__ uint32_t window() const {
         const uint64_t two = ((uint64_t)w0 << 32) | (uint64_t)w1;
-        return (uint32_t)((two << (pos & 31)) >> (64 - n));
+        return (uint32_t)((two << (pos & 31)) >> 32);
     }
+    __device__ __forceinline__ uint32_t peek(int n) const { return window() >> (32 - n); }  // 1 <= n <= 32
     __device__ __forceinline__ void skip(int n) {  // n <= 32
-        pos += (uint64_t)n;
+        pos += (uint32_t)n;
         if ((pos >> 5) != idx) {
             ++idx;
             w0 = w1;
@@ -537,21 +548,16 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
     if (local >= (uint64_t)tr.n_granules * nch) return;  // past what the frame parser found decodable
     const RgMp3HuffRec r = recs[u];
     uint8_t *__restrict__ sf = sf_all + tid;
-    BitCache b;
-    b.w = reinterpret_cast<const uint32_t *>(main + tr.main_base);  // the records' bit offsets are relative to the track's stream
+    BitCache b;  // the records' bit offsets are relative to the track's stream
     uint64_t illegal = 0;
     int preflag = 0;
     const bool reuse = !tr.lsf && r.gr == 1 && r.block_type != 2 && r.scfsi != 0;
     if (reuse) {  // granule 0 of the same frame and channel sits nch units back
         const RgMp3HuffRec r0 = recs[u - nch];
-        b.end = r0.bit_off + r0.part2_3_length;
-        b.limit = r0.frame_end_bit;
-        b.seek(r0.bit_off);
+        b.open(main + tr.main_base, r0.bit_off, r0.part2_3_length, r0.frame_end_bit);
         huff_scalefactors(b, r0, false, false, sf, &illegal, &preflag);
     }
-    b.end = r.bit_off + r.part2_3_length;
-    b.limit = r.frame_end_bit;
-    b.seek(r.bit_off);
+    b.open(main + tr.main_base, r.bit_off, r.part2_3_length, r.frame_end_bit);
     huff_scalefactors(b, r, tr.lsf != 0, reuse, sf, &illegal, &preflag);
     // ---- band layout and big_values regions (rg_mp3dec.cpp: parse_side_info, derived part) ----
     int long_end, short_start;
@@ -586,40 +592,56 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
         const int linbits = t_linbits[t];
         while (line < end) {
             if (b.pos >= b.end) { for (; line < end; line += 2) out.put(line, 0u); break; }
-            uint32_t e = E[b.peek(P)];
+            // code, escapes and signs come out of one 32-bit window whenever they fit (a code is at most 19 bits long)
+            const uint32_t win = b.window();
+            uint32_t e = E[win >> (32 - P)];
+            int used = 0;
             if (e & 0x80000000u) {
-                b.skip(P);
-                e = E[((e >> 8) & 0x7FFFFF) + b.peek((int)(e & 0xFF))];
+                e = E[((e >> 8) & 0x7FFFFF) + ((win << P) >> (32 - (int)(e & 0xFF)))];
+                used = P;
             }
-            b.skip((int)(e & 0xFF));
+            used += (int)(e & 0xFF);
             int x = (int)((e >> 12) & 15), y = (int)((e >> 8) & 15);
-            if (x) {
-                if (linbits && x == 15) x += (int)b.get(linbits);
-                if (b.get1()) x = -x;
-            }
-            if (y) {
-                if (linbits && y == 15) y += (int)b.get(linbits);
-                if (b.get1()) y = -y;
+            if (linbits == 0 || (x != 15 && y != 15)) {
+                if (x) { if ((win << used) >> 31) x = -x; ++used; }
+                if (y) { if ((win << used) >> 31) y = -y; ++used; }
+                b.skip(used);
+            } else {
+                b.skip(used);
+                if (x) {
+                    if (x == 15) x += (int)b.get(linbits);
+                    if (b.get1()) x = -x;
+                }
+                if (y) {
+                    if (y == 15) y += (int)b.get(linbits);
+                    if (b.get1()) y = -y;
+                }
             }
             out.put(line, ((uint32_t)x & 0xFFFFu) | ((uint32_t)y << 16));
             line += 2;
         }
     }
     while (line <= 572 && b.pos < b.end) {
-        int v;
+        const uint32_t win = b.window();
+        int v, used;
         if (r.count1table) {
-            v = (int)(~b.get(4)) & 15;
+            v = (int)(~(win >> 28)) & 15;
+            used = 4;
         } else {
-            const uint8_t q = quadA[b.peek(6)];
-            b.skip(q >> 4);
+            const uint8_t q = quadA[win >> 26];
+            used = q >> 4;
             v = q & 15;
         }
         int q4[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             q4[k] = (v >> (3 - k)) & 1;
-            if (q4[k] && b.get1()) q4[k] = -1;
+            if (q4[k]) {
+                if ((win << used) >> 31) q4[k] = -1;
+                ++used;
+            }
         }
+        b.skip(used);
         if (b.pos > b.end) break;  // the quadruple ran past the granule's bits: stuffing, not data
         out.put(line, ((uint32_t)q4[0] & 0xFFFFu) | ((uint32_t)q4[1] << 16));
         out.put(line + 2, ((uint32_t)q4[2] & 0xFFFFu) | ((uint32_t)q4[3] << 16));
