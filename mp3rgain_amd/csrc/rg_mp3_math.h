@@ -2,8 +2,7 @@
 //
 // The two decoders are held to bit-identical PCM (tests/test_gpu_mp3.py), so wherever the order of floating-point
 // operations is not the obvious left-to-right sum, both sides compile the same source: the 32-point DCT behind the
-// polyphase matrixing lives here.  Nothing in it can be contracted into an FMA (sums of products do not occur), so the
-// result does not depend on the compilers' contraction settings either.
+// polyphase matrixing lives here, and so does the one fused operation both sides use (rg_mp3_mac).
 #pragma once
 
 #if defined(__HIP__) || defined(__HIPCC__)
@@ -12,6 +11,11 @@
 #else
 #define RG_MP3_HD inline
 #endif
+
+// Multiply-accumulate as ONE rounding, on both sides: the dot products of the IMDCT and of the synthesis window are chains
+// of these (v_fma_f32 on the device, vfmadd on the host: rg_mp3dec.cpp is compiled with -mfma, and both with
+// -ffp-contract=off so that nothing else is fused behind the source's back).
+RG_MP3_HD float rg_mp3_mac(float a, float b, float acc) { return __builtin_fmaf(a, b, acc); }
 
 // 32-point DCT-II, unnormalised:  A[m] = sum_k x[k] cos(pi m (2k+1) / 64),  by Lee's recursive even/odd split
 //   u[k] = x[k] + x[N-1-k],  v[k] = (x[k] - x[N-1-k]) * sec_N[k],   sec_N[k] = 1 / (2 cos(pi (2k+1) / (2N)))

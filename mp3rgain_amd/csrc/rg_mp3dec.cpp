@@ -696,7 +696,7 @@ void hybrid(const float xr[576], const Granule &g, ChannelState &cs, const Table
             for (int p = 0; p < 18; ++p) {
                 const int i = p < 9 ? p : 9 + p;  // 0..8, 18..26
                 float s = 0.0f;
-                for (int k = 0; k < 18; ++k) s += X[k] * T.imdct36[i][k];
+                for (int k = 0; k < 18; ++k) s = rg_mp3_mac(X[k], T.imdct36[i][k], s);
                 if (p < 9) {
                     raw[i] = s * T.win[bt][i];
                     raw[17 - i] = -s * T.win[bt][17 - i];
@@ -710,8 +710,8 @@ void hybrid(const float xr[576], const Granule &g, ChannelState &cs, const Table
             for (int w = 0; w < 3; ++w)
                 for (int i = 0; i < 12; ++i) {
                     float s = 0.0f;
-                    for (int k = 0; k < 6; ++k) s += X[3 * k + w] * T.imdct12[i][k];
-                    raw[6 + 6 * w + i] += s * T.win[2][i];
+                    for (int k = 0; k < 6; ++k) s = rg_mp3_mac(X[3 * k + w], T.imdct12[i][k], s);
+                    raw[6 + 6 * w + i] = rg_mp3_mac(s, T.win[2][i], raw[6 + 6 * w + i]);
                 }
         }
         float *ov = cs.overlap[sb];
@@ -742,8 +742,8 @@ void synth(const float S[18][32], ChannelState &cs, const Tables &T, float *pcm 
         for (int j = 0; j < 32; ++j) {
             float s = 0.0f;
             for (int i = 0; i < 8; ++i) {
-                s += V[(o + i * 128 + j) & 1023] * T.D[i * 64 + j];
-                s += V[(o + i * 128 + 96 + j) & 1023] * T.D[i * 64 + 32 + j];
+                s = rg_mp3_mac(V[(o + i * 128 + j) & 1023], T.D[i * 64 + j], s);
+                s = rg_mp3_mac(V[(o + i * 128 + 96 + j) & 1023], T.D[i * 64 + 32 + j], s);
             }
             dst[j] = s;
         }

@@ -282,7 +282,7 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
                 const int i = p < 9 ? p : 9 + p;  // 0..8, 18..26
                 float s = 0.0f;
 #pragma unroll
-                for (int k = 0; k < 18; ++k) s += Xs[k] * T->imdct36[i][k];
+                for (int k = 0; k < 18; ++k) s = rg_mp3_mac(Xs[k], T->imdct36[i][k], s);
                 const int j = p < 9 ? 17 - i : 53 - i;  // the mirrored sample
                 const float a = s * T->win[bt][i];
                 const float b = (p < 9 ? -s : s) * T->win[bt][j];
@@ -297,8 +297,8 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
                     if (ii >= 0 && ii < 12) {
                         float s2 = 0.0f;
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) s2 += Xs[3 * k + w] * T->imdct12[ii][k];
-                        raw += s2 * T->win[2][ii];
+                        for (int k = 0; k < 6; ++k) s2 = rg_mp3_mac(Xs[3 * k + w], T->imdct12[ii][k], s2);
+                        raw = rg_mp3_mac(s2, T->win[2][ii], raw);
                     }
                 }
                 hyb[hyb_index(u0 + c, i < 18 ? 0 : 1, i < 18 ? i : i - 18, sb)] = raw;
@@ -366,8 +366,8 @@ rg_mp3_synth_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *_
         float s = 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            s += V[r - 2 * i][j] * T->D[i * 64 + j];
-            s += V[r - 2 * i - 1][32 + j] * T->D[i * 64 + 32 + j];
+            s = rg_mp3_mac(V[r - 2 * i][j], T->D[i * 64 + j], s);
+            s = rg_mp3_mac(V[r - 2 * i - 1][32 + j], T->D[i * 64 + 32 + j], s);
         }
         dst[e] = s;
     }

@@ -238,7 +238,7 @@ def test_damaged_reference_fixture_decodes_like_the_reference_would():
 
 
 def test_pcm_hashes_of_this_build():
-    """sha256 of round(pcm * 2^15) per stream; tests/golden/mp3_pcm_sha256.json (tools/make_mp3_golden.py --hashes)."""
+    """sha256 of round(pcm * 2^15) per stream; tests/golden/mp3_pcm_sha256.json: pins the decoder's own output (rewritten when its arithmetic changes on purpose, as with the fused multiply-adds of round 2; correctness is what the ffmpeg goldens above hold)."""
     want = json.loads((ROOT / "tests" / "golden" / "mp3_pcm_sha256.json").read_text())
     got = {}
     for p in STREAMS:
