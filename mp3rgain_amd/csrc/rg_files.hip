@@ -655,9 +655,9 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         if (!st.staged) RG_HIP(c, hipEventCreateWithFlags(&st.staged, hipEventDisableTiming));
     // earlier batches may still read the arena and the chunk buffers
     for (int s = 0; s < c->n_slots; ++s) RG_HIP(c, hipStreamSynchronize(c->slots[s].stream));
-    rc = rg_mp3dev_reserve_results(c, n);
-    if (rc != RG_OK) return rc;
     hipStream_t fs = c->user_attached ? c->user_stream : c->slot().stream;
+    rc = rg_mp3dev_reserve_results(c, n, fs);
+    if (rc != RG_OK) return rc;
 
     const bool trace = getenv("RG_TRACE_FILES") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1228,7 +1228,7 @@ extern "C" int rg_mp3_decode_device(rg_ctx *c, const void *data, size_t len, flo
         it.result_index = 0;
         it.d_ch0 = reinterpret_cast<float *>(c->d_arena.p);
         hipStream_t fs = c->slot().stream;
-        rc = rg_mp3dev_reserve_results(c, 1);
+        rc = rg_mp3dev_reserve_results(c, 1, fs);
         if (rc != RG_OK) return rc;
         rc = rg_mp3dev_enqueue_chunk(c, 0, st.p, total, tracks_off, st.staged, &it, 1, fs);
         if (rc != RG_OK) return rc;

@@ -782,6 +782,18 @@ bool decode_frame(Decoder &D, const uint8_t *f, const Header &h, const Tables &T
     // the frame's own main data joins the reservoir whether or not the frame can be decoded
     D.reservoir.insert(D.reservoir.end(), main, main + main_len);
     bool ok = side_ok && (size_t)si.main_data_begin <= have;
+    if (ok) {
+        // A frame decodes as a whole or not at all: a second granule whose lengths do not add up must not leave the first
+        // granule's overlap and filterbank history behind (the device routes decide per frame before they decode
+        // anything, with this same function: rg_mp3_frame.h).  The frame's own channel count is accepted here; what the
+        // callers do with a frame whose count differs from the stream's is theirs.
+        uint8_t slot[RG_MP3_SLOT_BYTES] = {0};
+        memcpy(slot, f, 4);
+        memcpy(slot + 4, side, (size_t)h.side_bytes);
+        RgMp3HuffRec recs[4];
+        uint32_t mb = 0;
+        ok = rg_mp3_frame_records(slot, have, h.channels, recs, &mb) != 0;
+    }
     const uint64_t sink_mark = D.sink ? D.sink->count : 0;  // a frame that fails half-way leaves no units behind
     if (ok) {
         const size_t begin = have - (size_t)si.main_data_begin;

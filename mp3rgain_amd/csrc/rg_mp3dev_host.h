@@ -46,6 +46,6 @@ size_t rg_mp3dev_track_bytes(size_t n_items);
 int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, size_t tracks_off, hipEvent_t staged,
                             const RgMp3StreamItem *items, size_t n, hipStream_t s);
 // granules decoded per result_index: rg_mp3dev_fetch_results enqueues the D2H on `s`; read after synchronising `s`
-int rg_mp3dev_reserve_results(rg_ctx *c, size_t n);
+int rg_mp3dev_reserve_results(rg_ctx *c, size_t n, hipStream_t s);  // zeroed on `s`, which the chunks' kernels must follow
 int rg_mp3dev_fetch_results(rg_ctx *c, size_t n, hipStream_t s);
 const uint32_t *rg_mp3dev_results(rg_ctx *c);

@@ -134,9 +134,11 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
 // ---- tuning key 6 = 3 ------------------------------------------------------------------------------------------------
 size_t rg_mp3dev_track_bytes(size_t n_items) { return n_items * sizeof(RgMp3DevTrack); }
 
-int rg_mp3dev_reserve_results(rg_ctx *c, size_t n) {
+int rg_mp3dev_reserve_results(rg_ctx *c, size_t n, hipStream_t s) {
     RG_HIP(c, c->d_mp3_results.reserve(n ? n : 1));
     RG_HIP(c, c->h_mp3_results.reserve(n ? n : 1));
+    // a stream without a single frame never reaches the frame parser: its count stays zero
+    RG_HIP(c, hipMemsetAsync(c->d_mp3_results.p, 0, (n ? n : 1) * sizeof(uint32_t), s));
     return RG_OK;
 }
 

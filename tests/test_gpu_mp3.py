@@ -404,3 +404,39 @@ def test_album_larger_than_the_device_is_analysed_in_parts(_ctx, oracle, tmp_pat
         per.append(oracle.analyze_pcm(pcm[0], pcm[1] if info.channels == 2 else None, info.sample_rate))
     want, _ = oracle.album_from_hists([h for _, h in per], [r["peak"] for r, _ in per])
     assert (parts.album_loudness_db, parts.album_gain_db, parts.album_peak) == (want["album_loudness_db"], want["album_gain_db"], want["album_peak"])
+
+
+@pytest.mark.parametrize("case", sorted((ROOT / "tests" / "golden" / "mp3_cases").glob("*.mp3")), ids=lambda p: p.stem)
+def test_a_frame_decodes_as_a_whole_or_not_at_all(_ctx, case):
+    """Regression fixtures found by tools/fuzz_mp3_routes.py: a frame whose second granule's lengths do not add up.  The
+    one-shot host decoder used to decode the first granule (moving the overlap and the filterbank history) before it
+    dropped the frame; the device routes decide per frame before decoding anything.  Every route, and the host decoder,
+    now produce the same PCM."""
+    data = case.read_bytes()
+    want, wi = mp3dec.decode(data)
+    assert wi.skipped_frames >= 1
+    for route in (3, 2, 1):
+        _ctx.set_tuning(6, route)
+        try:
+            got, gi = _ctx.decode_mp3_device(data)
+        finally:
+            _ctx.set_tuning(6, DEFAULT_ROUTE)
+        assert (gi.frames, gi.audio_frames, gi.skipped_frames) == (wi.frames, wi.audio_frames, wi.skipped_frames), route
+        assert np.array_equal(got, want), route
+
+
+def test_a_stream_without_a_whole_frame_decodes_to_nothing(_ctx):
+    """63 bytes: a header whose frame is cut short.  The host decoder returns zero frames; so must the device routes (the
+    frame parser never runs for such a stream: its count must not be whatever the buffer held before)."""
+    data = (GOLD / "v1_44k_stereo_long.mp3").read_bytes()
+    first = mp3dec.scan(data)
+    cut = data[int(first.first_frame_offset):int(first.first_frame_offset) + 63]
+    want, wi = mp3dec.decode(cut)
+    assert wi.frames == 0
+    for route in (3, 2, 1):
+        _ctx.set_tuning(6, route)
+        try:
+            got, gi = _ctx.decode_mp3_device(cut)
+        finally:
+            _ctx.set_tuning(6, DEFAULT_ROUTE)
+        assert gi.frames == 0 and got.shape[1] == 0
