@@ -38,7 +38,8 @@ typedef struct rg_mp3_stream_info {
     uint64_t frames;          /* PCM frames per channel: scan = upper bound, decode = what was produced  */
     uint32_t audio_frames;    /* Layer III frames found (scan) / decoded (decode)                        */
     uint32_t skipped_frames;  /* frames that could not be decoded and were dropped (bit reservoir underflow,
-                                 invalid side info): DecodeError -> continue, src/replaygain.rs:896-899   */
+                                 invalid side info, a channel count other than the stream's): DecodeError ->
+                                 continue, src/replaygain.rs:896-899                                       */
     uint32_t info_frame;      /* 1: a Xing / Info / VBRI header frame was found and not decoded (lib.rs:388-408 skips it too) */
     uint32_t id3v2_bytes;     /* size of the ID3v2 tag skipped at the start                              */
     uint32_t mpeg_version;    /* 1, 2, or 25 (MPEG-2.5)                                                  */
@@ -80,8 +81,7 @@ typedef struct rg_mp3_unit {
 } rg_mp3_unit;               /* 64 bytes */
 
 /* is_out: int16 [capacity_units][576]; units_out: [capacity_units].  out->frames / audio_frames / skipped_frames as
- * rg_mp3_decode_f32 reports them; *n_units = units written.  Frames whose channel count differs from the stream's
- * first frame are dropped here (the one-shot decoder spreads / truncates them). */
+ * rg_mp3_decode_f32 reports them; *n_units = units written. */
 int rg_mp3_parse_units(const void *data, size_t len, int16_t *is_out, rg_mp3_unit *units_out, uint64_t capacity_units,
                        uint64_t *n_units, rg_mp3_stream_info *out);
 

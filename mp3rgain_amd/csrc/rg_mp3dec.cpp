@@ -772,7 +772,8 @@ struct Decoder {
 };
 
 // Decodes one frame into out[ch][samples]; false = the frame is dropped (no output).
-bool decode_frame(Decoder &D, const uint8_t *f, const Header &h, const Tables &T, float *out0, float *out1) {
+// `wanted` = false: the frame only feeds the bit reservoir (its channel count is not the stream's)
+bool decode_frame(Decoder &D, const uint8_t *f, const Header &h, const Tables &T, float *out0, float *out1, bool wanted = true) {
     const uint8_t *side = f + 4 + (h.crc ? 2 : 0);
     SideInfo si;
     const bool side_ok = parse_side_info(side, h, T, &si);
@@ -781,7 +782,7 @@ bool decode_frame(Decoder &D, const uint8_t *f, const Header &h, const Tables &T
     const size_t have = D.reservoir.size();
     // the frame's own main data joins the reservoir whether or not the frame can be decoded
     D.reservoir.insert(D.reservoir.end(), main, main + main_len);
-    bool ok = side_ok && (size_t)si.main_data_begin <= have;
+    bool ok = wanted && side_ok && (size_t)si.main_data_begin <= have;
     if (ok) {
         // A frame decodes as a whole or not at all: a second granule whose lengths do not add up must not leave the first
         // granule's overlap and filterbank history behind (the device routes decide per frame before they decode
@@ -944,12 +945,14 @@ extern "C" int rg_mp3_decode_f32(const void *data, size_t len, float *ch0, float
     float tmp0[1152], tmp1[1152];
     const int rc = walk_frames((const uint8_t *)data, len, out, [&](const uint8_t *f, const Header &h) {
         if (!stream_channels) stream_channels = h.channels;
-        if (!decode_frame(*D, f, h, T, tmp0, tmp1)) { ++skipped; return; }
+        // a frame whose channel count differs from the stream's is dropped (every route does; the reference reads plane 1 of
+        // whatever its decoder returns and would not survive a mono frame in a stereo stream); its bytes still feed the
+        // reservoir
+        if (!decode_frame(*D, f, h, T, tmp0, tmp1, h.channels == stream_channels)) { ++skipped; return; }
         ++decoded;
         if (produced + (uint64_t)h.samples > capacity) { overflow = true; produced += (uint64_t)h.samples; return; }
         memcpy(ch0 + produced, tmp0, sizeof(float) * (size_t)h.samples);
-        // a frame whose channel count differs from the stream's: mono spreads to both channels, stereo keeps its first
-        if (stream_channels == 2 && ch1) memcpy(ch1 + produced, h.channels == 2 ? tmp1 : tmp0, sizeof(float) * (size_t)h.samples);
+        if (stream_channels == 2 && ch1) memcpy(ch1 + produced, tmp1, sizeof(float) * (size_t)h.samples);
         produced += (uint64_t)h.samples;
     });
     delete D;
@@ -975,7 +978,7 @@ extern "C" int rg_mp3_parse_units(const void *data, size_t len, int16_t *is_out,
     int stream_channels = 0;
     const int rc = walk_frames((const uint8_t *)data, len, out, [&](const uint8_t *f, const Header &h) {
         if (!stream_channels) stream_channels = h.channels;
-        if (h.channels != stream_channels || !decode_frame(*D, f, h, T, nullptr, nullptr)) { ++skipped; return; }
+        if (!decode_frame(*D, f, h, T, nullptr, nullptr, h.channels == stream_channels)) { ++skipped; return; }
         ++decoded;
         produced += (uint64_t)h.samples;
     });
