@@ -335,19 +335,40 @@ rg_mp3_synth_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *_
     const int ng = (int)(tr.n_granules - g0 < (uint32_t)R ? tr.n_granules - g0 : (uint32_t)R);
     const int nslots = 15 + 18 * ng;
     // ---- overlap-add + frequency inversion (rg_mp3dec.cpp: hybrid, tail) -----------------------------------------
-    for (int e = tid; e < nslots * 32; e += 256) {
-        const int r = e / 32, sb = e % 32;
-        const int rel = r - 15;                        // time slot relative to granule g0
-        const long long gg = (long long)g0 + (rel >= 0 ? rel / 18 : -1);
-        const int t = rel >= 0 ? rel % 18 : 18 + rel;
-        float v = 0.0f;
-        if (gg >= 0) {
-            const uint64_t unit = tr.unit_base + (uint64_t)gg * nch + c;
-            const float ov = gg >= 1 ? hyb[hyb_index(unit - nch, 1, t, sb)] : 0.0f;
-            v = hyb[hyb_index(unit, 0, t, sb)] + ov;
+    // The loop is unrolled so that all of a thread's loads (two per subband sample, sixteen samples) are in flight
+    // together: rolled, every iteration waited for its own pair, and those sixteen round trips to memory were most of the
+    // block's lifetime.
+    constexpr int kLoads = (SLOTS * 32 + 255) / 256;
+    float first[kLoads], ovl[kLoads];
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+        const int e = tid + 256 * k;
+        first[k] = 0.0f;
+        ovl[k] = 0.0f;
+        if (e < nslots * 32) {
+            const int r = e / 32, sb = e % 32;
+            const int rel = r - 15;                        // time slot relative to granule g0
+            const long long gg = (long long)g0 + (rel >= 0 ? rel / 18 : -1);
+            const int t = rel >= 0 ? rel % 18 : 18 + rel;
+            if (gg >= 0) {
+                const uint64_t unit = tr.unit_base + (uint64_t)gg * nch + c;
+                first[k] = hyb[hyb_index(unit, 0, t, sb)];
+                if (gg >= 1) ovl[k] = hyb[hyb_index(unit - nch, 1, t, sb)];
+            }
         }
-        if ((sb & 1) && (t & 1)) v = -v;
-        S[r][sb] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+        const int e = tid + 256 * k;
+        if (e < nslots * 32) {
+            const int r = e / 32, sb = e % 32;
+            const int rel = r - 15;
+            const int t = rel >= 0 ? rel % 18 : 18 + rel;
+            float v = first[k] + ovl[k];  // a granule without a predecessor (and the slots before the track) add 0.0f, as the host does
+            if (rel < 0 && (long long)g0 - 1 < 0) v = 0.0f;
+            if ((sb & 1) && (t & 1)) v = -v;
+            S[r][sb] = v;
+        }
     }
     __syncthreads();
     // ---- polyphase synthesis: matrixing, one time slot per thread (rg_mp3dec.cpp: synth) ---------------------------
