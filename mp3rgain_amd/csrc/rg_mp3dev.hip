@@ -96,6 +96,18 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
     const uint64_t u0 = tr.unit_base + (uint64_t)g * nch;
     if (tid < nch) U[tid] = units[u0 + tid];
     if (tid < 64) { band_nz[tid] = 0; band_mode[tid] = 0; }
+    // The quantised spectrum is fetched here, eight lines (16 bytes) per thread, with the long-block band numbers of those
+    // lines: neither depends on the units, so they travel while the units arrive and the gains are worked out.  (Fetched
+    // line by line inside the requantisation loop, each value and the table entry it selects were two round trips to memory
+    // per line, one after the other: most of a block's lifetime.)
+    const bool rq = tid < nch * 72;
+    const int rq_c = tid / 72, rq_l0 = (tid % 72) * 8;
+    uint4 rq_raw = make_uint4(0u, 0u, 0u, 0u);
+    uint2 rq_lb = make_uint2(0u, 0u);
+    if (rq) {
+        rq_raw = *reinterpret_cast<const uint4 *>(is + (u0 + rq_c) * 576 + rq_l0);
+        rq_lb = *reinterpret_cast<const uint2 *>(&T->long_band_of_line[rr][rq_l0]);
+    }
     __syncthreads();
 
     // ---- stage B: requantisation (rg_mp3dec.cpp: requantize) -----------------------------------------------------
@@ -122,23 +134,32 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
         }
     }
     __syncthreads();
-    for (int c = 0; c < nch; ++c) {
-        const rg_mp3_unit &u = U[c];
+    if (rq) {
+        const rg_mp3_unit &u = U[rq_c];
         const int long_lines = (int)T->sfb_long[rr][u.long_end];  // 0 when long_end == 0
         const int short_off = 3 * (int)T->sfb_short[rr][u.short_start < 13 ? u.short_start : 13];
-        const int16_t *__restrict__ src = is + (u0 + c) * 576;
-        for (int line = tid; line < 576; line += 256) {
-            float gv;
+        const uint32_t w[4] = {rq_raw.x, rq_raw.y, rq_raw.z, rq_raw.w};
+        float gv[8];
+        int a[8], v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int line = rq_l0 + j;
             if (u.block_type != 2 || line < long_lines) {
-                gv = gain_long[c][T->long_band_of_line[rr][line]];
+                gv[j] = gain_long[rq_c][((j < 4 ? rq_lb.x : rq_lb.y) >> (8 * (j & 3))) & 0xFFu];
             } else {
                 const int k = (int)T->short_idx_of_line[rr][line - long_lines + short_off] - 3 * (int)u.short_start;
-                gv = gain_short[c][k];
+                gv[j] = gain_short[rq_c][k];
             }
-            const int v = src[line];
-            const int a = v < 0 ? -v : v;
-            const float m = T->pow43[a] * gv;
-            xr[c][line] = v < 0 ? -m : m;
+            v[j] = (int)(int16_t)(w[j >> 1] >> (16 * (j & 1)));
+            a[j] = v[j] < 0 ? -v[j] : v[j];
+        }
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = T->pow43[a[j]];  // eight independent look-ups, in flight together
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = m[j] * gv[j];
+            xr[rq_c][rq_l0 + j] = v[j] < 0 ? -t : t;
         }
     }
     __syncthreads();
