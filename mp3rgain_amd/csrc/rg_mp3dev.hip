@@ -86,6 +86,11 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
     __shared__ float gain_long[2][22], gain_short[2][39];
     __shared__ int band_nz[64];
     __shared__ short band_mode[64];
+    // the constants the block's loops read, copied once: a look-up in LDS returns in a tenth of the time of one in memory,
+    // and the loops below are chains of look-up -> arithmetic -> next look-up
+    __shared__ float c36[36][18], c12[12][6], wn[4][36], cs_l[8], ca_l[8];
+    __shared__ float gtab[RG_MP3_GAIN_Q_MAX - RG_MP3_GAIN_Q_MIN + 1];
+    __shared__ uint8_t ptab[24];
     const int tid = threadIdx.x;
     const uint32_t ti = find_by_granule(tracks, n_tracks, blockIdx.x);
     const RgMp3DevTrack tr = tracks[ti];
@@ -108,6 +113,12 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
         rq_raw = *reinterpret_cast<const uint4 *>(is + (u0 + rq_c) * 576 + rq_l0);
         rq_lb = *reinterpret_cast<const uint2 *>(&T->long_band_of_line[rr][rq_l0]);
     }
+    for (int e = tid; e < 36 * 18; e += 256) (&c36[0][0])[e] = (&T->imdct36[0][0])[e];
+    for (int e = tid; e < RG_MP3_GAIN_Q_MAX - RG_MP3_GAIN_Q_MIN + 1; e += 256) gtab[e] = T->gain[e];
+    if (tid < 144) (&wn[0][0])[tid] = (&T->win[0][0])[tid];
+    if (tid < 72) (&c12[0][0])[tid] = (&T->imdct12[0][0])[tid];
+    if (tid < 8) { cs_l[tid] = T->cs[tid]; ca_l[tid] = T->ca[tid]; }
+    if (tid < 24) ptab[tid] = T->pretab[tid];
     __syncthreads();
 
     // ---- stage B: requantisation (rg_mp3dec.cpp: requantize) -----------------------------------------------------
@@ -118,8 +129,8 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
         const int m4 = u.scalefac_scale ? 4 : 2;  // 4 * mult
         const int base4 = (int)u.global_gain - 210;
         if (tid < 22) {
-            const int q = base4 - m4 * ((int)u.sf[tid] + (u.preflag ? (int)T->pretab[tid] : 0));
-            gain_long[c][tid] = T->gain[q - RG_MP3_GAIN_Q_MIN];
+            const int q = base4 - m4 * ((int)u.sf[tid] + (u.preflag ? (int)ptab[tid] : 0));
+            gain_long[c][tid] = gtab[q - RG_MP3_GAIN_Q_MIN];
         }
         if (tid >= 64 && tid < 64 + 39) {
             const int k = tid - 64;  // (band - short_start) * 3 + window
@@ -128,7 +139,7 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
             if (band < 13) {
                 const int s = band < 12 ? (int)u.sf[(int)u.long_end + k] : 0;
                 const int q = base4 - 8 * (int)u.subblock_gain[w] - m4 * s;
-                gv = T->gain[q - RG_MP3_GAIN_Q_MIN];
+                gv = gtab[q - RG_MP3_GAIN_Q_MIN];
             }
             gain_short[c][k] = gv;
         }
@@ -285,8 +296,8 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
         if (tid < boundaries * 8) {
             const int sb = 1 + tid / 8, i = tid % 8;
             const float a = X[sb * 18 - 1 - i], b = X[sb * 18 + i];
-            X[sb * 18 - 1 - i] = a * T->cs[i] - b * T->ca[i];
-            X[sb * 18 + i] = b * T->cs[i] + a * T->ca[i];
+            X[sb * 18 - 1 - i] = a * cs_l[i] - b * ca_l[i];
+            X[sb * 18 + i] = b * cs_l[i] + a * ca_l[i];
         }
         __syncthreads();
         // long blocks: x[17 - i] = -x[i], x[35 - j] = x[18 + j] -- eighteen dot products per subband give all 36 samples
@@ -303,10 +314,10 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
                 const int i = p < 9 ? p : 9 + p;  // 0..8, 18..26
                 float s = 0.0f;
 #pragma unroll
-                for (int k = 0; k < 18; ++k) s = rg_mp3_mac(Xs[k], T->imdct36[i][k], s);
+                for (int k = 0; k < 18; ++k) s = rg_mp3_mac(Xs[k], c36[i][k], s);
                 const int j = p < 9 ? 17 - i : 53 - i;  // the mirrored sample
-                const float a = s * T->win[bt][i];
-                const float b = (p < 9 ? -s : s) * T->win[bt][j];
+                const float a = s * wn[bt][i];
+                const float b = (p < 9 ? -s : s) * wn[bt][j];
                 hyb[hyb_index(u0 + c, i < 18 ? 0 : 1, i < 18 ? i : i - 18, sb)] = a;
                 hyb[hyb_index(u0 + c, j < 18 ? 0 : 1, j < 18 ? j : j - 18, sb)] = b;
             } else {
@@ -318,8 +329,8 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
                     if (ii >= 0 && ii < 12) {
                         float s2 = 0.0f;
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) s2 = rg_mp3_mac(Xs[3 * k + w], T->imdct12[ii][k], s2);
-                        raw = rg_mp3_mac(s2, T->win[2][ii], raw);
+                        for (int k = 0; k < 6; ++k) s2 = rg_mp3_mac(Xs[3 * k + w], c12[ii][k], s2);
+                        raw = rg_mp3_mac(s2, wn[2][ii], raw);
                     }
                 }
                 hyb[hyb_index(u0 + c, i < 18 ? 0 : 1, i < 18 ? i : i - 18, sb)] = raw;
