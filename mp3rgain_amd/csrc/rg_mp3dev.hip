@@ -367,6 +367,12 @@ rg_mp3_synth_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *_
     const int ng = (int)(tr.n_granules - g0 < (uint32_t)R ? tr.n_granules - g0 : (uint32_t)R);
     const int nslots = 15 + 18 * ng;
     // ---- overlap-add + frequency inversion (rg_mp3dec.cpp: hybrid, tail) -----------------------------------------
+    // the window's sixteen coefficients for this thread's sample index (e % 32 == tid % 32 for every e it takes), fetched
+    // with everything else the block reads from memory
+    const int wj = tid & 31;
+    float Dw[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { Dw[2 * i] = T->D[i * 64 + wj]; Dw[2 * i + 1] = T->D[i * 64 + 32 + wj]; }
     // The loop is unrolled so that all of a thread's loads (two per subband sample, sixteen samples) are in flight
     // together: rolled, every iteration waited for its own pair, and those sixteen round trips to memory were most of the
     // block's lifetime.
@@ -414,13 +420,13 @@ rg_mp3_synth_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *_
     __syncthreads();
     float *__restrict__ dst = (c == 0 ? tr.ch0 : tr.ch1) + (size_t)g0 * 576;
     for (int e = tid; e < ng * 576; e += 256) {
-        const int slot = e / 32, j = e % 32;   // slot = 18 * granule + t
+        const int slot = e / 32;   // slot = 18 * granule + t; the sample within the slot is this thread's wj
         const int r = 15 + slot;
         float s = 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            s = rg_mp3_mac(V[r - 2 * i][j], T->D[i * 64 + j], s);
-            s = rg_mp3_mac(V[r - 2 * i - 1][32 + j], T->D[i * 64 + 32 + j], s);
+            s = rg_mp3_mac(V[r - 2 * i][wj], Dw[2 * i], s);
+            s = rg_mp3_mac(V[r - 2 * i - 1][32 + wj], Dw[2 * i + 1], s);
         }
         dst[e] = s;
     }
