@@ -585,8 +585,8 @@ Mp3Pipe &mp3_pipe(rg_ctx *c) {
     return *static_cast<Mp3Pipe *>(c->mp3_pipe);
 }
 
-constexpr uint64_t kPipeChunkUnits = 1ull << 18;      // granule-channels per chunk: enough blocks for every CU several times over
-constexpr size_t kPipeStageBytes = (size_t)96 << 20;  // staging block (a 3-minute 320 kb/s file is 7.2 MB)
+constexpr uint64_t kPipeChunkUnits = 393216;          // granule-channels per chunk = the threads the Huffman kernel can have resident (256 CUs x 4 SIMDs x 6 waves x 64): one full wave of them
+constexpr size_t kPipeStageBytes = (size_t)128 << 20;  // staging block (a 3-minute 320 kb/s file is 7.2 MB and 27 600 granule-channels)
 
 struct PipeChunk {
     int stage = 0;
