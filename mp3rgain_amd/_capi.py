@@ -158,7 +158,12 @@ def load():
         import importlib.util
         import sys
 
-        if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        # A process that will never import torch (the command line, `python -m mp3rgain_amd`) says so with
+        # MP3RGAIN_AMD_STANDALONE=1 and saves the 1.5 s that import costs: the library then runs on the system's HIP runtime.
+        import os
+
+        standalone = os.environ.get("MP3RGAIN_AMD_STANDALONE") == "1"
+        if not standalone and "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
             import torch  # noqa: F401
         L = C.CDLL(str(LIB_PATH))
         for name, res, args in SYMBOLS:
