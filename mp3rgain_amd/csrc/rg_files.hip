@@ -799,6 +799,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         R.cv.notify_all();
     };
     auto work = [&](unsigned w) {
+        (void)hipSetDevice(device);  // the staging blocks a loader allocates or waits for belong to this context's GPU
         for (size_t i = next_file.fetch_add(1); i < n; i = next_file.fetch_add(1)) {
             load_file(i, P.scratch[w]);
             {
