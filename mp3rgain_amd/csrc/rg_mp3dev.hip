@@ -88,8 +88,9 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
     __shared__ short band_mode[64];
     // the constants the block's loops read, copied once: a look-up in LDS returns in a tenth of the time of one in memory,
     // and the loops below are chains of look-up -> arithmetic -> next look-up
-    __shared__ float c36[36][18], c12[12][6], wn[4][36], cs_l[8], ca_l[8];
-    __shared__ float gtab[RG_MP3_GAIN_Q_MAX - RG_MP3_GAIN_Q_MIN + 1];
+    // (the 18 rows of the long IMDCT that are used -- samples 0..8 and 18..26 -- in rows of 20 words: 16-byte reads)
+    __shared__ __attribute__((aligned(16))) float c36[18][20];
+    __shared__ float c12[12][6], wn[4][36], cs_l[8], ca_l[8];
     __shared__ uint8_t ptab[24];
     const int tid = threadIdx.x;
     const uint32_t ti = find_by_granule(tracks, n_tracks, blockIdx.x);
@@ -113,8 +114,7 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
         rq_raw = *reinterpret_cast<const uint4 *>(is + (u0 + rq_c) * 576 + rq_l0);
         rq_lb = *reinterpret_cast<const uint2 *>(&T->long_band_of_line[rr][rq_l0]);
     }
-    for (int e = tid; e < 36 * 18; e += 256) (&c36[0][0])[e] = (&T->imdct36[0][0])[e];
-    for (int e = tid; e < RG_MP3_GAIN_Q_MAX - RG_MP3_GAIN_Q_MIN + 1; e += 256) gtab[e] = T->gain[e];
+    for (int e = tid; e < 18 * 18; e += 256) c36[e / 18][e % 18] = T->imdct36[e / 18 < 9 ? e / 18 : e / 18 + 9][e % 18];
     if (tid < 144) (&wn[0][0])[tid] = (&T->win[0][0])[tid];
     if (tid < 72) (&c12[0][0])[tid] = (&T->imdct12[0][0])[tid];
     if (tid < 8) { cs_l[tid] = T->cs[tid]; ca_l[tid] = T->ca[tid]; }
@@ -130,7 +130,7 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
         const int base4 = (int)u.global_gain - 210;
         if (tid < 22) {
             const int q = base4 - m4 * ((int)u.sf[tid] + (u.preflag ? (int)ptab[tid] : 0));
-            gain_long[c][tid] = gtab[q - RG_MP3_GAIN_Q_MIN];
+            gain_long[c][tid] = T->gain[q - RG_MP3_GAIN_Q_MIN];
         }
         if (tid >= 64 && tid < 64 + 39) {
             const int k = tid - 64;  // (band - short_start) * 3 + window
@@ -139,7 +139,7 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
             if (band < 13) {
                 const int s = band < 12 ? (int)u.sf[(int)u.long_end + k] : 0;
                 const int q = base4 - 8 * (int)u.subblock_gain[w] - m4 * s;
-                gv = gtab[q - RG_MP3_GAIN_Q_MIN];
+                gv = T->gain[q - RG_MP3_GAIN_Q_MIN];
             }
             gain_short[c][k] = gv;
         }
@@ -304,17 +304,31 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
         // (the host computes exactly these eighteen); short blocks: each of the 36 samples on its own
         // consecutive threads take consecutive subbands of one sample index: the table row is a broadcast, the stores
         // to hyb[unit][half][t][sb] are whole 128-byte lines
+        // a thread's subband is the same in every turn of the loop (256 is a multiple of 32): its eighteen lines stay in
+        // registers, and a row of coefficients comes in five 16-byte reads -- per dot product 5 LDS reads instead of 36
+        float xs[18];
+        {
+            const float *Xr = X + (tid & 31) * 18;
+#pragma unroll
+            for (int k = 0; k < 18; ++k) xs[k] = Xr[k];
+        }
         for (int o = tid; o < 32 * 36; o += 256) {
             const int sb = o & 31, i36 = o >> 5;
-            const float *Xs = X + sb * 18;
+            const float *Xs = xs;
             const int bt = (u.block_type == 2 && u.mixed && sb < 2) ? 0 : (int)u.block_type;
             if (bt != 2) {
                 if (i36 >= 18) continue;  // eighteen workers per subband
                 const int p = i36;
                 const int i = p < 9 ? p : 9 + p;  // 0..8, 18..26
+                float cf[20];
+#pragma unroll
+                for (int k = 0; k < 20; k += 4) {
+                    const float4 q4 = *reinterpret_cast<const float4 *>(&c36[p][k]);
+                    cf[k] = q4.x; cf[k + 1] = q4.y; cf[k + 2] = q4.z; cf[k + 3] = q4.w;
+                }
                 float s = 0.0f;
 #pragma unroll
-                for (int k = 0; k < 18; ++k) s = rg_mp3_mac(Xs[k], c36[i][k], s);
+                for (int k = 0; k < 18; ++k) s = rg_mp3_mac(Xs[k], cf[k], s);
                 const int j = p < 9 ? 17 - i : 53 - i;  // the mirrored sample
                 const float a = s * wn[bt][i];
                 const float b = (p < 9 ? -s : s) * wn[bt][j];
