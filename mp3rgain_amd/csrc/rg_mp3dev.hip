@@ -662,46 +662,50 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
     // ---- Huffman-coded spectrum ----
     RowOut out{reinterpret_cast<uint4 *>(is + u * 576), 0u, 0u, 0u};
     int line = 0;
-#pragma unroll 1
-    for (int reg = 0; reg < 3; ++reg) {
-        int end = reg == 0 ? r0e : (reg == 1 ? r1e : bv2);
-        if (end > bv2) end = bv2;
-        const int t = r.table_select[reg];
-        const int P = t_pbits[t];
-        if (P == 0) {
-            for (; line < end; line += 2) out.put(line, 0u);
-            continue;
-        }
-        const uint32_t *__restrict__ E = E_all + t_base[t];
-        const int linbits = t_linbits[t];
-        while (line < end) {
-            if (b.pos >= b.end) { for (; line < end; line += 2) out.put(line, 0u); break; }
-            // code, escapes and signs come out of one 32-bit window whenever they fit (a code is at most 19 bits long)
-            const uint32_t win = b.window();
-            uint32_t e = E[win >> (32 - P)];
-            int used = 0;
-            if (e & 0x80000000u) {
-                e = E[((e >> 8) & 0x7FFFFF) + ((win << P) >> (32 - (int)(e & 0xFF)))];
-                used = P;
-            }
-            used += (int)(e & 0xFF);
-            int x = (int)((e >> 12) & 15), y = (int)((e >> 8) & 15);
-            if (linbits == 0 || (x != 15 && y != 15)) {
-                if (x) { if ((win << used) >> 31) x = -x; ++used; }
-                if (y) { if ((win << used) >> 31) y = -y; ++used; }
-                b.skip(used);
-            } else {
-                b.skip(used);
-                if (x) {
-                    if (x == 15) x += (int)b.get(linbits);
-                    if (b.get1()) x = -x;
+    // One loop over the big_values pairs of all three regions: which table a pair uses is a per-lane choice made with
+    // selects, so the lanes of a wave -- which sit in different regions of different granules -- run the same instructions
+    // instead of taking turns through three region loops.
+    {
+        const int e0 = r0e < bv2 ? r0e : bv2, e1 = r1e < bv2 ? r1e : bv2;
+        const int t0 = r.table_select[0], t1 = r.table_select[1], t2 = r.table_select[2];
+        const uint32_t tb0 = t_base[t0], tb1 = t_base[t1], tb2 = t_base[t2];
+        const int P0 = t_pbits[t0], P1 = t_pbits[t1], P2 = t_pbits[t2];
+        const int lb0 = t_linbits[t0], lb1 = t_linbits[t1], lb2 = t_linbits[t2];
+        while (line < bv2) {
+            const bool in0 = line < e0, in1 = line < e1;
+            const int P = in0 ? P0 : (in1 ? P1 : P2);
+            uint32_t word = 0u;
+            if (P != 0 && b.pos < b.end) {  // table 0 codes nothing; a granule whose bits have run out is zeros from here on
+                const uint32_t *__restrict__ E = E_all + (in0 ? tb0 : (in1 ? tb1 : tb2));
+                const int linbits = in0 ? lb0 : (in1 ? lb1 : lb2);
+                // code, escapes and signs come out of one 32-bit window whenever they fit (a code is at most 19 bits long)
+                const uint32_t win = b.window();
+                uint32_t e = E[win >> (32 - P)];
+                int used = 0;
+                if (e & 0x80000000u) {
+                    e = E[((e >> 8) & 0x7FFFFF) + ((win << P) >> (32 - (int)(e & 0xFF)))];
+                    used = P;
                 }
-                if (y) {
-                    if (y == 15) y += (int)b.get(linbits);
-                    if (b.get1()) y = -y;
+                used += (int)(e & 0xFF);
+                int x = (int)((e >> 12) & 15), y = (int)((e >> 8) & 15);
+                if (linbits == 0 || (x != 15 && y != 15)) {
+                    if (x) { if ((win << used) >> 31) x = -x; ++used; }
+                    if (y) { if ((win << used) >> 31) y = -y; ++used; }
+                    b.skip(used);
+                } else {
+                    b.skip(used);
+                    if (x) {
+                        if (x == 15) x += (int)b.get(linbits);
+                        if (b.get1()) x = -x;
+                    }
+                    if (y) {
+                        if (y == 15) y += (int)b.get(linbits);
+                        if (b.get1()) y = -y;
+                    }
                 }
+                word = ((uint32_t)x & 0xFFFFu) | ((uint32_t)y << 16);
             }
-            out.put(line, ((uint32_t)x & 0xFFFFu) | ((uint32_t)y << 16));
+            out.put(line, word);
             line += 2;
         }
     }
