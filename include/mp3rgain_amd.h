@@ -183,7 +183,7 @@ int rg_set_kernel(rg_ctx *ctx, int variant);
  * and the polyphase filterbank run on the GPU, file reads, copies and decode overlap chunk by chunk, and the PCM is
  * written straight into the analysis arena; 2 = the host parses the side information too; 1 = scalefactors + Huffman on
  * the host's cores, the rest on the GPU; 0 = the host decoder.  (An album of 64 three-minute 320 kb/s files:
- * 0.96 s / 0.25 s / 0.04 s / 0.019 s for 0 / 1 / 2 / 3.) */
+ * 0.96 s / 0.25 s / 0.04 s / 0.017 s for 0 / 1 / 2 / 3.) */
 int rg_set_tuning(rg_ctx *ctx, int key, int64_t value);
 /* diagnostic (host only): variant 2's design for one rate and segment length.  T_out: [L][12],
  * gram_last_out: [78]; either may be NULL.  RG_ERR_INVALID_ARG when no design exists. */
