@@ -390,36 +390,38 @@ rg_mp3_synth_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *_
     // The loop is unrolled so that all of a thread's loads (two per subband sample, sixteen samples) are in flight
     // together: rolled, every iteration waited for its own pair, and those sixteen round trips to memory were most of the
     // block's lifetime.
-    constexpr int kLoads = (SLOTS * 32 + 255) / 256;
-    float first[kLoads], ovl[kLoads];
+    // ... and in 16-byte pieces: four adjacent subbands of one time slot per load.
+    constexpr int kLoads = (SLOTS * 8 + 255) / 256;
+    float4 first[kLoads], ovl[kLoads];
 #pragma unroll
     for (int k = 0; k < kLoads; ++k) {
         const int e = tid + 256 * k;
-        first[k] = 0.0f;
-        ovl[k] = 0.0f;
-        if (e < nslots * 32) {
-            const int r = e / 32, sb = e % 32;
+        first[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        ovl[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (e < nslots * 8) {
+            const int r = e / 8, sb = (e % 8) * 4;
             const int rel = r - 15;                        // time slot relative to granule g0
             const long long gg = (long long)g0 + (rel >= 0 ? rel / 18 : -1);
             const int t = rel >= 0 ? rel % 18 : 18 + rel;
             if (gg >= 0) {
                 const uint64_t unit = tr.unit_base + (uint64_t)gg * nch + c;
-                first[k] = hyb[hyb_index(unit, 0, t, sb)];
-                if (gg >= 1) ovl[k] = hyb[hyb_index(unit - nch, 1, t, sb)];
+                first[k] = *reinterpret_cast<const float4 *>(&hyb[hyb_index(unit, 0, t, sb)]);
+                if (gg >= 1) ovl[k] = *reinterpret_cast<const float4 *>(&hyb[hyb_index(unit - nch, 1, t, sb)]);
             }
         }
     }
 #pragma unroll
     for (int k = 0; k < kLoads; ++k) {
         const int e = tid + 256 * k;
-        if (e < nslots * 32) {
-            const int r = e / 32, sb = e % 32;
+        if (e < nslots * 8) {
+            const int r = e / 8, sb = (e % 8) * 4;
             const int rel = r - 15;
             const int t = rel >= 0 ? rel % 18 : 18 + rel;
-            float v = first[k] + ovl[k];  // a granule without a predecessor (and the slots before the track) add 0.0f, as the host does
-            if (rel < 0 && (long long)g0 - 1 < 0) v = 0.0f;
-            if ((sb & 1) && (t & 1)) v = -v;
-            S[r][sb] = v;
+            // a granule without a predecessor (and the slots before the track) add 0.0f, as the host does
+            float v[4] = {first[k].x + ovl[k].x, first[k].y + ovl[k].y, first[k].z + ovl[k].z, first[k].w + ovl[k].w};
+            if (t & 1) { v[1] = -v[1]; v[3] = -v[3]; }  // frequency inversion: odd subbands of odd time slots
+#pragma unroll
+            for (int q = 0; q < 4; ++q) S[r][sb + q] = v[q];
         }
     }
     __syncthreads();
