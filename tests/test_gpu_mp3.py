@@ -15,6 +15,9 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from mp3rgain_amd import mp3dec  # noqa: E402
 
+sys.path.insert(0, str(ROOT / "tests"))
+import mp3gold  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 GOLD = ROOT / "tests" / "golden" / "mp3"
 FIX = ROOT / "tests" / "golden" / "fixtures"
@@ -45,6 +48,33 @@ def test_device_half_reproduces_the_host_decoder(_ctx, path, split_mode):
         d = np.abs(got.astype(np.float64) - want.astype(np.float64))
         bad = np.argwhere(d > 0)
         raise AssertionError(f"{len(bad)} of {got.size} samples differ, max {d.max():.3g} (peak {np.abs(want).max():.3g}), first at {bad[0]}")
+
+
+@pytest.mark.parametrize("path", mp3gold.STREAMS, ids=lambda p: p.stem)
+def test_device_pcm_matches_ffmpeg(_ctx, oracle, path, split_mode, tmp_path):
+    """The pin on the HIP decode path itself, not through the host decoder: PCM decoded on the device (every route)
+    against ffmpeg's decode of the same stream (tests/golden/mp3/*.ffmpeg.np[yz]), max |delta| <= 1.5 and RMS <= 0.6
+    steps of 2^-15 -- on the reference's fixtures, the sixteen syntax-walking streams and the dense music-like encodes
+    (tools/make_mp3_dense.py).  Then the file-level entry point on the same file, packet semantics of
+    src/replaygain.rs:881-904 (nothing trimmed): loudness within 0.1 dB of the oracle's on ffmpeg's PCM -- where ffmpeg
+    trimmed the encoder delay by the Info header, its samples are laid over this decoder's at their place."""
+    data = path.read_bytes()
+    gold = mp3gold.load_gold(path)
+    got, gi = _ctx.decode_mp3_device(data)
+    assert gold.shape[0] == gi.channels == got.shape[0] and gi.skipped_frames == 0
+    mx, rms, off, n = mp3gold.compare_with_gold(got, gi.info_frame, gold)
+    assert mx <= mp3gold.MAX_STEPS, f"max |delta| {mx:.2f} steps of 2^-15"
+    assert rms <= mp3gold.RMS_STEPS, f"rms {rms:.3f}"
+    f = tmp_path / path.name
+    f.write_bytes(data)
+    _ctx.set_kernel(0)
+    res = _ctx.analyze_track_file(f)
+    ref = got.copy()
+    ref[:, off:off + n] = (gold[:, :n].astype(np.float64) / 32768.0).astype(np.float32)
+    want, _ = oracle.analyze_pcm(ref[0], ref[1] if ref.shape[0] == 2 else None, gi.sample_rate)
+    assert abs(res.loudness_db - want["loudness_db"]) <= 0.1, (res.loudness_db, want["loudness_db"])
+    assert abs(res.peak - want["peak"]) <= 2.0 / 32768.0
+    assert res.sample_rate == gi.sample_rate
 
 
 def test_dropped_and_damaged_frames_behave_like_the_host_decoder(_ctx, split_mode):

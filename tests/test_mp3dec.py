@@ -33,27 +33,47 @@ sys.path.insert(0, str(ROOT / "oracle"))
 
 from mp3rgain_amd import mp3dec  # noqa: E402
 
-GOLD = ROOT / "tests" / "golden" / "mp3"
-FIX = ROOT / "tests" / "golden" / "fixtures"
-STREAMS = sorted(GOLD.glob("*.mp3")) + [FIX / n for n in ("test_joint_stereo.mp3", "test_mono.mp3", "test_vbr.mp3")]
-LAME_DELAY = 576 + 528 + 1  # encoder delay + decoder delay, what a gapless-aware decoder cuts from the front
+sys.path.insert(0, str(ROOT / "tests"))
+from mp3gold import FIX, GOLD, LAME_DELAY, MAX_STEPS, RMS_STEPS, STREAMS, compare_with_gold, load_gold  # noqa: E402
 
 
 @pytest.mark.parametrize("path", STREAMS, ids=lambda p: p.stem)
 def test_pcm_matches_ffmpeg(path):
     data = path.read_bytes()
     pcm, info = mp3dec.decode(data)
-    gold = np.load(GOLD / (path.stem + ".ffmpeg.npy")).astype(np.float64)
+    gold = load_gold(path)
     assert gold.shape[0] == info.channels == pcm.shape[0]
-    # the golden decoder trims by the Xing/LAME header when there is one; this decoder, like the reference, never trims
-    off = LAME_DELAY if info.info_frame else 0
-    n = min(gold.shape[1], pcm.shape[1] - off)
-    assert n >= gold.shape[1] - 1152 and n > 4000
-    d = pcm[:, off:off + n].astype(np.float64) * 32768.0 - gold[:, :n]
-    assert np.abs(d).max() <= 1.5, f"max |delta| {np.abs(d).max():.2f} steps of 2^-15"
-    assert np.sqrt((d ** 2).mean()) <= 0.6
+    mx, rms, _, _ = compare_with_gold(pcm, info.info_frame, gold)
+    assert mx <= MAX_STEPS, f"max |delta| {mx:.2f} steps of 2^-15"
+    assert rms <= RMS_STEPS
     assert info.skipped_frames == 0
     assert np.abs(gold).max() > 150, "the case must carry signal well above the comparison floor"
+
+
+def test_dense_streams_are_what_the_encoder_makes_and_decode_to_the_music():
+    """tests/golden/mp3/dense_*.mp3 (tools/make_mp3_dense.py): tens of seconds of synthetic music through a real encoder
+    chain (oracle/mp3_encoder.py).  The shortest is re-encoded here and must be the committed bytes; every one decodes to
+    the piece it was made from (SNR >= 20 dB at the chain's delay -- there is no psychoacoustic model), uses window
+    switching at its attacks, and the joint-stereo one switches mid/side per frame."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import make_mp3_dense as M
+    import mp3_encoder as E
+
+    for name, rate, nch, secs, br, seed, ms in M.CASES:
+        data = (GOLD / f"{name}.mp3").read_bytes()
+        pcm = M.piece(rate, secs, nch, seed)
+        if name == "dense_22k_mono_56":
+            assert E.encode(pcm, rate, br, seed=seed, allow_ms=ms) == data, "the committed stream is not the generator's output"
+        dec, info = mp3dec.decode(data)
+        assert info.skipped_frames == 0 and info.frames / rate > secs
+        d = 1057  # analysis + synthesis filterbank (481) and one granule of MDCT overlap (576)
+        m = min(dec.shape[1] - d, pcm.shape[1])
+        err = dec[:, d:d + m] - pcm[:, :m]
+        assert 10 * np.log10((pcm[:, :m] ** 2).sum() / (err ** 2).sum()) >= 20.0
+        _, units, _ = mp3dec.parse_units(data)
+        kinds = {int(u.block_type) for u in units}
+        assert kinds == {0, 1, 2, 3}, kinds
+        assert np.mean([int(u.nz) for u in units]) > 350  # dense: most of the 576 lines carry something
 
 
 def test_synthetic_streams_cover_the_syntax():
