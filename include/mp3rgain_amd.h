@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION 2
+#define RG_ABI_VERSION 3
 #define RG_HISTOGRAM_SIZE 12000         /* HISTOGRAM_SIZE        src/replaygain.rs:630 */
 #define RG_HISTOGRAM_OFFSET 2000        /* HISTOGRAM_OFFSET      src/replaygain.rs:635 */
 #define RG_REPLAYGAIN_REFERENCE_DB 89.0 /* REPLAYGAIN_REFERENCE_DB src/replaygain.rs:37 */
@@ -183,7 +183,9 @@ int rg_set_kernel(rg_ctx *ctx, int variant);
  * and the polyphase filterbank run on the GPU, file reads, copies and decode overlap chunk by chunk, and the PCM is
  * written straight into the analysis arena; 2 = the host parses the side information too; 1 = scalefactors + Huffman on
  * the host's cores, the rest on the GPU; 0 = the host decoder.  (An album of 64 three-minute 320 kb/s files:
- * 0.96 s / 0.25 s / 0.04 s / 0.017 s for 0 / 1 / 2 / 3.) */
+ * 0.96 s / 0.25 s / 0.04 s / 0.017 s for 0 / 1 / 2 / 3.),
+ * key 7 = host threads the file-level entry points load files with (0 = every core this process may use; a node of
+ * several contexts gives each its share, mp3rgain_amd_node.h). */
 int rg_set_tuning(rg_ctx *ctx, int key, int64_t value);
 /* diagnostic (host only): variant 2's design for one rate and segment length.  T_out: [L][12],
  * gram_last_out: [78]; either may be NULL.  RG_ERR_INVALID_ARG when no design exists. */
@@ -292,6 +294,12 @@ const char *rg_tracks_error(const rg_ctx *ctx, size_t i);
  * whose PCM does not fit the device at once is analysed in parts whose histograms and peaks are folded: same result. */
 int rg_analyze_album(rg_ctx *ctx, const char *const *paths, size_t n, int32_t track_index,
                      rg_track_result *tracks_out, rg_album_result *album_out);
+/* The same up to, not including, the album percentile: per-file results are out, the album's [histogram | peak] pack of
+ * THESE files is ready on the device.  rg_album_finish completes it; when other GPUs hold the rest of the album,
+ * rg_album_exchange (or a host fold of the packs) comes first -- mp3rgain_amd_node.h does exactly that over all GPUs of a
+ * node.  *failed_index (may be NULL): which file failed, (size_t)-1 when the failure is not a file's. */
+int rg_analyze_album_begin(rg_ctx *ctx, const char *const *paths, size_t n, int32_t track_index,
+                           rg_track_result *tracks_out, size_t *failed_index);
 /* find_peak_amplitude (src/replaygain.rs:1140-1249) */
 int rg_find_peak_amplitude(rg_ctx *ctx, const char *path, rg_peak_result *out);
 /* One MPEG Layer III stream through the split decoder (stage A on the host, stages B-E on the device), PCM copied back

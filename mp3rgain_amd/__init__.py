@@ -13,6 +13,7 @@ from .replaygain import (  # noqa: F401
     AlbumGainResult,
     Analyzer,
     AudioFileType,
+    Node,
     PcmTrack,
     PeakAmplitudeResult,
     ReplayGainError,

@@ -139,7 +139,36 @@ SYMBOLS = [
     ("rg_tracks_error", C.c_char_p, [_vp, C.c_size_t]),
     ("rg_find_peak_amplitude", _int, [_vp, C.c_char_p, _P(PeakResult)]),
     ("rg_mp3_decode_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    ("rg_analyze_album_begin", _int, [_vp, _P(C.c_char_p), _sz, _i32, _P(TrackResult), _P(_sz)]),
+    # include/mp3rgain_amd_node.h
+    ("rg_node_create", _vp, [_P(_int), _sz]),
+    ("rg_node_create_backend", _vp, [_vp, _P(_int), _sz]),
+    ("rg_node_destroy", None, [_vp]),
+    ("rg_node_last_error", C.c_char_p, [_vp]),
+    ("rg_node_devices", _sz, [_vp]),
+    ("rg_node_ctx", _vp, [_vp, _sz]),
+    ("rg_node_set_exchange", _int, [_vp, _int]),
+    ("rg_node_partition", None, [_P(_u64), _sz, _sz, _P(_u32)]),
+    ("rg_analyze_album_node", _int, [_vp, _P(C.c_char_p), _sz, _i32, _P(TrackResult), _P(AlbumResult)]),
+    ("rg_analyze_tracks_node", _int, [_vp, _P(C.c_char_p), _sz, _i32, _P(TrackResult), _P(_i32)]),
+    ("rg_node_tracks_error", C.c_char_p, [_vp, _sz]),
+    ("rg_node_last_partition", _int, [_vp, _P(_u32), _sz]),
 ]
+
+# rg_node_backend (include/mp3rgain_amd_node.h): a table of per-device functions
+NODE_OPEN = C.CFUNCTYPE(_vp, _int, _vp)
+NODE_CLOSE = C.CFUNCTYPE(None, _vp, _vp)
+NODE_ALBUM_BEGIN = C.CFUNCTYPE(_int, _vp, _P(C.c_char_p), _sz, _i32, _P(TrackResult), _P(_sz), _vp)
+NODE_ALBUM_PACK = C.CFUNCTYPE(_int, _vp, _P(_u32), _vp)
+NODE_TRACKS = C.CFUNCTYPE(_int, _vp, _P(C.c_char_p), _sz, _i32, _P(TrackResult), _P(_i32), _vp)
+NODE_TRACKS_ERROR = C.CFUNCTYPE(_vp, _vp, _sz, _vp)  # const char *: the callee keeps the bytes alive
+NODE_LAST_ERROR = C.CFUNCTYPE(_vp, _vp, _vp)
+
+
+class NodeBackend(C.Structure):
+    _fields_ = [("open", NODE_OPEN), ("close", NODE_CLOSE), ("album_begin", NODE_ALBUM_BEGIN), ("album_pack", NODE_ALBUM_PACK),
+                ("tracks", NODE_TRACKS), ("tracks_error", NODE_TRACKS_ERROR), ("last_error", NODE_LAST_ERROR), ("user", _vp)]
+
 
 _lib = None
 

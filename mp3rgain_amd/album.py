@@ -143,17 +143,26 @@ def analyze_album_files_sharded(analyzer, files: Sequence, group=None, exchange_
     files = [os.fspath(f) for f in files]
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    sizes = []
-    for f in files:
-        try:
-            sizes.append(os.path.getsize(f))
-        except OSError:
-            sizes.append(0)  # the rank that owns it reports "Failed to open"
+    # ONE view of the sizes decides the partition: rank 0's, broadcast.  (Every rank stat'ing for itself can disagree
+    # -- a lagging network filesystem, a file rewritten meanwhile -- and then tracks are analysed twice or not at all
+    # and the gathered results no longer line up.)
+    box = [None]
+    if rank == 0:
+        sizes = []
+        for f in files:
+            try:
+                sizes.append(os.path.getsize(f))
+            except OSError:
+                sizes.append(0)  # the rank that owns it reports "Failed to open"
+        box[0] = sizes
+    if world > 1:
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    sizes = box[0]
     mine = shard_indices(len(files), world, rank, frames=sizes)
     err, local = None, None
     try:
         local = analyzer.analyze_album_files([files[i] for i in mine])
-    except ReplayGainError as ex:
+    except Exception as ex:  # not only ReplayGainError: a rank that raised alone would leave the others in the collective
         err = ex
     abort_if_any_failed(err, group)
     if world > 1 or exchange_even_if_alone:

@@ -272,16 +272,29 @@ def _name(p: Path) -> str:
     return p.name or "unknown"
 
 
+def _file_identity(f):
+    """What makes two command-line arguments the same file: device + inode (a symlink, ./x and x, a relative and an
+    absolute path all name one file); the resolved path when it cannot be stat'ed."""
+    try:
+        st = os.stat(f)
+        return (st.st_dev, st.st_ino)
+    except OSError:
+        return os.path.realpath(os.fspath(f))
+
+
 class Cli:
     def __init__(self, opts: Options, out, err):
         self.o, self.out, self.err = opts, out, err
-        self._an: Optional[rgmod.Analyzer] = None
+        self._an: Optional[rgmod.Node] = None
         self._batch: Optional[dict] = None  # results of the one batched analysis of all files (analyze_track)
 
-    # the GPU context is created on first use: byte-level commands never touch a device
-    def analyzer(self) -> rgmod.Analyzer:
+    # The GPU contexts are created on first use: byte-level commands never touch a device.  The analysis runs on a node
+    # (include/mp3rgain_amd_node.h): every visible GPU of the machine, one context each -- `-a` and `-r` over many files
+    # deal the files out over all of them, a single file runs on the first.  MP3RGAIN_AMD_DEVICES="0,2" restricts it.
+    def analyzer(self) -> rgmod.Node:
         if self._an is None:
-            self._an = rgmod.Analyzer(0)
+            devs = os.environ.get("MP3RGAIN_AMD_DEVICES")
+            self._an = rgmod.Node([int(d) for d in devs.split(",")] if devs else None)
             dec = self.o.decoder or os.environ.get("MP3RGAIN_AMD_DECODER")
             if dec:
                 self._an.set_decoder_command(dec)
@@ -294,7 +307,7 @@ class Cli:
         (src/main.rs:1937-2001), the results are the same."""
         files = self.o.files
         # (a file named twice is analysed again after its first occurrence has been patched, as in the reference: no batch)
-        if len(files) > 1 and len({os.fspath(f) for f in files}) == len(files):
+        if len(files) > 1 and len({_file_identity(f) for f in files}) == len(files):
             if self._batch is None:
                 res = self.analyzer().analyze_track_files(files, self.o.track_index)
                 self._batch = {os.fspath(f): r for f, r in zip(files, res)}

@@ -320,6 +320,7 @@ extern "C" int rg_set_tuning(rg_ctx *c, int key, int64_t value) {
         case RG_TUNE_TM_WINDOWS: c->tune_tm_windows = (uint32_t)(value > 255 ? 255 : value); return RG_OK;
         case RG_TUNE_INGEST_CHUNK_KIB: c->tune_ingest_chunk_kib = (uint64_t)value; return RG_OK;
         case RG_TUNE_GPU_MP3_DECODE: c->gpu_mp3_decode = value > 3 ? 3 : (int)value; return RG_OK;
+        case RG_TUNE_LOADER_THREADS: c->loader_threads = (unsigned)(value > 1024 ? 1024 : value); return RG_OK;
         case RG_TUNE_PIPELINE_SLOTS: {
             if (sync_all(c) != RG_OK) return RG_ERR_DEVICE;
             c->n_slots = value == 0 ? RG_DEFAULT_SLOTS : (value > RG_MAX_SLOTS ? RG_MAX_SLOTS : (int)value);
@@ -545,6 +546,36 @@ extern "C" int rg_comm_init(rg_ctx *c, const void *id, int world, int rank) {
     void *comm = nullptr;
     const int r = f(&comm, world, nid, rank);
     if (r != 0 || !comm) return rg_set_err(c, RG_ERR_COLLECTIVE, "ncclCommInitRank(%d of %d) failed: %s", rank, world, nccl_error(r));
+    c->comm = comm;
+    c->comm_world = world;
+    return RG_OK;
+}
+
+// One communicator per context of this process (ncclCommInitAll: ranks = positions in `ctxs`), for a node that drives
+// all its GPUs from one process (rg_node.hip).
+int rg_comm_init_all(rg_ctx **ctxs, size_t n) {
+    if (!ctxs || n == 0) return RG_ERR_INVALID_ARG;
+    typedef int (*nccl_init_all_fn)(void **, int, const int *);
+    nccl_init_all_fn f = (nccl_init_all_fn)resolve("ncclCommInitAll");
+    if (!f) return rg_set_err(ctxs[0], RG_ERR_COLLECTIVE, "RCCL entry points not found (librccl.so)");
+    std::vector<int> devs(n);
+    std::vector<void *> comms(n, nullptr);
+    for (size_t i = 0; i < n; ++i) {
+        devs[i] = ctxs[i]->device;
+        (void)rg_comm_destroy(ctxs[i]);
+    }
+    const int r = f(comms.data(), (int)n, devs.data());
+    if (r != 0) return rg_set_err(ctxs[0], RG_ERR_COLLECTIVE, "ncclCommInitAll(%zu devices) failed: %s", n, nccl_error(r));
+    for (size_t i = 0; i < n; ++i) {
+        ctxs[i]->comm = comms[i];
+        ctxs[i]->comm_world = (int)n;
+    }
+    return RG_OK;
+}
+
+int rg_comm_adopt(rg_ctx *c, void *comm, int world) {
+    if (!c || !comm || world < 1) return RG_ERR_INVALID_ARG;
+    (void)rg_comm_destroy(c);
     c->comm = comm;
     c->comm_world = world;
     return RG_OK;
@@ -782,6 +813,16 @@ extern "C" int rg_analyze_album_pcm(rg_ctx *c, const rg_track_desc *tracks, size
         if (v != RG_OK) return v;
         return analyze_host_streamed(c, tracks, n, (const unsigned char *)pcm_base, 1, tracks_out, nullptr, album_out, album_hist_out, chunk);
     }
+    int rc = rg_album_local_pcm(c, tracks, n, pcm_base, pcm_bytes, on_device, tracks_out);
+    if (rc != RG_OK) return rc;
+    return rg_album_finish(c, album_out, album_hist_out);
+}
+
+// rg_ctx.h: the album of this context's tracks up to, not including, the album percentile: per-track results (exact
+// repeat of flagged tracks included) on the host, the album's [histogram | peak] pack ready on the device.  What follows
+// is rg_album_finish, or first rg_album_exchange when other GPUs hold more of the album (rg_node.cpp).
+int rg_album_local_pcm(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *pcm_base, size_t pcm_bytes, int on_device,
+                       rg_track_result *tracks_out) {
     const void *d_base = nullptr;
     int rc = stage_pcm(c, pcm_base, pcm_bytes, on_device, &d_base);
     if (rc != RG_OK) return rc;
@@ -802,7 +843,7 @@ extern "C" int rg_analyze_album_pcm(rg_ctx *c, const rg_track_desc *tracks, size
         rc = rg_collect(c, tracks_out, nullptr);
         if (rc != RG_OK) return rc;
     }
-    return rg_album_finish(c, album_out, album_hist_out);
+    return RG_OK;
 }
 
 // rg_ctx.h: an album in parts (the file layer's albums larger than the device); same folding as the streamed host ingest
@@ -831,10 +872,16 @@ int rg_album_part(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *
     return RG_OK;
 }
 
-int rg_album_parts_finish(rg_ctx *c, size_t parts, rg_album_result *album_out) {
+int rg_album_parts_fold(rg_ctx *c, size_t parts) {
     RgSlot &S = c->slot();
     RG_HIP(c, rg_launch_album_reduce_gathered(c->d_album_packs.p, (uint32_t)parts, S.d_album_hist.p, S.d_album_peak.p, S.stream));
     S.album_ready = true;
+    return RG_OK;
+}
+
+int rg_album_parts_finish(rg_ctx *c, size_t parts, rg_album_result *album_out) {
+    const int rc = rg_album_parts_fold(c, parts);
+    if (rc != RG_OK) return rc;
     return rg_album_finish(c, album_out, nullptr);
 }
 

@@ -63,7 +63,7 @@ struct RgTmDeviceTables {
 };
 
 enum { RG_TUNE_TM_SEGMENT = 1, RG_TUNE_TM_TARGET_LANES = 2, RG_TUNE_PIPELINE_SLOTS = 3, RG_TUNE_TM_WINDOWS = 4, RG_TUNE_INGEST_CHUNK_KIB = 5,
-       RG_TUNE_GPU_MP3_DECODE = 6 };
+       RG_TUNE_GPU_MP3_DECODE = 6, RG_TUNE_LOADER_THREADS = 7 };
 
 #define RG_MAX_SLOTS 8
 #define RG_SLOT_STREAMS 4   // HIP streams the slots are spread over (the runtime has 4 hardware queues by default)
@@ -162,6 +162,7 @@ struct rg_ctx {
     int gpu_mp3_decode = 3;                  // tuning key 6: 0 = host decoder, 1 = stages B-E of MP3 decoding run on the device,
                                              // 2 = scalefactors + Huffman too, 3 (default) = side-information parsing too: the host
                                              // only finds the frames and strips their headers (loader pipeline, rg_files.hip)
+    unsigned loader_threads = 0;             // tuning key 7: host threads of the file loaders; 0 = every core this process may use
     DevBuf<unsigned char> d_arena;           // staging for host PCM (synchronous API)
     DevBuf<unsigned char> d_ingest[2];       // streamed host ingest: two sub-batch arenas, one filling while the other is analysed
     DevBuf<uint32_t> d_album_packs;          // streamed album: one [histogram | peak] pack per sub-batch, folded at the end
@@ -195,6 +196,14 @@ void rg_tm_tables_release(rg_ctx *c);
 int rg_album_part(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *d_base, size_t bytes, size_t index, size_t parts,
                   rg_track_result *out);
 int rg_album_parts_finish(rg_ctx *c, size_t parts, rg_album_result *album_out);
+int rg_album_parts_fold(rg_ctx *c, size_t parts);  // the fold alone: the album pack is ready on the device, no percentile yet
+// rg_analyze_album_pcm up to, not including, the album percentile (rg_capi.hip)
+int rg_album_local_pcm(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *pcm_base, size_t pcm_bytes, int on_device,
+                       rg_track_result *tracks_out);
+// adopt a communicator made elsewhere (ncclCommInitAll in rg_node.hip); the context owns it from here on
+int rg_comm_adopt(rg_ctx *c, void *comm, int world);
+int rg_comm_init_all(rg_ctx **ctxs, size_t n);
+unsigned rg_usable_cores();  // rg_files.hip: the affinity mask cut by the cgroup CPU quota
 int rg_validate_batch(rg_ctx *c, const rg_track_desc *tracks, size_t n, size_t pcm_bytes);  // argument checks of an enqueue
 
 #define RG_HIP(ctx, call)                                                                          \

@@ -605,6 +605,7 @@ struct PipeRun {
     std::condition_variable cv;
     std::deque<PipeChunk> chunks;
     int open = -1;
+    bool preparing = false;  // a loader is getting the next chunk's staging block ready, outside the lock
     size_t files_done = 0;
     size_t stage_want = 0;
     int hip_error = RG_OK;
@@ -648,7 +649,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
     int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
     Mp3Pipe &P = mp3_pipe(c);
-    unsigned workers = usable_cores();
+    unsigned workers = c->loader_threads ? c->loader_threads : usable_cores();
     if (workers > n) workers = (unsigned)n;
     if (P.scratch.size() < workers) P.scratch.resize(workers);
     for (Mp3Stage &st : P.stage)
@@ -756,19 +757,38 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
                     R.cv.notify_all();
                 }
                 const size_t id = R.chunks.size();
-                if (id >= (size_t)Mp3Pipe::NSTAGE && !R.chunks[id - Mp3Pipe::NSTAGE].issued) {  // every block is filling or waiting to be sent
+                // every block is filling or waiting to be sent, or another loader is already preparing the next one
+                if (R.preparing || (id >= (size_t)Mp3Pipe::NSTAGE && !R.chunks[id - Mp3Pipe::NSTAGE].issued)) {
                     R.cv.wait(lk);
                     continue;
                 }
+                // Waiting for the block's last H2D copy and pinning memory (up to 128 MB) happen WITHOUT the lock: every
+                // loader and the drive thread take it for each file and each chunk, and one loader sitting on it stalled
+                // file reads, copy completion and chunk issue for all the others.
                 Mp3Stage &st = P.stage[id % Mp3Pipe::NSTAGE];
+                R.preparing = true;
+                lk.unlock();
+                bool ev_ok = true, mem_ok = true;
                 if (id >= (size_t)Mp3Pipe::NSTAGE) {
                     (void)hipSetDevice(device);
-                    if (hipEventSynchronize(st.staged) != hipSuccess) hip_fail("waiting for a staging block failed");
+                    ev_ok = hipEventSynchronize(st.staged) == hipSuccess;
                 }
-                if (!grow_stage(st, std::max(R.stage_want, (size_t)4096))) { hip_fail("hipHostMalloc of a staging block failed"); (*rcs)[i] = RG_ERR_DEVICE; err = "out of pinned memory"; la.staged = false; return; }
+                mem_ok = grow_stage(st, std::max(R.stage_want, (size_t)4096));
+                lk.lock();
+                R.preparing = false;
+                if (!ev_ok) hip_fail("waiting for a staging block failed");
+                if (!mem_ok) {
+                    hip_fail("hipHostMalloc of a staging block failed");
+                    (*rcs)[i] = RG_ERR_DEVICE;
+                    err = "out of pinned memory";
+                    la.staged = false;
+                    R.cv.notify_all();
+                    return;
+                }
                 R.chunks.emplace_back();
                 R.chunks.back().stage = (int)(id % Mp3Pipe::NSTAGE);
                 R.open = (int)id;
+                R.cv.notify_all();
             }
             chunk = &R.chunks[(size_t)R.open];
             f.main_off = chunk->used;
@@ -922,7 +942,7 @@ int load_many(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedA
         const int prc = load_many_pipelined(c, paths, n, out, &rcs, &errs);
         if (prc != RG_OK) return prc;
     } else {
-        unsigned workers = usable_cores();
+        unsigned workers = c->loader_threads ? c->loader_threads : usable_cores();
         if (workers > n) workers = (unsigned)n;
         std::atomic<size_t> next{0};
         const std::string cmd = c->decoder_cmd;
@@ -960,6 +980,8 @@ uint32_t file_type_of(const char *path) {  // detect_file_type, src/replaygain.r
 }
 
 }  // namespace
+
+unsigned rg_usable_cores() { return usable_cores(); }
 
 // =================================================================================================
 extern "C" int rg_set_decoder_command(rg_ctx *c, const char *command_template) {
@@ -1024,27 +1046,72 @@ static void file_groups(rg_ctx *c, const char *const *paths, size_t n, std::vect
     }
 }
 
-// analyze_album_with_index (src/replaygain.rs:1044-1074): the first failing file aborts the album (:1055).  An album
-// whose PCM does not fit the device at once is analysed in parts and the parts' histograms and peaks are folded (u32
-// adds commute: the result does not depend on the partition).
-extern "C" int rg_analyze_album(rg_ctx *c, const char *const *paths, size_t n, int32_t track_index, rg_track_result *tracks_out,
-                                rg_album_result *album_out) {
-    if (!c || (n && (!paths || !tracks_out)) || !album_out) return RG_ERR_INVALID_ARG;
+// What one file of a list comes to before any analysis, in the order the reference meets its errors
+// (src/replaygain.rs:804-873): open / read, track selection, probe, sample rate.  RG_OK, or the code with `msg` set.
+static int file_outcome(const LoadedAudio &la, int load_rc, const std::string &load_err, const char *path, int32_t track_index,
+                        std::string *msg) {
+    if (load_rc != RG_OK) {
+        *msg = load_err;
+        return load_rc;
+    }
+    if (track_index > 0) {
+        char m[128];
+        snprintf(m, sizeof m, "Track index %d out of range (file has 1 audio track(s))", track_index);
+        *msg = m;
+        return RG_ERR_INVALID_ARG;
+    }
+    uint32_t rate = la.sample_rate;
+    if (!la.decoded && !la.split && !la.staged) {
+        rg_wav_info wi;
+        rate = rg_wav_parse(la.wav.data(), la.wav.size(), &wi) == RG_OK ? wi.sample_rate : 0;
+        if (rate == 0) {
+            *msg = std::string("Failed to probe format: ") + path;
+            return RG_ERR_FORMAT;
+        }
+    }
+    if (!rg_supported_rate(rate)) {
+        char m[256];
+        snprintf(m, sizeof m, "Unsupported sample rate: %u Hz. Supported rates: 96000, 88200, 64000, 48000, 44100, 32000, 24000, "
+                              "22050, 16000, 12000, 11025, 8000", rate);
+        *msg = m;
+        return RG_ERR_UNSUPPORTED_RATE;
+    }
+    return RG_OK;
+}
+
+// analyze_album_with_index (src/replaygain.rs:1044-1074) up to, not including, the album percentile: per-file results in
+// input order on the host, the album's [histogram | peak] pack ready on the device (rg_album_finish reads it out; on a
+// node with several GPUs rg_album_exchange comes first, rg_node.cpp).  The first failing file IN INPUT ORDER aborts
+// the album (:1055) -- the files of a group are loaded together, so every file's outcome is looked at before anything is
+// reported -- and *failed_index (if given) says which one it was.  An album whose PCM does not fit the device at once is
+// analysed in parts and the parts' histograms and peaks are folded (u32 adds commute: the result does not depend on the
+// partition).
+extern "C" int rg_analyze_album_begin(rg_ctx *c, const char *const *paths, size_t n, int32_t track_index, rg_track_result *tracks_out,
+                                      size_t *failed_index) {
+    if (failed_index) *failed_index = (size_t)-1;
+    if (!c || (n && (!paths || !tracks_out))) return RG_ERR_INVALID_ARG;
     int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
     std::vector<std::pair<size_t, size_t>> groups;
     file_groups(c, paths, n, &groups);
     const bool trace = getenv("RG_TRACE_FILES") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto fail_at = [&](size_t i, int code) {
+        if (failed_index) *failed_index = i;
+        return code;
+    };
     for (size_t g = 0; g < std::max<size_t>(groups.size(), 1); ++g) {
         const size_t first = groups.empty() ? 0 : groups[g].first, cnt = groups.empty() ? 0 : groups[g].second;
         std::vector<LoadedAudio> &in = file_pool(c, cnt);
         const double t0 = now();
-        rc = load_many(c, paths + first, cnt, &in);
-        if (rc != RG_OK) return rc;
-        if (cnt) {
-            rc = check_track_index(c, track_index);
-            if (rc != RG_OK) return rc;
+        std::vector<int> rcs;
+        std::vector<std::string> errs;
+        rc = load_many(c, paths + first, cnt, &in, &rcs, &errs);
+        if (rc != RG_OK) return fail_at(first, rc);
+        for (size_t i = 0; i < cnt; ++i) {
+            std::string msg;
+            const int frc = file_outcome(in[i], rcs[i], errs[i], paths[first + i], track_index, &msg);
+            if (frc != RG_OK) return fail_at(first + i, rg_set_err(c, frc, "%s", msg.c_str()));
         }
         const double t1 = now();
         std::vector<rg_track_desc> descs;
@@ -1053,18 +1120,27 @@ extern "C" int rg_analyze_album(rg_ctx *c, const char *const *paths, size_t n, i
         if (trace) fprintf(stderr, "[rg_analyze_album] load %.1f ms, stage + device decode %.1f ms\n", (t1 - t0) * 1e3, (now() - t1) * 1e3);
         if (rc == RG_ERR_FORMAT) {  // "input i ..." -> the reference's text with the file's name
             size_t i = 0;
-            if (sscanf(c->err.c_str(), "input %zu", &i) == 1 && i < cnt) return rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s", paths[first + i]);
+            if (sscanf(c->err.c_str(), "input %zu", &i) == 1 && i < cnt)
+                return fail_at(first + i, rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s", paths[first + i]));
         }
-        if (rc != RG_OK) return rc;
+        if (rc != RG_OK) return fail_at(first, rc);
         const double t2 = now();
-        if (groups.size() <= 1) rc = rg_analyze_album_pcm(c, descs.data(), cnt, c->d_arena.p, arena_bytes, 1, tracks_out, album_out, nullptr);
+        if (groups.size() <= 1) rc = rg_album_local_pcm(c, descs.data(), cnt, c->d_arena.p, arena_bytes, 1, tracks_out);
         else rc = rg_album_part(c, descs.data(), cnt, c->d_arena.p, arena_bytes, g, groups.size(), tracks_out + first);
-        if (rc != RG_OK) return rc;
+        if (rc != RG_OK) return fail_at(first, rc);
         for (size_t i = 0; i < cnt; ++i) tracks_out[first + i].file_type = in[i].is_mp4 ? RG_FILE_AAC : RG_FILE_MP3;
         if (trace) fprintf(stderr, "[rg_analyze_album] analysis %.1f ms\n", (now() - t2) * 1e3);
     }
-    if (groups.size() > 1) return rg_album_parts_finish(c, groups.size(), album_out);
+    if (groups.size() > 1) return rg_album_parts_fold(c, groups.size());
     return RG_OK;
+}
+
+extern "C" int rg_analyze_album(rg_ctx *c, const char *const *paths, size_t n, int32_t track_index, rg_track_result *tracks_out,
+                                rg_album_result *album_out) {
+    if (!c || (n && (!paths || !tracks_out)) || !album_out) return RG_ERR_INVALID_ARG;
+    const int rc = rg_analyze_album_begin(c, paths, n, track_index, tracks_out, nullptr);
+    if (rc != RG_OK) return rc;
+    return rg_album_finish(c, album_out, nullptr);
 }
 
 // one group of rg_analyze_tracks: files [first, first + n) of the call; file_errors is indexed by the call's numbering
@@ -1085,28 +1161,10 @@ static int analyze_tracks_group(rg_ctx *c, const char *const *paths, size_t firs
         status_out[i] = rcs[i];
         c->file_errors[first + i] = errs[i];
         if (rcs[i] != RG_OK) continue;
-        if (track_index > 0) {
-            char msg[128];
-            snprintf(msg, sizeof msg, "Track index %d out of range (file has 1 audio track(s))", track_index);
-            status_out[i] = RG_ERR_INVALID_ARG;
-            c->file_errors[first + i] = msg;
-            continue;
-        }
-        uint32_t rate = in[i].sample_rate;
-        if (!in[i].decoded && !in[i].split && !in[i].staged) {
-            rg_wav_info wi;
-            rate = rg_wav_parse(in[i].wav.data(), in[i].wav.size(), &wi) == RG_OK ? wi.sample_rate : 0;
-            if (rate == 0) {
-                status_out[i] = RG_ERR_FORMAT;
-                c->file_errors[first + i] = std::string("Failed to probe format: ") + paths[i];
-                continue;
-            }
-        }
-        if (!rg_supported_rate(rate)) {
-            char msg[256];
-            snprintf(msg, sizeof msg, "Unsupported sample rate: %u Hz. Supported rates: 96000, 88200, 64000, 48000, 44100, 32000, 24000, "
-                                      "22050, 16000, 12000, 11025, 8000", rate);
-            status_out[i] = RG_ERR_UNSUPPORTED_RATE;
+        std::string msg;
+        const int frc = file_outcome(in[i], RG_OK, errs[i], paths[i], track_index, &msg);
+        if (frc != RG_OK) {
+            status_out[i] = frc;
             c->file_errors[first + i] = msg;
             continue;
         }

@@ -260,7 +260,11 @@ __global__ void __launch_bounds__(256) rg_k1_halo_kernel(const RgTrackDev *__res
             rsum += sq;
         }
         if (++n >= W) {
-            if (i >= bad_from) lsum = qnan;  // the window holds, or follows, the first non-finite sample
+            // A window that starts after the first non-finite sample is a NaN window in the reference (the filter state
+            // never recovers) whatever this lane's zero-warmed state says.  The window that HOLDS that sample went through
+            // this lane's own cascade, in the reference's order: its sum is the reference's -- NaN, or +Inf when an Inf is
+            // its very last frame (then `val as i32` saturates, the index wraps and the window is dropped, :749-759).
+            if (i + 1 - n > bad_from) lsum = qnan;
             const int idx = rg_window_bin(lsum, rsum, n);
             if (idx >= 0) atomicAdd(&h[idx], 1u);
             lsum = 0.0; rsum = 0.0; n = 0;
@@ -316,7 +320,7 @@ __global__ void __launch_bounds__(256) rg_k1_halo_kernel(const RgTrackDev *__res
     }
     (void)mag;
     if (n > 0) {  // final partial window, src/replaygain.rs:907
-        if (last - 1 >= bad_from) lsum = qnan;
+        if (last - n > bad_from) lsum = qnan;
         const int idx = rg_window_bin(lsum, rsum, n);
         if (idx >= 0) atomicAdd(&h[idx], 1u);
     }

@@ -13,6 +13,8 @@
 // FP64 vector FMA bound (27 FMA + 1 convert per channel-sample, plus 2..12 moment FMAs); MFMA is
 // not used.  Compiled with the default -ffp-contract (explicit fma() everywhere anyway).
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <type_traits>
 
 #include "rg_device.h"
@@ -795,9 +797,26 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
             Mseg += 2.0 * quad[c];
         }
     }
-    // windows at or after the first non-finite sample of the track are NaN windows (see the main kernel)
+    // windows after the first non-finite unit of the track are NaN windows (see the main kernel).  The unit itself has
+    // the class of its zero-state energy (the true output differs from the zero-state one by finite terms): NaN, or
+    // +Inf when an Inf sample is the unit's very last frame and nothing after it has turned into NaN yet -- if that
+    // is also the window's last frame the reference's sum is +Inf and the window is DROPPED (`val as i32` saturates,
+    // the index wraps out of range, src/replaygain.rs:749-759), not counted in bin 2000.  A + 2 B.sigma + ... itself
+    // would be Inf - Inf there.
     const uint32_t nf = nonfinite[tr.track_index];
-    if (nf != 0 && owner && (uint64_t)seg * G.m >= 0xFFFFFFFFu - nf) S = __longlong_as_double(0x7FF8000000000000ll);
+    if (nf != 0 && owner) {
+        const uint64_t unit = (uint64_t)seg * G.m, bad = 0xFFFFFFFFu - nf;
+        if (unit > bad) S = __longlong_as_double(0x7FF8000000000000ll);
+        else if (unit == bad) {
+            double cls = 0.0;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const double a = rec[(size_t)c * RG_TM_REC * total_recs + idx];
+                if (!(fabs(a) <= 1.7976931348623157e308)) cls += a;  // +Inf stays +Inf, anything + NaN is NaN
+            }
+            S = cls;
+        }
+    }
     pieces[i] = owner ? S : 0.0;
     pieces_m[i] = owner ? Mseg : 0.0;
     __syncthreads();
@@ -900,7 +919,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
                     if (w == 1) e += 2.0 * dlt[c] * sqrt((double)n * fabs(a)) + (double)n * dlt[c] * dlt[c];
                 }
                 if (NCH == 1) { total *= 2.0; e *= 2.0; }
-                if (nf != 0 && widx >= 0xFFFFFFFFu - nf) total = __longlong_as_double(0x7FF8000000000000ll);
+                if (nf != 0 && widx > 0xFFFFFFFFu - nf) total = __longlong_as_double(0x7FF8000000000000ll);  // == : its own class
                 const int wb = rg_window_bin(total, 0.0, n);
                 if (w == 1 && e > 1.0e-13 * total) {
                     const double lo = total - e;
@@ -956,11 +975,16 @@ static hipError_t launch_main_fmt(int nch, const RgTmCoef &K, const RgTmGeom &G,
     size_t lds = rg_tm_lds_bytes(G.L, G.H10, G.block);
     uint32_t lds_tables = lds <= RG_TM_LDS_BYTES ? 1u : 0u;
     if (!lds_tables) lds = 0;
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
+    // the attribute belongs to the function ON THE CURRENT DEVICE: a node drives several devices from one process
+    // (rg_node.hip), each from its own host thread
+    static std::atomic<unsigned long long> attr_set{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long dev_bit = 1ull << (dev & 63);
+    if (lds > 48 * 1024 && !(attr_set.load(std::memory_order_acquire) & dev_bit)) {
         (void)hipFuncSetAttribute((const void *)rg_tm_main_kernel<FMT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_TM_LDS_BYTES);
         (void)hipFuncSetAttribute((const void *)rg_tm_main_kernel<FMT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_TM_LDS_BYTES);
-        attr_set = true;
+        attr_set.fetch_or(dev_bit, std::memory_order_release);
     }
     if (G.m > 1) {
         if (!lds_tables) return hipErrorInvalidValue;  // multi-window segments exist on the LDS path only

@@ -33,6 +33,8 @@
 #include "rg_mp3_math.h"
 #include "rg_mp3_frame.h"
 
+extern "C" int rg_cpu_has_fma(void);  // rg_mp3gain.cpp (built without -mfma)
+
 namespace {
 
 thread_local char g_err[256] = "";
@@ -44,6 +46,10 @@ int fail(int code, const char *fmt, ...) {
     va_end(ap);
     return code;
 }
+
+// this file is compiled with -mfma (Makefile): on a CPU without FMA3 it must not be entered
+#define RG_NEED_FMA() \
+    do { if (!rg_cpu_has_fma()) return fail(RG_MP3DEC_ERR_ARG, "this build of the MP3 decoder needs a CPU with FMA3"); } while (0)
 
 // ---------------------------------------------------------------------------------------------------------------
 // frame header (the same field tables as src/lib.rs:152-252; ISO 11172-3 2.4.1.3)
@@ -922,6 +928,7 @@ int walk_frames(const uint8_t *d, size_t len, rg_mp3_stream_info *info, F &&on_f
 extern "C" const char *rg_mp3dec_last_error(void) { return g_err; }
 
 extern "C" int rg_mp3_scan(const void *data, size_t len, rg_mp3_stream_info *out) {
+    RG_NEED_FMA();
     if (!data || !out) return fail(RG_MP3DEC_ERR_ARG, "null argument");
     g_err[0] = 0;
     uint32_t n = 0;
@@ -934,6 +941,7 @@ extern "C" int rg_mp3_scan(const void *data, size_t len, rg_mp3_stream_info *out
 
 extern "C" int rg_mp3_decode_f32(const void *data, size_t len, float *ch0, float *ch1, uint64_t capacity,
                                  rg_mp3_stream_info *out) {
+    RG_NEED_FMA();
     if (!data || !out || !ch0) return fail(RG_MP3DEC_ERR_ARG, "null argument");
     g_err[0] = 0;
     const Tables &T = tables();
@@ -967,6 +975,7 @@ extern "C" int rg_mp3_decode_f32(const void *data, size_t len, float *ch0, float
 
 extern "C" int rg_mp3_parse_units(const void *data, size_t len, int16_t *is_out, rg_mp3_unit *units_out, uint64_t capacity_units,
                                   uint64_t *n_units, rg_mp3_stream_info *out) {
+    RG_NEED_FMA();
     if (!data || !out || !n_units || (capacity_units && (!is_out || !units_out))) return fail(RG_MP3DEC_ERR_ARG, "null argument");
     g_err[0] = 0;
     const Tables &T = tables();
@@ -1052,6 +1061,7 @@ extern "C" void rg_mp3_fill_device_huff(RgMp3DevHuff *o) {
 
 int rg_mp3_index_stream(const void *data, size_t len, std::vector<uint8_t> *main_stream, std::vector<RgMp3HuffRec> *recs,
                         rg_mp3_stream_info *out) {
+    RG_NEED_FMA();
     if (!data || !main_stream || !recs || !out) return fail(RG_MP3DEC_ERR_ARG, "null argument");
     g_err[0] = 0;
     main_stream->clear();
@@ -1090,6 +1100,7 @@ int rg_mp3_index_stream(const void *data, size_t len, std::vector<uint8_t> *main
 // Which frames decode, and to what, is the device's business (rg_mp3_frames_kernel).
 int rg_mp3_compact_stream(uint8_t *data, size_t len, std::vector<uint8_t> *slots, std::vector<uint64_t> *tiles, uint64_t *main_len_out,
                           rg_mp3_stream_info *out) {
+    RG_NEED_FMA();
     if (!data || !slots || !tiles || !main_len_out || !out) return fail(RG_MP3DEC_ERR_ARG, "null argument");
     g_err[0] = 0;
     slots->clear();
@@ -1120,6 +1131,7 @@ int rg_mp3_compact_stream(uint8_t *data, size_t len, std::vector<uint8_t> *slots
 // walk) and rg_mp3_compact_stream + rg_mp3_frame_records over the slots afterwards (what rg_mp3_frames_kernel does on the
 // device) and compares main data and records.  0 = identical, 1 = different, < 0 = the stream has no audio.
 extern "C" int rg_mp3_index_selfcheck(const void *data, size_t len) {
+    RG_NEED_FMA();
     std::vector<uint8_t> main_a, slots;
     std::vector<uint64_t> tiles;
     std::vector<RgMp3HuffRec> recs_a, recs_b;
@@ -1150,6 +1162,7 @@ extern "C" int rg_mp3_index_selfcheck(const void *data, size_t len) {
 }
 
 extern "C" int rg_mp3_index_units(const void *data, size_t len, uint64_t *n_units, rg_mp3_stream_info *out) {
+    RG_NEED_FMA();
     if (!n_units) return fail(RG_MP3DEC_ERR_ARG, "null argument");
     std::vector<uint8_t> main_stream;
     std::vector<RgMp3HuffRec> recs;

@@ -18,6 +18,8 @@ hipError_t rg_launch_mp3_synth(const RgMp3DevTables *, const RgMp3DevTrack *, ui
 hipError_t rg_launch_mp3_frames(RgMp3DevTrack *, uint32_t, uint32_t, const uint8_t *, uint32_t *, RgMp3HuffRec *, uint32_t *, hipStream_t);
 }
 
+extern "C" int rg_cpu_has_fma(void);  // rg_mp3gain.cpp
+
 namespace {
 // units per chunk: 4.6 KB of IMDCT halves + 1.2 KB of input each (256 K units = 1.5 GB); a longer single track gets a
 // chunk of its own size
@@ -32,6 +34,7 @@ int rg_mp3_rate_row(uint32_t sample_rate) {
 }
 
 static int ensure_tables(rg_ctx *c) {
+    if (!c->mp3_tab_ready && !rg_cpu_has_fma()) return rg_set_err(c, RG_ERR_DEVICE, "this build of the MP3 decoder needs a host CPU with FMA3");
     if (!c->mp3_tab_ready) {
         RgMp3DevTables *tab = new RgMp3DevTables();
         rg_mp3_fill_device_tables(tab);
@@ -158,7 +161,10 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
     if (!c->mp3_copy_stream) RG_HIP(c, hipStreamCreateWithFlags(&c->mp3_copy_stream, hipStreamNonBlocking));
     for (int k = 0; k < 2; ++k)
         if (!c->mp3_set_free[k]) RG_HIP(c, hipEventCreateWithFlags(&c->mp3_set_free[k], hipEventDisableTiming));
-    // the descriptors, laid out for the upper bound "every walked frame decodes"
+    // the descriptors are written into the staging block itself: check that they fit BEFORE writing them
+    const size_t total = tracks_off + n * sizeof(RgMp3DevTrack);
+    if (total > bytes || (tracks_off & 7) != 0) return rg_set_err(c, RG_ERR_INVALID_ARG, "MP3 staging block: descriptors do not fit");
+    // laid out for the upper bound "every walked frame decodes"
     RgMp3DevTrack *tr = reinterpret_cast<RgMp3DevTrack *>(staging + tracks_off);
     uint64_t ub = 0;
     uint32_t gb = 0, sb = 0, tb = 0;
@@ -187,8 +193,6 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
         gb += granules;
         sb += ((granules + RG_MP3_SYNTH_RUN - 1) / RG_MP3_SYNTH_RUN) * it.channels;
     }
-    const size_t total = tracks_off + n * sizeof(RgMp3DevTrack);
-    if (total > bytes) return rg_set_err(c, RG_ERR_INVALID_ARG, "MP3 staging block: descriptors do not fit");
     // grow-only buffers; growing one frees the old allocation, which waits for the kernels still using it
     RG_HIP(c, c->d_mp3_stage[set].reserve(bytes + 64));
     if (ub) {

@@ -15,6 +15,19 @@
 namespace {
 
 thread_local std::string g_err;
+}  // namespace
+
+// The host MP3 decoder (rg_mp3dec.cpp) is built with -mfma on x86-64; its entry points ask here -- a file built without
+// the flag -- whether the CPU has FMA3, and refuse to run rather than die on an illegal instruction.
+extern "C" int rg_cpu_has_fma(void) {
+#if defined(__x86_64__) || defined(__i386__)
+    return __builtin_cpu_supports("fma") ? 1 : 0;
+#else
+    return 1;
+#endif
+}
+
+namespace {
 
 int64_t fail(int code, const char *fmt, ...) {
     char buf[1024];

@@ -416,6 +416,133 @@ class Analyzer:
         return s.value, k.value, sp.value
 
 
+class Node:
+    """All GPUs of this machine behind the reference's file-level signatures, in one process
+    (include/mp3rgain_amd_node.h): one context and one host thread per device, files dealt out by size, the album's
+    histogram merged across devices.  `devices` = HIP ordinals, None = every visible device."""
+
+    EXCHANGE_HOST, EXCHANGE_RCCL = 0, 1
+
+    def __init__(self, devices: Optional[Sequence[int]] = None, _backend=None):
+        self._lib = _capi.load()
+        self._node = None
+        if _backend is not None:  # tests: a table of per-device functions instead of rg_ctx
+            devs = (C.c_int * len(devices))(*devices)
+            self._backend = _backend
+            self._node = self._lib.rg_node_create_backend(C.addressof(_backend), devs, len(devices))
+        elif devices is None:
+            self._node = self._lib.rg_node_create(None, 0)
+        else:
+            devs = (C.c_int * max(1, len(devices)))(*devices)
+            self._node = self._lib.rg_node_create(devs, len(devices))
+        if not self._node:
+            raise ReplayGainError(-4, self._lib.rg_node_last_error(None).decode("utf-8", "replace"))
+
+    def close(self):
+        if self._node:
+            self._lib.rg_node_destroy(self._node)
+            self._node = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise ReplayGainError(rc, self._lib.rg_node_last_error(self._node).decode("utf-8", "replace"))
+
+    @property
+    def devices(self) -> int:
+        return int(self._lib.rg_node_devices(self._node))
+
+    def set_exchange(self, mode: int):
+        self._check(self._lib.rg_node_set_exchange(self._node, int(mode)))
+
+    def set_tuning(self, key: int, value: int):
+        """rg_set_tuning on every device's context."""
+        for i in range(self.devices):
+            ctx = self._lib.rg_node_ctx(self._node, i)
+            if ctx and self._lib.rg_set_tuning(ctx, int(key), int(value)) != 0:
+                raise ReplayGainError(-1, self._lib.rg_last_error(ctx).decode("utf-8", "replace"))
+
+    def set_decoder_command(self, command_template: Optional[str]):
+        for i in range(self.devices):
+            ctx = self._lib.rg_node_ctx(self._node, i)
+            if ctx:
+                self._lib.rg_set_decoder_command(ctx, command_template.encode() if command_template else None)
+
+    def analyze_album_files(self, files, track_index: Optional[int] = None) -> AlbumGainResult:
+        """analyze_album_with_index (src/replaygain.rs:1044-1074) over all devices."""
+        n = len(files)
+        paths = (C.c_char_p * max(1, n))(*[os.fsencode(os.fspath(f)) for f in files])
+        out = (_capi.TrackResult * max(1, n))()
+        alb = _capi.AlbumResult()
+        self._check(self._lib.rg_analyze_album_node(self._node, paths, n, -1 if track_index is None else int(track_index), out, C.byref(alb)))
+        return AlbumGainResult([_to_result(out[i], out[i].file_type) for i in range(n)], alb.album_loudness_db,
+                               alb.album_gain_db, alb.album_peak)
+
+    def analyze_track_files(self, files, track_index: Optional[int] = None) -> list:
+        """analyze_track for every file (`-r`), the files dealt out over all devices; per file a result or its error."""
+        n = len(files)
+        paths = (C.c_char_p * max(1, n))(*[os.fsencode(os.fspath(f)) for f in files])
+        out = (_capi.TrackResult * max(1, n))()
+        status = (C.c_int32 * max(1, n))()
+        self._check(self._lib.rg_analyze_tracks_node(self._node, paths, n, -1 if track_index is None else int(track_index), out, status))
+        res = []
+        for i in range(n):
+            if status[i] == 0:
+                res.append(_to_result(out[i], out[i].file_type))
+            else:
+                res.append(ReplayGainError(int(status[i]), self._lib.rg_node_tracks_error(self._node, i).decode("utf-8", "replace")))
+        return res
+
+    def analyze_track_file(self, file_path, track_index: Optional[int] = None) -> ReplayGainResult:
+        """analyze_track_with_index (src/replaygain.rs:935-941) on the node's first device."""
+        ctx = self._lib.rg_node_ctx(self._node, 0)
+        if not ctx:
+            r = self.analyze_track_files([file_path], track_index)[0]
+            if isinstance(r, ReplayGainError):
+                raise r
+            return r
+        out = _capi.TrackResult()
+        rc = self._lib.rg_analyze_track(ctx, os.fsencode(os.fspath(file_path)), -1 if track_index is None else int(track_index), C.byref(out))
+        if rc != 0:
+            raise ReplayGainError(rc, self._lib.rg_last_error(ctx).decode("utf-8", "replace"))
+        return _to_result(out, out.file_type)
+
+    def find_peak_amplitude_file(self, file_path) -> PeakAmplitudeResult:
+        """find_peak_amplitude (src/replaygain.rs:1140-1249) on the node's first device."""
+        ctx = self._lib.rg_node_ctx(self._node, 0)
+        pk = _capi.PeakResult()
+        rc = self._lib.rg_find_peak_amplitude(ctx, os.fsencode(os.fspath(file_path)), C.byref(pk))
+        if rc != 0:
+            raise ReplayGainError(rc, self._lib.rg_last_error(ctx).decode("utf-8", "replace"))
+        return PeakAmplitudeResult(pk.peak, pk.peak_pcm, pk.sample_rate)
+
+    def last_partition(self, n: int) -> List[int]:
+        own = (C.c_uint32 * max(1, n))()
+        self._check(self._lib.rg_node_last_partition(self._node, own, n))
+        return [int(own[i]) for i in range(n)]
+
+
+def node_partition(sizes: Sequence[int], world: int) -> List[int]:
+    """rg_node_partition: device of every item (heaviest first, each to the least loaded device)."""
+    lib = _capi.load()
+    n = len(sizes)
+    a = (C.c_uint64 * max(1, n))(*[int(x) for x in sizes])
+    own = (C.c_uint32 * max(1, n))()
+    lib.rg_node_partition(a, n, world, own)
+    return [int(own[i]) for i in range(n)]
+
+
 def _to_result(r: _capi.TrackResult, file_type: AudioFileType) -> ReplayGainResult:
     return ReplayGainResult(r.loudness_db, r.gain_db, r.peak, r.sample_rate, AudioFileType(int(file_type)), r.windows, r.flags)
 

@@ -14,7 +14,7 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def _declared_functions():
-    txt = (ROOT / "include" / "mp3rgain_amd.h").read_text()
+    txt = (ROOT / "include" / "mp3rgain_amd.h").read_text() + (ROOT / "include" / "mp3rgain_amd_node.h").read_text()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(rg_[a-z0-9_]+)\s*\(", txt)))
 

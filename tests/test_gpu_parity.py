@@ -246,9 +246,10 @@ def test_device_synth_matches_host_and_device_resident_path(analyzer, oracle, ca
     assert alb.album_loudness_db == aw["album_loudness_db"] and alb.album_peak == aw["album_peak"]
 
 
-@pytest.mark.parametrize("where", ["start", "middle", "last_window", "both_channels"])
+@pytest.mark.parametrize("where", ["start", "middle", "last_window", "both_channels", "window_end", "window_end_right", "track_end",
+                                   "segment_end_inside_window"])
 @pytest.mark.parametrize("what", ["nan", "inf"])
-@pytest.mark.parametrize("mode", ["variant2", "variant1", "auto_96k"])
+@pytest.mark.parametrize("mode", ["variant2", "variant2_multi4", "variant2_short", "variant1", "auto_96k"])
 def test_non_finite_samples_poison_the_rest_of_the_track(_ctx, oracle, where, what, mode):
     """A NaN (or an Inf, which turns into NaN one subtraction later) leaves the reference's filter state NaN for the
     rest of the track: every window from there on is a NaN window and lands in bin 2000 (`NaN as i32` = 0,
@@ -258,16 +259,28 @@ def test_non_finite_samples_poison_the_rest_of_the_track(_ctx, oracle, where, wh
     import mp3rgain_amd as rg
 
     an = _ctx
-    an.set_kernel({"variant2": 2, "variant1": 1, "auto_96k": 0}[mode])
-    for key in (1, 2, 3):
+    an.set_kernel({"variant2": 2, "variant2_multi4": 2, "variant2_short": 2, "variant1": 1, "auto_96k": 0}[mode])
+    for key in (1, 2, 3, 4):
         an.set_tuning(key, 0)
+    if mode == "variant2_multi4":    # four windows per segment: the bad window can be a plain-energy window of its lane
+        an.set_tuning(2, 1)
+        an.set_tuning(4, 4)
+    elif mode == "variant2_short":   # many segments per window: the bad segment can sit inside its window
+        an.set_tuning(2, 1 << 40)
     rate = 96000 if mode == "auto_96k" else 44100
     n = rate * 4 + 1234
     l, r = oracle.synth_f32(91, 0, rate, n).copy(), oracle.synth_f32(91, 1, rate, n).copy()
     bad = np.float32(np.nan) if what == "nan" else np.float32(np.inf)
     W = rate // 20
-    at = {"start": 0, "middle": W * 37 + 1000, "last_window": n - 50, "both_channels": W * 11 + 5}[where]
-    l[at] = bad
+    # "window_end": the very last frame of a window.  An Inf there leaves the reference's sum at +Inf (the NaN comes one
+    # frame later, in the next window): `val as i32` saturates, the index wraps and that one window is DROPPED, not
+    # counted in bin 2000 (src/replaygain.rs:749-759).  "track_end": the same in the partial last window.
+    at = {"start": 0, "middle": W * 37 + 1000, "last_window": n - 50, "both_channels": W * 11 + 5, "window_end": W * 38 - 1,
+          "window_end_right": W * 38 - 1, "track_end": n - 1, "segment_end_inside_window": W * 37 + W // 5 - 1}[where]
+    if where == "window_end_right":
+        r[at] = -bad
+    else:
+        l[at] = bad
     if where == "both_channels":
         r[at + 3000] = -bad
     clean_l, clean_r = oracle.synth_f32(92, 0, rate, n), oracle.synth_f32(92, 1, rate, n)
@@ -282,8 +295,12 @@ def test_non_finite_samples_poison_the_rest_of_the_track(_ctx, oracle, where, wh
         assert got[0].flags & 1 and not got[1].flags & 1  # RG_TRACK_FLAG_NONFINITE
         ok, hc = an.analyze_tracks([rg.PcmTrack([clean_l, clean_r], rate)], return_histograms=True)
         assert np.array_equal(hc[0], cwh)
-    assert wh[2000] >= (n - at) // W  # the poisoned windows really are in bin 2000
+    assert wh[2000] >= (n - at) // W - 1  # the poisoned windows really are in bin 2000
+    if what == "inf" and where in ("window_end", "window_end_right"):
+        assert wh.sum() == n // W and wh[2000] == (n - at) // W + 1  # 81 windows, one dropped; all later ones (partial included) NaN
     an.set_kernel(0)
+    for key in (1, 2, 3, 4):
+        an.set_tuning(key, 0)
 
 
 def _random_cases(count, seed=20260928):
