@@ -306,6 +306,13 @@ int rg_find_peak_amplitude(rg_ctx *ctx, const char *path, rg_peak_result *out);
  * to the host: same outputs as rg_mp3_decode_f32 of mp3rgain_amd_dec.h, bit for bit.  `info` is an rg_mp3_stream_info. */
 int rg_mp3_decode_device(rg_ctx *ctx, const void *data, size_t len, float *ch0, float *ch1, uint64_t capacity, void *info);
 
+/* Measurement hook: the device decode chain alone on `copies` copies of one stream (one chunk of the default route), each of
+ * its four kernels bracketed with HIP events on their own stream: ms_out[0..3] = frame parser, Huffman, hybrid, synthesis
+ * (average of `reps` repetitions), ms_out[4] = the chain.  units = granule-channels, frames = PCM frames per channel decoded
+ * per repetition, compressed_bytes = main data + slots the chain reads. */
+int rg_mp3_decode_bench(rg_ctx *ctx, const void *data, size_t len, uint32_t copies, uint32_t reps, double *ms_out,
+                        uint64_t *units_out, uint64_t *compressed_bytes_out, uint64_t *frames_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -139,6 +139,7 @@ SYMBOLS = [
     ("rg_tracks_error", C.c_char_p, [_vp, C.c_size_t]),
     ("rg_find_peak_amplitude", _int, [_vp, C.c_char_p, _P(PeakResult)]),
     ("rg_mp3_decode_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    ("rg_mp3_decode_bench", _int, [_vp, _vp, _sz, _u32, _u32, _P(_dbl), _P(_u64), _P(_u64), _P(_u64)]),
     ("rg_analyze_album_begin", _int, [_vp, _P(C.c_char_p), _sz, _i32, _P(TrackResult), _P(_sz)]),
     # include/mp3rgain_amd_node.h
     ("rg_node_create", _vp, [_P(_int), _sz]),

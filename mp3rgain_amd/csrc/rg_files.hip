@@ -1233,6 +1233,97 @@ extern "C" int rg_find_peak_amplitude(rg_ctx *c, const char *path, rg_peak_resul
     return rg_find_peak_pcm(c, &descs[0], c->d_arena.p, arena_bytes, 1, out);
 }
 
+// Measurement hook (bench.py, tools/): the device decode chain alone.  `copies` copies of one MPEG Layer III stream form ONE
+// chunk of the default route (compacted by the host once, staged in pinned memory, copied H2D per repetition on the copy
+// stream), and the chunk's four kernels -- frame parser, Huffman, hybrid, synthesis -- are bracketed with HIP events on the
+// stream they run on.  ms_out[0..3] = average duration of each kernel over `reps` repetitions, ms_out[4] = first event to
+// last (the chain); the PCM lands in the analysis arena as in a real call and is not copied back.
+extern "C" int rg_mp3_decode_bench(rg_ctx *c, const void *data, size_t len, uint32_t copies, uint32_t reps, double *ms_out /* 5 */,
+                                   uint64_t *units_out, uint64_t *compressed_bytes_out, uint64_t *frames_out) {
+    if (!c || !data || !ms_out || copies == 0 || reps == 0) return RG_ERR_INVALID_ARG;
+    int rc = rg_bind_device(c);
+    if (rc != RG_OK) return rc;
+    Mp3Pipe &P = mp3_pipe(c);
+    if (P.scratch.empty()) P.scratch.resize(1);
+    Mp3Scratch &sc = P.scratch[0];
+    if (sc.cap < len + 64) {
+        uint8_t *q = static_cast<uint8_t *>(realloc(sc.p, len + 64));
+        if (!q) return rg_set_err(c, RG_ERR_IO, "out of memory");
+        sc.p = q;
+        sc.cap = len + 64;
+    }
+    memcpy(sc.p, data, len);
+    memset(sc.p + len, 0, 64);
+    rg_mp3_stream_info si;
+    uint64_t main_len = 0;
+    if (rg_mp3_compact_stream(sc.p, len, &sc.slots, &sc.tiles, &main_len, &si) != RG_MP3DEC_OK)
+        return rg_set_err(c, RG_ERR_FORMAT, "%s", rg_mp3dec_last_error());
+    for (int s = 0; s < c->n_slots; ++s) RG_HIP(c, hipStreamSynchronize(c->slots[s].stream));
+    const size_t per_stream = (size_t)si.frames * si.channels * sizeof(float);
+    RG_HIP(c, c->d_arena.reserve(per_stream * copies + 64));
+    const size_t one = align64((size_t)main_len + 8) + align64(sc.slots.size()) + align64(sc.tiles.size() * sizeof(uint64_t));
+    const size_t tracks_off = one * copies;
+    const size_t total = tracks_off + rg_mp3dev_track_bytes(copies);
+    Mp3Stage &st = P.stage[0];
+    if (!st.staged) RG_HIP(c, hipEventCreateWithFlags(&st.staged, hipEventDisableTiming));
+    if (st.cap < total) {
+        if (st.p) (void)hipHostFree(st.p);
+        st.p = nullptr;
+        st.cap = 0;
+        RG_HIP(c, hipHostMalloc((void **)&st.p, total + total / 8, hipHostMallocDefault));
+        st.cap = total + total / 8;
+    }
+    std::vector<RgMp3StreamItem> items(copies);
+    for (uint32_t k = 0; k < copies; ++k) {
+        RgMp3StreamItem &it = items[k];
+        it.main_off = one * k;
+        it.slots_off = it.main_off + align64((size_t)main_len + 8);
+        it.tiles_off = it.slots_off + align64(sc.slots.size());
+        memcpy(st.p + it.main_off, sc.p, (size_t)main_len);
+        memset(st.p + it.main_off + main_len, 0, (size_t)(it.slots_off - it.main_off - main_len));
+        memcpy(st.p + it.slots_off, sc.slots.data(), sc.slots.size());
+        memcpy(st.p + it.tiles_off, sc.tiles.data(), sc.tiles.size() * sizeof(uint64_t));
+        it.n_frames = si.audio_frames;
+        it.channels = si.channels;
+        it.rate_row = (uint32_t)rg_mp3_rate_row(si.sample_rate);
+        it.lsf = si.mpeg_version == 1 ? 0u : 1u;
+        it.result_index = k;
+        it.d_ch0 = reinterpret_cast<float *>(c->d_arena.p + per_stream * k);
+    }
+    hipStream_t fs = c->slot().stream;
+    // one set of events per repetition: the repetitions are enqueued back to back (a synchronise after each would let the
+    // clocks fall between them) and read out at the end
+    if (reps > 256) reps = 256;
+    std::vector<hipEvent_t> ev((size_t)5 * (reps + 1), nullptr);
+    for (hipEvent_t &e : ev) RG_HIP(c, hipEventCreate(&e));
+    double sum[5] = {0, 0, 0, 0, 0};
+    rc = rg_mp3dev_reserve_results(c, copies, fs);
+    for (uint32_t r = 0; r < reps + 1 && rc == RG_OK; ++r) {  // the first repetition is not counted
+        c->mp3_bench_ev = &ev[(size_t)5 * r];
+        rc = rg_mp3dev_enqueue_chunk(c, (int)(r & 1), st.p, total, tracks_off, st.staged, items.data(), copies, fs);
+        c->mp3_bench_ev = nullptr;
+    }
+    if (rc == RG_OK && hipStreamSynchronize(fs) != hipSuccess) rc = rg_set_err(c, RG_ERR_DEVICE, "decode bench: stream synchronise failed");
+    for (uint32_t r = 1; r < reps + 1 && rc == RG_OK; ++r) {
+        for (int k = 0; k < 4; ++k) {
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, ev[(size_t)5 * r + k], ev[(size_t)5 * r + k + 1]);
+            sum[k] += ms;
+        }
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, ev[(size_t)5 * r], ev[(size_t)5 * r + 4]);
+        sum[4] += ms;
+    }
+    for (hipEvent_t &e : ev) (void)hipEventDestroy(e);
+    if (rc != RG_OK) return rc;
+    for (int k = 0; k < 5; ++k) ms_out[k] = sum[k] / reps;
+    const uint64_t per_frame = si.mpeg_version == 1 ? 2u : 1u;
+    if (units_out) *units_out = (uint64_t)si.audio_frames * per_frame * si.channels * copies;
+    if (compressed_bytes_out) *compressed_bytes_out = (uint64_t)(main_len + sc.slots.size()) * copies;
+    if (frames_out) *frames_out = (uint64_t)si.frames * copies;
+    return RG_OK;
+}
+
 // Decode one MPEG Layer III stream through the split decoder (stage A on the host, B-E on the device) and bring the PCM
 // back: the parity hook of tests/test_gpu_mp3.py.  Same outputs as rg_mp3_decode_f32.
 extern "C" int rg_mp3_decode_device(rg_ctx *c, const void *data, size_t len, float *ch0, float *ch1, uint64_t capacity,

@@ -62,3 +62,70 @@ RG_MP3_HD void rg_mp3_matrixing(const float *S /* 32 */, Out &&V, const float *s
 #pragma unroll
     for (int i = 49; i < 64; ++i) V[i] = -A[i - 48];
 }
+
+// ---- 36-point IMDCT of a long block, fast -------------------------------------------------------------------------
+// x[i] = sum_k X[k] cos(pi/72 (2i + 1 + 18)(2k + 1)), i = 0..35, has x[17 - i] = -x[i] and x[35 - j] = x[18 + j]; the
+// eighteen independent samples are an 18-point DCT-IV,  t[n] = sum_k X[k] cos(pi/72 (2n + 1)(2k + 1)):
+//     x[i] = t[9 + i] (i = 0..8),   x[18 + j] = -t[8 - j] (j = 0..8).
+// The DCT-IV goes through a 9-point complex DFT (ISO 11172-3 leaves the method open; this is the textbook route):
+//     z[k] = (X[2k] + i X[17 - 2k]) e^{-i pi (4k + 1) / 72},   Z = DFT_9(z) as 3 x 3 radix-3 butterflies,
+//     t[2k] = Re(Z[k] e^{-i pi k / 18}),   t[17 - 2k] = -Im(Z[k] e^{-i pi k / 18})
+// -- 156 multiply / add / fused operations instead of 324 multiply-adds.  Every fused operation is an explicit rg_mp3_mac,
+// so host and device produce the same bits.
+struct RgMp3Cx { float r, i; };
+RG_MP3_HD RgMp3Cx rg_mp3_cmul(const RgMp3Cx a, const float wr, const float wi) {
+    return RgMp3Cx{rg_mp3_mac(a.r, wr, -(a.i * wi)), rg_mp3_mac(a.r, wi, a.i * wr)};
+}
+// 3-point DFT, W = e^{-2 pi i / 3}
+RG_MP3_HD void rg_mp3_dft3(const RgMp3Cx x0, const RgMp3Cx x1, const RgMp3Cx x2, RgMp3Cx &y0, RgMp3Cx &y1, RgMp3Cx &y2) {
+    const float s3 = 0.866025388f;  // sqrt(3) / 2
+    const float sr = x1.r + x2.r, si = x1.i + x2.i, dr = x1.r - x2.r, di = x1.i - x2.i;
+    const float mr = rg_mp3_mac(-0.5f, sr, x0.r), mi = rg_mp3_mac(-0.5f, si, x0.i);
+    y0 = RgMp3Cx{x0.r + sr, x0.i + si};
+    y1 = RgMp3Cx{rg_mp3_mac(s3, di, mr), rg_mp3_mac(-s3, dr, mi)};
+    y2 = RgMp3Cx{rg_mp3_mac(-s3, di, mr), rg_mp3_mac(s3, dr, mi)};
+}
+RG_MP3_HD void rg_mp3_dct4_18(const float *X /* 18 */, float *t /* 18 */) {
+    RgMp3Cx z[9];
+    z[0] = rg_mp3_cmul(RgMp3Cx{X[0], X[17]}, 0.999048233f, -0.0436193869f);
+    z[1] = rg_mp3_cmul(RgMp3Cx{X[2], X[15]}, 0.976296008f, -0.21643962f);
+    z[2] = rg_mp3_cmul(RgMp3Cx{X[4], X[13]}, 0.923879504f, -0.382683426f);
+    z[3] = rg_mp3_cmul(RgMp3Cx{X[6], X[11]}, 0.843391418f, -0.537299633f);
+    z[4] = rg_mp3_cmul(RgMp3Cx{X[8], X[9]}, 0.737277329f, -0.675590217f);
+    z[5] = rg_mp3_cmul(RgMp3Cx{X[10], X[7]}, 0.60876143f, -0.793353319f);
+    z[6] = rg_mp3_cmul(RgMp3Cx{X[12], X[5]}, 0.4617486f, -0.887010813f);
+    z[7] = rg_mp3_cmul(RgMp3Cx{X[14], X[3]}, 0.300705791f, -0.953716934f);
+    z[8] = rg_mp3_cmul(RgMp3Cx{X[16], X[1]}, 0.130526185f, -0.991444886f);
+    RgMp3Cx F[3][3], Z[9];
+    rg_mp3_dft3(z[0], z[3], z[6], F[0][0], F[0][1], F[0][2]);
+    rg_mp3_dft3(z[1], z[4], z[7], F[1][0], F[1][1], F[1][2]);
+    rg_mp3_dft3(z[2], z[5], z[8], F[2][0], F[2][1], F[2][2]);
+    rg_mp3_dft3(F[0][0], F[1][0], F[2][0], Z[0], Z[3], Z[6]);
+    rg_mp3_dft3(F[0][1], rg_mp3_cmul(F[1][1], 0.766044438f, -0.642787635f), rg_mp3_cmul(F[2][1], 0.173648179f, -0.98480773f), Z[1], Z[4], Z[7]);
+    rg_mp3_dft3(F[0][2], rg_mp3_cmul(F[1][2], 0.173648179f, -0.98480773f), rg_mp3_cmul(F[2][2], -0.939692616f, -0.342020154f), Z[2], Z[5], Z[8]);
+    t[0] = Z[0].r;
+    t[17] = -Z[0].i;
+    { const RgMp3Cx y = rg_mp3_cmul(Z[1], 0.98480773f, -0.173648179f); t[2] = y.r; t[15] = -y.i; }
+    { const RgMp3Cx y = rg_mp3_cmul(Z[2], 0.939692616f, -0.342020154f); t[4] = y.r; t[13] = -y.i; }
+    { const RgMp3Cx y = rg_mp3_cmul(Z[3], 0.866025388f, -0.5f); t[6] = y.r; t[11] = -y.i; }
+    { const RgMp3Cx y = rg_mp3_cmul(Z[4], 0.766044438f, -0.642787635f); t[8] = y.r; t[9] = -y.i; }
+    { const RgMp3Cx y = rg_mp3_cmul(Z[5], 0.642787635f, -0.766044438f); t[10] = y.r; t[7] = -y.i; }
+    { const RgMp3Cx y = rg_mp3_cmul(Z[6], 0.5f, -0.866025388f); t[12] = y.r; t[5] = -y.i; }
+    { const RgMp3Cx y = rg_mp3_cmul(Z[7], 0.342020154f, -0.939692616f); t[14] = y.r; t[3] = -y.i; }
+    { const RgMp3Cx y = rg_mp3_cmul(Z[8], 0.173648179f, -0.98480773f); t[16] = y.r; t[1] = -y.i; }
+}
+
+// The 36 windowed samples of a long block (block types 0, 1, 3) from its 18 lines:  raw[i] = x[i] * win[i].
+template <typename Out>
+RG_MP3_HD void rg_mp3_imdct36_windowed(const float *X /* 18 */, const float *win /* 36 */, Out &&raw /* 36 */) {
+    float t[18];
+    rg_mp3_dct4_18(X, t);
+#pragma unroll
+    for (int m = 0; m < 9; ++m) {
+        const float a = t[9 + m], b = t[8 - m];
+        raw[m] = a * win[m];
+        raw[17 - m] = -a * win[17 - m];
+        raw[18 + m] = -b * win[18 + m];
+        raw[35 - m] = -b * win[35 - m];
+    }
+}

@@ -698,19 +698,9 @@ void hybrid(const float xr[576], const Granule &g, ChannelState &cs, const Table
         float raw[36];
         const int bt = (g.block_type == 2 && g.mixed && sb < 2) ? 0 : g.block_type;
         if (bt != 2) {
-            // x[17 - i] = -x[i] and x[35 - j] = x[18 + j]: eighteen dot products give all 36 samples
-            for (int p = 0; p < 18; ++p) {
-                const int i = p < 9 ? p : 9 + p;  // 0..8, 18..26
-                float s = 0.0f;
-                for (int k = 0; k < 18; ++k) s = rg_mp3_mac(X[k], T.imdct36[i][k], s);
-                if (p < 9) {
-                    raw[i] = s * T.win[bt][i];
-                    raw[17 - i] = -s * T.win[bt][17 - i];
-                } else {
-                    raw[i] = s * T.win[bt][i];
-                    raw[53 - i] = s * T.win[bt][53 - i];
-                }
-            }
+            // x[17 - i] = -x[i] and x[35 - j] = x[18 + j]: an 18-point DCT-IV gives all 36 samples (rg_mp3_math.h, shared
+            // with the device decoder)
+            rg_mp3_imdct36_windowed(X, T.win[bt], raw);
         } else {
             for (int i = 0; i < 36; ++i) raw[i] = 0.0f;
             for (int w = 0; w < 3; ++w)

@@ -88,8 +88,6 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
     __shared__ short band_mode[64];
     // the constants the block's loops read, copied once: a look-up in LDS returns in a tenth of the time of one in memory,
     // and the loops below are chains of look-up -> arithmetic -> next look-up
-    // (the 18 rows of the long IMDCT that are used -- samples 0..8 and 18..26 -- in rows of 20 words: 16-byte reads)
-    __shared__ __attribute__((aligned(16))) float c36[18][20];
     __shared__ float c12[12][6], wn[4][36], cs_l[8], ca_l[8];
     __shared__ uint8_t ptab[24];
     const int tid = threadIdx.x;
@@ -114,7 +112,6 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
         rq_raw = *reinterpret_cast<const uint4 *>(is + (u0 + rq_c) * 576 + rq_l0);
         rq_lb = *reinterpret_cast<const uint2 *>(&T->long_band_of_line[rr][rq_l0]);
     }
-    for (int e = tid; e < 18 * 18; e += 256) c36[e / 18][e % 18] = T->imdct36[e / 18 < 9 ? e / 18 : e / 18 + 9][e % 18];
     if (tid < 144) (&wn[0][0])[tid] = (&T->win[0][0])[tid];
     if (tid < 72) (&c12[0][0])[tid] = (&T->imdct12[0][0])[tid];
     if (tid < 8) { cs_l[tid] = T->cs[tid]; ca_l[tid] = T->ca[tid]; }
@@ -300,57 +297,51 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
             X[sb * 18 + i] = b * cs_l[i] + a * ca_l[i];
         }
         __syncthreads();
-        // long blocks: x[17 - i] = -x[i], x[35 - j] = x[18 + j] -- eighteen dot products per subband give all 36 samples
-        // (the host computes exactly these eighteen); short blocks: each of the 36 samples on its own
-        // consecutive threads take consecutive subbands of one sample index: the table row is a broadcast, the stores
-        // to hyb[unit][half][t][sb] are whole 128-byte lines
-        // a thread's subband is the same in every turn of the loop (256 is a multiple of 32): its eighteen lines stay in
-        // registers, and a row of coefficients comes in five 16-byte reads -- per dot product 5 LDS reads instead of 36
-        float xs[18];
-        {
-            const float *Xr = X + (tid & 31) * 18;
+    }
+    // ---- IMDCT + window.  Long subbands (block types 0, 1, 3, and the two lowest of a mixed block): one thread per
+    // (channel, subband) runs the fast 36-point IMDCT of rg_mp3_math.h -- the code the host decoder runs -- on its eighteen
+    // lines; consecutive threads are consecutive subbands, so every store to hyb[unit][half][t][sb] is a whole 128-byte line.
+    if (tid < 32 * nch) {
+        const int c = tid >> 5, sb = tid & 31;
+        const rg_mp3_unit &u = U[c];
+        const int bt = (u.block_type == 2 && u.mixed && sb < 2) ? 0 : (int)u.block_type;
+        if (bt != 2) {
+            float xs[18];
+            const float *Xr = xr[c] + sb * 18;
 #pragma unroll
             for (int k = 0; k < 18; ++k) xs[k] = Xr[k];
+            struct Store {
+                float *__restrict__ base;  // hyb[unit][0][0][sb]
+                struct Ref {
+                    float *p;
+                    __device__ __forceinline__ void operator=(float v) { *p = v; }
+                };
+                __device__ __forceinline__ Ref operator[](int i) { return Ref{base + (size_t)i * 32}; }  // [half][t] is i = 18 half + t
+            } out{hyb + hyb_index(u0 + c, 0, 0, sb)};
+            rg_mp3_imdct36_windowed(xs, wn[bt], out);
         }
+    }
+    // Short subbands: each of the 36 samples on its own; consecutive threads take consecutive subbands of one sample index
+    for (int c = 0; c < nch; ++c) {
+        const rg_mp3_unit &u = U[c];
+        if (u.block_type != 2) continue;
         for (int o = tid; o < 32 * 36; o += 256) {
-            const int sb = o & 31, i36 = o >> 5;
-            const float *Xs = xs;
-            const int bt = (u.block_type == 2 && u.mixed && sb < 2) ? 0 : (int)u.block_type;
-            if (bt != 2) {
-                if (i36 >= 18) continue;  // eighteen workers per subband
-                const int p = i36;
-                const int i = p < 9 ? p : 9 + p;  // 0..8, 18..26
-                float cf[20];
+            const int sb = o & 31, i = o >> 5;
+            if (u.mixed && sb < 2) continue;
+            const float *Xs = xr[c] + sb * 18;
+            float raw = 0.0f;
 #pragma unroll
-                for (int k = 0; k < 20; k += 4) {
-                    const float4 q4 = *reinterpret_cast<const float4 *>(&c36[p][k]);
-                    cf[k] = q4.x; cf[k + 1] = q4.y; cf[k + 2] = q4.z; cf[k + 3] = q4.w;
+            for (int w = 0; w < 3; ++w) {
+                const int ii = i - 6 - 6 * w;
+                if (ii >= 0 && ii < 12) {
+                    float s2 = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) s2 = rg_mp3_mac(Xs[3 * k + w], c12[ii][k], s2);
+                    raw = rg_mp3_mac(s2, wn[2][ii], raw);
                 }
-                float s = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 18; ++k) s = rg_mp3_mac(Xs[k], cf[k], s);
-                const int j = p < 9 ? 17 - i : 53 - i;  // the mirrored sample
-                const float a = s * wn[bt][i];
-                const float b = (p < 9 ? -s : s) * wn[bt][j];
-                hyb[hyb_index(u0 + c, i < 18 ? 0 : 1, i < 18 ? i : i - 18, sb)] = a;
-                hyb[hyb_index(u0 + c, j < 18 ? 0 : 1, j < 18 ? j : j - 18, sb)] = b;
-            } else {
-                const int i = i36;
-                float raw = 0.0f;
-#pragma unroll
-                for (int w = 0; w < 3; ++w) {
-                    const int ii = i - 6 - 6 * w;
-                    if (ii >= 0 && ii < 12) {
-                        float s2 = 0.0f;
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) s2 = rg_mp3_mac(Xs[3 * k + w], c12[ii][k], s2);
-                        raw = rg_mp3_mac(s2, wn[2][ii], raw);
-                    }
-                }
-                hyb[hyb_index(u0 + c, i < 18 ? 0 : 1, i < 18 ? i : i - 18, sb)] = raw;
             }
+            hyb[hyb_index(u0 + c, i < 18 ? 0 : 1, i < 18 ? i : i - 18, sb)] = raw;
         }
-        __syncthreads();
     }
 }
 
@@ -361,10 +352,11 @@ __global__ void __launch_bounds__(256)
 rg_mp3_synth_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks,
                     const float *__restrict__ hyb) {
     constexpr int R = RG_MP3_SYNTH_RUN, SLOTS = 15 + 18 * R;
-    // rows padded by one word: the matrixing below has every thread walk its own row, and rows 32 / 64 words apart
-    // would all start in the same LDS bank
-    __shared__ float S[SLOTS][33];   // subband samples of time slots -15 .. 18 R - 1 relative to the run's first granule
-    __shared__ float V[SLOTS][65];
+    // One array for both stages: row r first holds the subband samples of time slot r (-15 .. 18 R - 1 relative to the run's
+    // first granule), then -- overwritten by the one thread that read them -- the 32 outputs A of that slot's DCT, from
+    // which the 64 matrixing values V follow by symmetry (rg_mp3_math.h: rg_mp3_matrixing).  Rows are padded by one word
+    // (a thread per row walking rows 32 words apart would have every lane in the same LDS bank); the pad holds 0.0f = V[16].
+    __shared__ float S[SLOTS][33];
     const int tid = threadIdx.x;
     uint32_t lo = 0, hi = n_tracks - 1;
     while (lo < hi) {
@@ -427,24 +419,52 @@ rg_mp3_synth_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *_
     __syncthreads();
     // ---- polyphase synthesis: matrixing, one time slot per thread (rg_mp3dec.cpp: synth) ---------------------------
     if (tid < nslots) {
-        float x[32];
+        float x[32], A[32];
 #pragma unroll
         for (int k = 0; k < 32; ++k) x[k] = S[tid][k];
-        float *row = V[tid];
-        rg_mp3_matrixing(x, row, T->sec);
+        RgMp3Dct<32>::run(x, A, T->sec);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) S[tid][k] = A[k];
+        S[tid][32] = 0.0f;
     }
     __syncthreads();
-    float *__restrict__ dst = (c == 0 ? tr.ch0 : tr.ch1) + (size_t)g0 * 576;
-    for (int e = tid; e < ng * 576; e += 256) {
-        const int slot = e / 32;   // slot = 18 * granule + t; the sample within the slot is this thread's wj
-        const int r = 15 + slot;
-        float s = 0.0f;
+    // ---- the 512-tap window.  PCM sample j of time slot r is  sum_{i<8} V[r-2i][j] D[64i+j] + V[r-2i-1][32+j] D[64i+32+j]
+    // in that order (the host's).  V[.][j] = A[.][16+j] (j < 16), 0 (j = 16), -A[.][48-j] (j > 16); V[.][32+j] = -A[.][16-j]
+    // (j < 16), -A[.][0] (j = 16), -A[.][j-16] (j > 16): per thread two fixed columns of A, the signs folded into its sixteen
+    // window coefficients (fma(-a, d, s) and fma(a, -d, s) are the same bits).  A thread owns sample j = tid % 32 of up to
+    // fourteen consecutive time slots and keeps the rows they share in registers: 2 LDS reads per output instead of 16.
+    {
+        constexpr int PER = (18 * R + 7) / 8;  // time slots per group of 32 threads
+        const int col1 = wj < 16 ? 16 + wj : (wj == 16 ? 32 : 48 - wj);
+        const int col2 = wj < 16 ? 16 - wj : wj - 16;
+        float D1[8], D2[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            s = rg_mp3_mac(V[r - 2 * i][wj], Dw[2 * i], s);
-            s = rg_mp3_mac(V[r - 2 * i - 1][32 + wj], Dw[2 * i + 1], s);
+            D1[i] = wj > 16 ? -Dw[2 * i] : Dw[2 * i];
+            D2[i] = -Dw[2 * i + 1];
         }
-        dst[e] = s;
+        const int s0 = (tid >> 5) * PER;              // first time slot of this thread, relative to granule g0
+        const int ns = ng * 18 - s0 < PER ? ng * 18 - s0 : PER;
+        if (ns > 0) {
+            float c1[PER + 15], c2[PER + 15];         // rows s0 .. s0 + PER + 14 of S (time slots s0 - 15 .. s0 + PER - 1)
+#pragma unroll
+            for (int q = 0; q < PER + 15; ++q) {
+                const bool live = q < ns + 15;
+                c1[q] = live ? S[s0 + q][col1] : 0.0f;
+                c2[q] = live ? S[s0 + q][col2] : 0.0f;
+            }
+            float *__restrict__ dst = (c == 0 ? tr.ch0 : tr.ch1) + (size_t)g0 * 576 + (size_t)s0 * 32 + wj;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                float s = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    s = rg_mp3_mac(c1[q + 15 - 2 * i], D1[i], s);
+                    s = rg_mp3_mac(c2[q + 15 - 2 * i - 1], D2[i], s);
+                }
+                if (q < ns) dst[(size_t)q * 32] = s;
+            }
+        }
     }
 }
 

@@ -213,12 +213,18 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
         const RgMp3DevHuff *d_huff = reinterpret_cast<const RgMp3DevHuff *>(c->d_mp3_huff.p);
         const RgMp3DevTables *d_tab = reinterpret_cast<const RgMp3DevTables *>(c->d_mp3_tab.p);
         RgMp3HuffRec *d_recs = reinterpret_cast<RgMp3HuffRec *>(c->d_mp3_recs.p);
+        hipEvent_t *ev = c->mp3_bench_ev;  // measurement hook (rg_mp3_decode_bench): the kernels' boundaries on their own stream
+        if (ev) RG_HIP(c, hipEventRecord(ev[0], s));
         RG_HIP(c, rg_launch_mp3_frames(d_tr, (uint32_t)n, tb, d_chunk, c->d_mp3_tiles.p, d_recs, c->d_mp3_results.p, s));
+        if (ev) RG_HIP(c, hipEventRecord(ev[1], s));
         RG_HIP(c, rg_launch_mp3_huffman(d_tab, d_huff, d_tr, (uint32_t)n, d_recs, d_chunk, reinterpret_cast<rg_mp3_unit *>(c->d_mp3_units.p),
                                         c->d_mp3_is.p, ub, s));
+        if (ev) RG_HIP(c, hipEventRecord(ev[2], s));
         RG_HIP(c, rg_launch_mp3_hybrid(d_tab, d_tr, (uint32_t)n, gb, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p), c->d_mp3_is.p,
                                        c->d_mp3_hyb.p, s));
+        if (ev) RG_HIP(c, hipEventRecord(ev[3], s));
         RG_HIP(c, rg_launch_mp3_synth(d_tab, d_tr, (uint32_t)n, sb, c->d_mp3_hyb.p, s));
+        if (ev) RG_HIP(c, hipEventRecord(ev[4], s));
     }
     RG_HIP(c, hipEventRecord(c->mp3_set_free[set], s));
     c->mp3_set_used[set] = true;
