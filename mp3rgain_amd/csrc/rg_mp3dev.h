@@ -9,7 +9,7 @@
 #define RG_MP3_GAIN_Q_MIN (-512)   // requantisation gains 2^(q/4) are tabulated for q in [RG_MP3_GAIN_Q_MIN, RG_MP3_GAIN_Q_MAX]
 #define RG_MP3_GAIN_Q_MAX 64
 #define RG_MP3_HUFF_LDS_ENTRIES 7808  // room for the flattened Huffman tables in the Huffman kernel's LDS (they have 7752 entries)
-#define RG_MP3_SYNTH_RUN 6        // consecutive granules of one channel per block of the synthesis kernel
+#define RG_MP3_SYNTH_RUN 6        // consecutive granules per block of the hybrid kernel (both channels) and of the synthesis kernel (one)
 
 // Every constant the device stages use, built once on the host from the very tables the host decoder uses, so that
 // the two halves work with identical numbers.
@@ -75,7 +75,7 @@ struct RgMp3DevTrack {
     uint32_t channels;
     uint32_t rate_row;
     uint32_t lsf;
-    uint32_t reserved_;
+    uint32_t hrun_base;      // first block of the track in the hybrid kernel's grid (one block per run of RG_MP3_SYNTH_RUN granules)
     float *ch0;              // PCM outputs (planar); 576 frames per granule
     float *ch1;
     uint64_t main_base;      // device Huffman stage: byte offset of the track's main-data stream in the chunk buffer

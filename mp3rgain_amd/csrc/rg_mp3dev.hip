@@ -70,130 +70,307 @@ struct DevBits {
 }  // namespace
 
 namespace {
-// hyb[unit][half][t][sb]
-__device__ __forceinline__ size_t hyb_index(uint64_t unit, int half, int t, int sb) {
-    return (((size_t)unit * 2 + (size_t)half) * 18 + (size_t)t) * 32 + (size_t)sb;
+// finished subband samples: sub[unit][t][sb], t = time slot 0..17 of the granule
+__device__ __forceinline__ size_t sub_index(uint64_t unit, int t, int sb) {
+    return ((size_t)unit * 18 + (size_t)t) * 32 + (size_t)sb;
 }
 
 }  // namespace
 
-__global__ void __launch_bounds__(256)
+// One block = a run of up to RG_MP3_SYNTH_RUN consecutive granules of one track, both channels.  The block is a two-stage
+// pipeline over the run's granules with ONE barrier per granule in the common case:
+//   wave 1     requantises granule k (and applies plain mid/side stereo) into one half of a double-buffered spectrum,
+//   wave 0     thread (channel, subband) takes granule k-1 out of the other half: alias reduction folded into the load of
+//              its eighteen lines, the IMDCT (the fast 36-point one of rg_mp3_math.h -- the code the host runs -- or three
+//              12-point ones for a short block), window, overlap-add with the second half it kept from the granule before,
+//              frequency inversion, store.
+// What leaves the kernel are FINISHED subband samples, 2304 bytes per granule and channel; a run that starts inside the
+// track first takes the granule before it through the same stages for its overlap alone.  Granules that need more than
+// that between requantisation and IMDCT -- intensity stereo, short-block reordering -- get it from both waves in extra
+// barrier-separated steps, exactly as the one-granule-per-block kernel of round 2 did it.  Everything a granule's stages
+// look up lives in LDS (copied once per run); units and quantised spectra are fetched one granule ahead.  Two waves per
+// block, because the IMDCT wave is the long pole of a step and the register file has room for sixteen waves per CU: eight
+// blocks, eight IMDCT waves in flight.
+// (Round 2: a block was one granule, six barrier-separated stages, both IMDCT halves through memory to the synthesis
+// kernel, the prologue -- track look-up, tables into LDS -- once per granule: 0.68 ms per 256 K units, now 0.3.)
+#define RG_MP3_HYB_THREADS 128
+// 128 VGPRs: four waves per SIMD, eight blocks per CU (A/B on one board: 0.586 ms per 256 K units against 0.646 at the 144
+// registers the compiler takes when left alone, and 0.614 with the overlap prefetched into registers and 12 bytes spilled)
+#define RG_HYB_WAVES 4
+#define RG_HYB_OVPREF 0
+__global__ void __launch_bounds__(RG_MP3_HYB_THREADS) __attribute__((amdgpu_waves_per_eu(RG_HYB_WAVES)))
 rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks,
-                     const rg_mp3_unit *__restrict__ units, const int16_t *__restrict__ is, float *__restrict__ hyb) {
-    __shared__ float xr[2][576];
+                     const rg_mp3_unit *__restrict__ units, const int16_t *__restrict__ is, float *__restrict__ sub) {
+    constexpr int R = RG_MP3_SYNTH_RUN;
+    __shared__ float xrb[2][2][576];   // [buffer][channel][line]
     __shared__ float tmp[576];
-    __shared__ rg_mp3_unit U[2];
-    __shared__ float gain_long[2][22], gain_short[2][39];
+    __shared__ __attribute__((aligned(16))) rg_mp3_unit Ub[3][2];  // units of the granules in the pipeline, slot = step % 3
     __shared__ int band_nz[64];
     __shared__ short band_mode[64];
-    // the constants the block's loops read, copied once: a look-up in LDS returns in a tenth of the time of one in memory,
-    // and the loops below are chains of look-up -> arithmetic -> next look-up
     __shared__ float c12[12][6], wn[4][36], cs_l[8], ca_l[8];
     __shared__ uint8_t ptab[24];
+    // the overlap: the second half of the previous granule's 36 windowed samples, one column per IMDCT thread (read and
+    // written by that thread alone; in registers it cost the kernel half its occupancy)
+    __shared__ float ovl[18][64];
+    __shared__ float gain_l[RG_MP3_GAIN_Q_MAX - RG_MP3_GAIN_Q_MIN + 1];
+    constexpr int kPowLds = 512;       // x^(4/3) for the values that occur; larger ones go to the table in memory
+    __shared__ float pow_l[kPowLds];
+    __shared__ uint16_t sfbl_l[24], sfbs_l[16];
+    constexpr int NT = RG_MP3_HYB_THREADS;
     const int tid = threadIdx.x;
-    const uint32_t ti = find_by_granule(tracks, n_tracks, blockIdx.x);
+    uint32_t ti = 0;
+    {
+        uint32_t lo = 0, hi = n_tracks - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (tracks[mid].hrun_base <= blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        ti = lo;
+    }
     const RgMp3DevTrack tr = tracks[ti];
-    const uint32_t g = blockIdx.x - tr.granule_base;
-    if (g >= tr.n_granules) return;  // past what the device-side frame parser found decodable (block-uniform)
+    const uint32_t g0 = (blockIdx.x - tr.hrun_base) * R;
+    if (g0 >= tr.n_granules) return;  // past what the device-side frame parser found decodable (block-uniform)
+    const int ng = (int)(tr.n_granules - g0 < (uint32_t)R ? tr.n_granules - g0 : (uint32_t)R);
     const int nch = (int)tr.channels;
     const int rr = (int)tr.rate_row;
-    const uint64_t u0 = tr.unit_base + (uint64_t)g * nch;
-    if (tid < nch) U[tid] = units[u0 + tid];
-    if (tid < 64) { band_nz[tid] = 0; band_mode[tid] = 0; }
-    // The quantised spectrum is fetched here, eight lines (16 bytes) per thread, with the long-block band numbers of those
-    // lines: neither depends on the units, so they travel while the units arrive and the gains are worked out.  (Fetched
-    // line by line inside the requantisation loop, each value and the table entry it selects were two round trips to memory
-    // per line, one after the other: most of a block's lifetime.)
-    const bool rq = tid < nch * 72;
-    const int rq_c = tid / 72, rq_l0 = (tid % 72) * 8;
-    uint4 rq_raw = make_uint4(0u, 0u, 0u, 0u);
-    uint2 rq_lb = make_uint2(0u, 0u);
-    if (rq) {
-        rq_raw = *reinterpret_cast<const uint4 *>(is + (u0 + rq_c) * 576 + rq_l0);
-        rq_lb = *reinterpret_cast<const uint2 *>(&T->long_band_of_line[rr][rq_l0]);
-    }
-    if (tid < 144) (&wn[0][0])[tid] = (&T->win[0][0])[tid];
+    const int gi0 = g0 > 0 ? -1 : 0;   // first granule of the pipeline, relative to g0
+    const uint64_t ubase = tr.unit_base + (uint64_t)((long long)g0 + gi0) * nch;  // its first unit
+    const int nsteps = ng - gi0;       // granules through the pipeline
+    for (int e = tid; e < 144; e += NT) (&wn[0][0])[e] = (&T->win[0][0])[e];
     if (tid < 72) (&c12[0][0])[tid] = (&T->imdct12[0][0])[tid];
     if (tid < 8) { cs_l[tid] = T->cs[tid]; ca_l[tid] = T->ca[tid]; }
     if (tid < 24) ptab[tid] = T->pretab[tid];
-    __syncthreads();
-
-    // ---- stage B: requantisation (rg_mp3dec.cpp: requantize) -----------------------------------------------------
-    // gains per band: 2^(e), e = (global_gain - 210)/4 - mult (sf + preflag pretab) [- 2 subblock_gain], a multiple
-    // of 1/4 exactly: the table is indexed by 4e
-    for (int c = 0; c < nch; ++c) {
-        const rg_mp3_unit &u = U[c];
-        const int m4 = u.scalefac_scale ? 4 : 2;  // 4 * mult
-        const int base4 = (int)u.global_gain - 210;
-        if (tid < 22) {
-            const int q = base4 - m4 * ((int)u.sf[tid] + (u.preflag ? (int)ptab[tid] : 0));
-            gain_long[c][tid] = T->gain[q - RG_MP3_GAIN_Q_MIN];
-        }
-        if (tid >= 64 && tid < 64 + 39) {
-            const int k = tid - 64;  // (band - short_start) * 3 + window
-            const int band = (int)u.short_start + k / 3, w = k % 3;
-            float gv = 0.0f;
-            if (band < 13) {
-                const int s = band < 12 ? (int)u.sf[(int)u.long_end + k] : 0;
-                const int q = base4 - 8 * (int)u.subblock_gain[w] - m4 * s;
-                gv = T->gain[q - RG_MP3_GAIN_Q_MIN];
-            }
-            gain_short[c][k] = gv;
-        }
+    for (int e = tid; e < RG_MP3_GAIN_Q_MAX - RG_MP3_GAIN_Q_MIN + 1; e += NT) gain_l[e] = T->gain[e];
+    for (int e = tid; e < kPowLds; e += NT) pow_l[e] = T->pow43[e];
+    if (tid >= 32 && tid < 56) sfbl_l[tid - 32] = T->sfb_long[rr][tid - 32];
+    if (tid >= 64 && tid < 80) sfbs_l[tid - 64] = T->sfb_short[rr][tid - 64];
+    // ---- roles ----------------------------------------------------------------------------------------------------
+    const bool imdct_thread = tid < 32 * nch;          // wave 0 (half of it for a mono stream)
+    const int my_c = tid >> 5, my_sb = tid & 31;
+    if (imdct_thread) {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) ovl[i][tid] = 0.0f;  // a granule without a predecessor adds 0.0f, as the host does
     }
-    __syncthreads();
+    // wave 1: lane j requantises the four-line pieces j, j + 64, j + 128 (144 pieces) of every channel
+    const bool rq = tid >= 64;
+    const int rq_lane = tid - 64;
+    constexpr int kRounds = 3;
+    uint32_t rq_lb[kRounds] = {0u, 0u, 0u};            // long-block band numbers of a piece's four lines
     if (rq) {
-        const rg_mp3_unit &u = U[rq_c];
-        const int long_lines = (int)T->sfb_long[rr][u.long_end];  // 0 when long_end == 0
-        const int short_off = 3 * (int)T->sfb_short[rr][u.short_start < 13 ? u.short_start : 13];
-        const uint32_t w[4] = {rq_raw.x, rq_raw.y, rq_raw.z, rq_raw.w};
-        float gv[8];
-        int a[8], v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int line = rq_l0 + j;
-            if (u.block_type != 2 || line < long_lines) {
-                gv[j] = gain_long[rq_c][((j < 4 ? rq_lb.x : rq_lb.y) >> (8 * (j & 3))) & 0xFFu];
-            } else {
-                const int k = (int)T->short_idx_of_line[rr][line - long_lines + short_off] - 3 * (int)u.short_start;
-                gv[j] = gain_short[rq_c][k];
-            }
-            v[j] = (int)(int16_t)(w[j >> 1] >> (16 * (j & 1)));
-            a[j] = v[j] < 0 ? -v[j] : v[j];
-        }
-        float m[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) m[j] = T->pow43[a[j]];  // eight independent look-ups, in flight together
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float t = m[j] * gv[j];
-            xr[rq_c][rq_l0 + j] = v[j] < 0 ? -t : t;
-        }
+        for (int r = 0; r < kRounds; ++r)
+            if (rq_lane + 64 * r < 144) rq_lb[r] = *reinterpret_cast<const uint32_t *>(&T->long_band_of_line[rr][4 * (rq_lane + 64 * r)]);
     }
+    static_assert(sizeof(rg_mp3_unit) == 64, "the unit prefetch assumes 64-byte units");
+    const bool uq = tid >= 120 && tid < 120 + 4 * nch; // threads that carry the units: four 16-byte words each
+    const int uq_t = tid - 120;
+    // units: step 0's go to LDS now, step 1's wait in registers; spectra: step 0's wait in registers
+    uint4 u_reg = make_uint4(0u, 0u, 0u, 0u);
+    if (uq) {
+        reinterpret_cast<uint4 *>(&Ub[0][0])[uq_t] = reinterpret_cast<const uint4 *>(units + ubase)[uq_t];
+        if (nsteps > 1) u_reg = reinterpret_cast<const uint4 *>(units + ubase + nch)[uq_t];
+    }
+    uint2 rq_next[kRounds][2];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) rq_next[r][0] = rq_next[r][1] = make_uint2(0u, 0u);
+    auto fetch_spectra = [&](const int step) {
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (c < nch && rq_lane + 64 * r < 144)
+                    rq_next[r][c] = *reinterpret_cast<const uint2 *>(is + (ubase + (uint64_t)step * nch + c) * 576 + 4 * (rq_lane + 64 * r));
+    };
+    if (rq) fetch_spectra(0);
     __syncthreads();
 
-    // ---- stage C: joint stereo (rg_mp3dec.cpp: stereo) -----------------------------------------------------------
-    if (nch == 2 && U[0].mode_ext != 0) {
-        const rg_mp3_unit &u1 = U[1];
-        const bool ms = (U[0].mode_ext & 2) != 0, is_on = (U[0].mode_ext & 1) != 0;
-        const float isq2 = 0.70710678118654752440f;
-        if (!is_on) {
-            const int n = U[0].nz > U[1].nz ? U[0].nz : U[1].nz;
-            for (int i = tid; i < n; i += 256) {
-                const float a = xr[0][i], b = xr[1][i];
-                xr[0][i] = (a + b) * isq2;
-                xr[1][i] = (a - b) * isq2;
+    for (int k = 0; k <= nsteps; ++k) {
+        // this step requantises granule k of the pipeline (if there is one) and transforms granule k - 1 (if there is one)
+        const int pb = k & 1;
+        float (*const XP)[576] = xrb[pb];
+        const rg_mp3_unit *const UP = Ub[k % 3];
+        bool special = false;
+        if (k < nsteps) {
+            // intensity stereo and short-block reordering need whole-block steps of their own behind the barrier
+            special = (nch == 2 && (UP[0].mode_ext & 1)) || UP[0].block_type == 2 || (nch == 2 && UP[1].block_type == 2);
+            // the units of step k + 1 become visible at this step's barrier; those of step k + 2 start travelling
+            if (uq) {
+                if (k + 1 < nsteps) reinterpret_cast<uint4 *>(&Ub[(k + 1) % 3][0])[uq_t] = u_reg;
+                if (k + 2 < nsteps) u_reg = reinterpret_cast<const uint4 *>(units + ubase + (uint64_t)(k + 2) * nch)[uq_t];
             }
-        } else {
-            const int long_lines = (int)T->sfb_long[rr][u1.long_end];
-            const int short_off = 3 * (int)T->sfb_short[rr][u1.short_start < 13 ? u1.short_start : 13];
+            if (rq) {
+                // ---- stage B: requantisation (rg_mp3dec.cpp: requantize).  The gain of a line is 2^(e),
+                // e = (global_gain - 210)/4 - mult (sf + preflag pretab) [- 2 subblock_gain], a multiple of 1/4 exactly:
+                // the table is indexed by 4e
+                uint2 raw[kRounds][2];
+#pragma unroll
+                for (int r = 0; r < kRounds; ++r) { raw[r][0] = rq_next[r][0]; raw[r][1] = rq_next[r][1]; }
+                if (k + 1 < nsteps) fetch_spectra(k + 1);
+                const int ms_n = (nch == 2 && (UP[0].mode_ext & 3) == 2) ? (UP[0].nz > UP[1].nz ? (int)UP[0].nz : (int)UP[1].nz) : 0;
+#pragma unroll
+                for (int r = 0; r < kRounds; ++r) {
+                    const int piece = rq_lane + 64 * r;
+                    if (piece >= 144) continue;
+                    const int rq_l0 = 4 * piece;
+                    float val[2][4];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        if (c >= nch) continue;
+                        const rg_mp3_unit &u = UP[c];
+                        const int m4 = u.scalefac_scale ? 4 : 2;  // 4 * mult
+                        const int base4 = (int)u.global_gain - 210;
+                        const int long_lines = (int)sfbl_l[u.long_end];  // 0 when long_end == 0
+                        const int short_off = 3 * (int)sfbs_l[u.short_start < 13 ? u.short_start : 13];
+                        const uint32_t w[2] = {raw[r][c].x, raw[r][c].y};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int line = rq_l0 + j;
+                            float gv;
+                            if (u.block_type != 2 || line < long_lines) {
+                                const int band = (int)((rq_lb[r] >> (8 * j)) & 0xFFu);
+                                const int q = base4 - m4 * ((int)u.sf[band] + (u.preflag ? (int)ptab[band] : 0));
+                                gv = gain_l[q - RG_MP3_GAIN_Q_MIN];
+                            } else {
+                                const int kk = (int)T->short_idx_of_line[rr][line - long_lines + short_off] - 3 * (int)u.short_start;  // (band - short_start) * 3 + window
+                                const int band = (int)u.short_start + kk / 3, win = kk % 3;
+                                gv = 0.0f;
+                                if (band < 13) {
+                                    const int sv = band < 12 ? (int)u.sf[(int)u.long_end + kk] : 0;
+                                    const int q = base4 - 8 * (int)u.subblock_gain[win] - m4 * sv;
+                                    gv = gain_l[q - RG_MP3_GAIN_Q_MIN];
+                                }
+                            }
+                            const int v = (int)(int16_t)(w[j >> 1] >> (16 * (j & 1)));
+                            const int a = v < 0 ? -v : v;
+                            const float m = a < kPowLds ? pow_l[a] : T->pow43[a];
+                            const float t = m * gv;
+                            val[c][j] = v < 0 ? -t : t;
+                        }
+                    }
+                    // ---- stage C, the plain case: mid/side on every line below the longer channel's end (rg_mp3dec.cpp: stereo)
+                    if (ms_n) {
+                        const float isq2 = 0.70710678118654752440f;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (rq_l0 + j < ms_n) {
+                                const float a = val[0][j], b = val[1][j];
+                                val[0][j] = (a + b) * isq2;
+                                val[1][j] = (a - b) * isq2;
+                            }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        if (c < nch) *reinterpret_cast<float4 *>(&XP[c][rq_l0]) = make_float4(val[c][0], val[c][1], val[c][2], val[c][3]);
+                }
+            }
+        }
+        if (k >= 1 && imdct_thread) {
+            // ---- stage D of granule k - 1: alias reduction + IMDCT + window + overlap-add (rg_mp3dec.cpp: antialias, hybrid)
+            const int q = k - 1;
+            const rg_mp3_unit &u = Ub[q % 3][my_c];
+            const float *const X = xrb[pb ^ 1][my_c];
+            const int bt = (u.block_type == 2 && u.mixed && my_sb < 2) ? 0 : (int)u.block_type;
+            // the butterflies between subbands sb - 1 | sb, sb = 1 .. nb; this thread evaluates its own half of the two it touches
+            const int nb = u.block_type == 2 ? (u.mixed ? 1 : 0) : 31;
+            float xs[18];
+            const float *Xr = X + my_sb * 18;
+#pragma unroll
+            for (int i = 0; i < 18; ++i) xs[i] = Xr[i];
+            if (my_sb >= 1 && my_sb <= nb) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float a = Xr[-1 - i], b = xs[i];
+                    xs[i] = b * cs_l[i] + a * ca_l[i];
+                }
+            }
+            if (my_sb < nb) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float a = xs[17 - i], b = Xr[18 + i];
+                    xs[17 - i] = a * cs_l[i] - b * ca_l[i];
+                }
+            }
+            float *__restrict__ dst = sub + sub_index(ubase + (uint64_t)q * nch + my_c, 0, my_sb);
+            const bool keep = q + gi0 >= 0;
+            const bool flip = (my_sb & 1) != 0;
+            // windowed sample i of this granule: the first eighteen are added to the overlap and leave (frequency inversion:
+            // odd samples of odd subbands change sign), the second eighteen are the next granule's overlap
+#if RG_HYB_OVPREF
+            float ov[18];  // all eighteen reads in flight together, ahead of the arithmetic
+#pragma unroll
+            for (int i = 0; i < 18; ++i) ov[i] = ovl[i][tid];
+#endif
+            auto emit = [&](const int i, const float val) {
+                if (i < 18) {
+#if RG_HYB_OVPREF
+                    float v = val + ov[i];
+#else
+                    float v = val + ovl[i][tid];
+#endif
+                    if (flip && (i & 1)) v = -v;
+                    if (keep) dst[(size_t)i * 32] = v;
+                } else {
+                    ovl[i - 18][tid] = val;
+                }
+            };
+            if (bt != 2) {
+                struct Sink {
+                    decltype(emit) &f;
+                    struct Ref {
+                        decltype(emit) &f;
+                        int i;
+                        __device__ __forceinline__ void operator=(float v) { f(i, v); }
+                    };
+                    __device__ __forceinline__ Ref operator[](int i) { return Ref{f, i}; }
+                } sink{emit};
+                rg_mp3_imdct36_windowed(xs, wn[bt], sink);  // raw[m], raw[17-m] (read the overlap) before raw[18+m], raw[35-m] (write it)
+            } else {
+                // sample i of the three overlapping 12-point IMDCTs: window w contributes its sample i - 6 - 6w, in the
+                // order w = 0, 1, 2 (the host's)
+#pragma unroll 1
+                for (int i = 0; i < 36; ++i) {
+                    float raw = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < 3; ++w) {
+                        const int ii = i - 6 - 6 * w;
+                        if (ii >= 0 && ii < 12) {
+                            float s2 = 0.0f;
+#pragma unroll
+                            for (int kk = 0; kk < 6; ++kk) s2 = rg_mp3_mac(xs[3 * kk + w], c12[ii][kk], s2);
+                            raw = rg_mp3_mac(s2, wn[2][ii], raw);
+                        }
+                    }
+                    // (the loop is rolled: the overlap comes from LDS by index here, not from the registers above)
+                    if (i < 18) {
+                        float v = raw + ovl[i][tid];
+                        if (flip && (i & 1)) v = -v;
+                        if (keep) dst[(size_t)i * 32] = v;
+                    } else {
+                        ovl[i - 18][tid] = raw;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (!special) continue;
+
+        // ==== the rest of granule k's stage C / D preparation, all four waves (uniform: `special` comes from the units) ====
+        if (nch == 2 && (UP[0].mode_ext & 1)) {
+            // ---- intensity stereo, with mid/side on the bands it leaves (rg_mp3dec.cpp: stereo)
+            const rg_mp3_unit &u1 = UP[1];
+            const bool ms = (UP[0].mode_ext & 2) != 0;
+            const float isq2 = 0.70710678118654752440f;
+            if (tid < 64) { band_nz[tid] = 0; band_mode[tid] = 0; }
+            __syncthreads();
+            const int long_lines = (int)sfbl_l[u1.long_end];
+            const int short_off = 3 * (int)sfbs_l[u1.short_start < 13 ? u1.short_start : 13];
             // stereo band of a line: short bands 0..38 = (band - short_start) * 3 + window, long bands 39 + band
             auto band_of = [&](int line) -> int {
                 if (u1.block_type != 2 || line < long_lines) return 39 + (int)T->long_band_of_line[rr][line];
                 return (int)T->short_idx_of_line[rr][line - long_lines + short_off] - 3 * (int)u1.short_start;
             };
-            for (int line = tid; line < 576; line += 256)
-                if (xr[1][line] != 0.0f) band_nz[band_of(line)] = 1;
+            for (int line = tid; line < 576; line += NT)
+                if (XP[1][line] != 0.0f) band_nz[band_of(line)] = 1;
             __syncthreads();
             if (tid == 0) {
                 // walk the bands from the top: a band is intensity coded while every band above it (of the same
@@ -205,12 +382,12 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
                     for (int b = 12; b >= (int)u1.short_start; --b) {
                         const int sb = b == 12 ? 11 : b;
                         for (int w = 2; w >= 0; --w) {
-                            const int k = (b - (int)u1.short_start) * 3 + w;
+                            const int kk = (b - (int)u1.short_start) * 3 + w;
                             const int idx = (int)u1.long_end + 3 * (sb - (int)u1.short_start) + w;
                             bool intensity = false;
                             int mode = 0;
                             if (!found[w]) {
-                                if (band_nz[k]) {
+                                if (band_nz[kk]) {
                                     found[w] = true;
                                 } else {
                                     const int p = u1.sf[idx];
@@ -219,7 +396,7 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
                                 }
                             }
                             if (!intensity && ms) mode = 1;
-                            band_mode[k] = (short)mode;
+                            band_mode[kk] = (short)mode;
                         }
                     }
                     found_long = found[0] || found[1] || found[2];
@@ -245,12 +422,12 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
             }
             __syncthreads();
             const int scale = u1.intensity_scale & 1;
-            for (int line = tid; line < 576; line += 256) {
+            for (int line = tid; line < 576; line += NT) {
                 const int mode = band_mode[band_of(line)];
                 if (mode == 1) {
-                    const float a = xr[0][line], b = xr[1][line];
-                    xr[0][line] = (a + b) * isq2;
-                    xr[1][line] = (a - b) * isq2;
+                    const float a = XP[0][line], b = XP[1][line];
+                    XP[0][line] = (a + b) * isq2;
+                    XP[1][line] = (a - b) * isq2;
                 } else if (mode >= 2) {
                     const int pos = mode - 2;
                     float kl, kr;
@@ -266,81 +443,26 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
                         kl = 1.0f;
                         kr = T->lsf_is[scale][pos >> 1];
                     }
-                    const float v = xr[0][line];
-                    xr[0][line] = v * kl;
-                    xr[1][line] = v * kr;
+                    const float v = XP[0][line];
+                    XP[0][line] = v * kl;
+                    XP[1][line] = v * kr;
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
-    }
-
-    // ---- stage D per channel: reorder, alias reduction, IMDCT + window -------------------------------------------
-    for (int c = 0; c < nch; ++c) {
-        const rg_mp3_unit &u = U[c];
-        float *X = xr[c];
-        if (u.block_type == 2) {
-            const int long_lines = u.mixed ? (int)T->sfb_long[rr][u.long_end] : 0;
-            const int short_off = 3 * (int)T->sfb_short[rr][u.short_start];
-            for (int line = tid; line < 576; line += 256)
+        // ---- short blocks: the spectrum from bitstream order [band][window][line] to [line][window] (rg_mp3dec.cpp: reorder)
+        for (int c = 0; c < nch; ++c) {
+            const rg_mp3_unit &u = UP[c];
+            if (u.block_type != 2) continue;
+            float *X = XP[c];
+            const int long_lines = u.mixed ? (int)sfbl_l[u.long_end] : 0;
+            const int short_off = 3 * (int)sfbs_l[u.short_start];
+            for (int line = tid; line < 576; line += NT)
                 tmp[line] = line < long_lines ? X[line]
                                               : X[(int)T->short_reorder_src[rr][line - long_lines + short_off] - short_off + long_lines];
             __syncthreads();
-            for (int line = tid; line < 576; line += 256) X[line] = tmp[line];
+            for (int line = tid; line < 576; line += NT) X[line] = tmp[line];
             __syncthreads();
-        }
-        const int boundaries = u.block_type == 2 ? (u.mixed ? 1 : 0) : 31;
-        if (tid < boundaries * 8) {
-            const int sb = 1 + tid / 8, i = tid % 8;
-            const float a = X[sb * 18 - 1 - i], b = X[sb * 18 + i];
-            X[sb * 18 - 1 - i] = a * cs_l[i] - b * ca_l[i];
-            X[sb * 18 + i] = b * cs_l[i] + a * ca_l[i];
-        }
-        __syncthreads();
-    }
-    // ---- IMDCT + window.  Long subbands (block types 0, 1, 3, and the two lowest of a mixed block): one thread per
-    // (channel, subband) runs the fast 36-point IMDCT of rg_mp3_math.h -- the code the host decoder runs -- on its eighteen
-    // lines; consecutive threads are consecutive subbands, so every store to hyb[unit][half][t][sb] is a whole 128-byte line.
-    if (tid < 32 * nch) {
-        const int c = tid >> 5, sb = tid & 31;
-        const rg_mp3_unit &u = U[c];
-        const int bt = (u.block_type == 2 && u.mixed && sb < 2) ? 0 : (int)u.block_type;
-        if (bt != 2) {
-            float xs[18];
-            const float *Xr = xr[c] + sb * 18;
-#pragma unroll
-            for (int k = 0; k < 18; ++k) xs[k] = Xr[k];
-            struct Store {
-                float *__restrict__ base;  // hyb[unit][0][0][sb]
-                struct Ref {
-                    float *p;
-                    __device__ __forceinline__ void operator=(float v) { *p = v; }
-                };
-                __device__ __forceinline__ Ref operator[](int i) { return Ref{base + (size_t)i * 32}; }  // [half][t] is i = 18 half + t
-            } out{hyb + hyb_index(u0 + c, 0, 0, sb)};
-            rg_mp3_imdct36_windowed(xs, wn[bt], out);
-        }
-    }
-    // Short subbands: each of the 36 samples on its own; consecutive threads take consecutive subbands of one sample index
-    for (int c = 0; c < nch; ++c) {
-        const rg_mp3_unit &u = U[c];
-        if (u.block_type != 2) continue;
-        for (int o = tid; o < 32 * 36; o += 256) {
-            const int sb = o & 31, i = o >> 5;
-            if (u.mixed && sb < 2) continue;
-            const float *Xs = xr[c] + sb * 18;
-            float raw = 0.0f;
-#pragma unroll
-            for (int w = 0; w < 3; ++w) {
-                const int ii = i - 6 - 6 * w;
-                if (ii >= 0 && ii < 12) {
-                    float s2 = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) s2 = rg_mp3_mac(Xs[3 * k + w], c12[ii][k], s2);
-                    raw = rg_mp3_mac(s2, wn[2][ii], raw);
-                }
-            }
-            hyb[hyb_index(u0 + c, i < 18 ? 0 : 1, i < 18 ? i : i - 18, sb)] = raw;
         }
     }
 }
@@ -372,34 +494,27 @@ rg_mp3_synth_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *_
     const uint32_t g0 = (local % runs) * R;
     const int ng = (int)(tr.n_granules - g0 < (uint32_t)R ? tr.n_granules - g0 : (uint32_t)R);
     const int nslots = 15 + 18 * ng;
-    // ---- overlap-add + frequency inversion (rg_mp3dec.cpp: hybrid, tail) -----------------------------------------
     // the window's sixteen coefficients for this thread's sample index (e % 32 == tid % 32 for every e it takes), fetched
     // with everything else the block reads from memory
     const int wj = tid & 31;
     float Dw[16];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { Dw[2 * i] = T->D[i * 64 + wj]; Dw[2 * i + 1] = T->D[i * 64 + 32 + wj]; }
-    // The loop is unrolled so that all of a thread's loads (two per subband sample, sixteen samples) are in flight
-    // together: rolled, every iteration waited for its own pair, and those sixteen round trips to memory were most of the
-    // block's lifetime.
-    // ... and in 16-byte pieces: four adjacent subbands of one time slot per load.
+    // Finished subband samples (the hybrid kernel has added the overlap and applied the frequency inversion), sixteen
+    // bytes = four adjacent subbands of one time slot per load, all of a thread's loads in flight together.
     constexpr int kLoads = (SLOTS * 8 + 255) / 256;
-    float4 first[kLoads], ovl[kLoads];
+    float4 first[kLoads];
 #pragma unroll
     for (int k = 0; k < kLoads; ++k) {
         const int e = tid + 256 * k;
         first[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        ovl[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (e < nslots * 8) {
             const int r = e / 8, sb = (e % 8) * 4;
             const int rel = r - 15;                        // time slot relative to granule g0
             const long long gg = (long long)g0 + (rel >= 0 ? rel / 18 : -1);
             const int t = rel >= 0 ? rel % 18 : 18 + rel;
-            if (gg >= 0) {
-                const uint64_t unit = tr.unit_base + (uint64_t)gg * nch + c;
-                first[k] = *reinterpret_cast<const float4 *>(&hyb[hyb_index(unit, 0, t, sb)]);
-                if (gg >= 1) ovl[k] = *reinterpret_cast<const float4 *>(&hyb[hyb_index(unit - nch, 1, t, sb)]);
-            }
+            // the slots before the track are silence
+            if (gg >= 0) first[k] = *reinterpret_cast<const float4 *>(&hyb[sub_index(tr.unit_base + (uint64_t)gg * nch + c, t, sb)]);
         }
     }
 #pragma unroll
@@ -407,13 +522,10 @@ rg_mp3_synth_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *_
         const int e = tid + 256 * k;
         if (e < nslots * 8) {
             const int r = e / 8, sb = (e % 8) * 4;
-            const int rel = r - 15;
-            const int t = rel >= 0 ? rel % 18 : 18 + rel;
-            // a granule without a predecessor (and the slots before the track) add 0.0f, as the host does
-            float v[4] = {first[k].x + ovl[k].x, first[k].y + ovl[k].y, first[k].z + ovl[k].z, first[k].w + ovl[k].w};
-            if (t & 1) { v[1] = -v[1]; v[3] = -v[3]; }  // frequency inversion: odd subbands of odd time slots
-#pragma unroll
-            for (int q = 0; q < 4; ++q) S[r][sb + q] = v[q];
+            S[r][sb] = first[k].x;
+            S[r][sb + 1] = first[k].y;
+            S[r][sb + 2] = first[k].z;
+            S[r][sb + 3] = first[k].w;
         }
     }
     __syncthreads();
@@ -889,11 +1001,12 @@ extern "C" hipError_t rg_launch_mp3_huffman(const RgMp3DevTables *d_tab, const R
     return hipGetLastError();
 }
 
+// n_runs: blocks of the grid, one per run of RG_MP3_SYNTH_RUN granules (RgMp3DevTrack::hrun_base)
 extern "C" hipError_t rg_launch_mp3_hybrid(const RgMp3DevTables *d_tab, const RgMp3DevTrack *d_tracks, uint32_t n_tracks,
-                                           uint32_t n_granules, const rg_mp3_unit *d_units, const int16_t *d_is, float *d_hyb,
+                                           uint32_t n_runs, const rg_mp3_unit *d_units, const int16_t *d_is, float *d_hyb,
                                            hipStream_t s) {
-    if (n_granules == 0) return hipSuccess;
-    hipLaunchKernelGGL(rg_mp3_hybrid_kernel, dim3(n_granules), dim3(256), 0, s, d_tab, d_tracks, n_tracks, d_units, d_is, d_hyb);
+    if (n_runs == 0) return hipSuccess;
+    hipLaunchKernelGGL(rg_mp3_hybrid_kernel, dim3(n_runs), dim3(RG_MP3_HYB_THREADS), 0, s, d_tab, d_tracks, n_tracks, d_units, d_is, d_hyb);
     return hipGetLastError();
 }
 

@@ -71,7 +71,7 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
         while (last < n && (last == first || units + items[last].n_units <= kChunkUnits)) units += items[last++].n_units;
         std::vector<RgMp3DevTrack> tr(last - first);
         uint64_t ub = 0, mainb = 0;
-        uint32_t gb = 0, sb = 0;
+        uint32_t gb = 0, sb = 0, hb = 0;
         bool any_recs = false;
         for (size_t i = first; i < last; ++i) {
             const RgMp3SplitItem &it = items[i];
@@ -86,7 +86,9 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
             t.ch0 = it.d_ch0;
             t.ch1 = it.d_ch1;
             t.synth_base = sb;
+            t.hrun_base = hb;
             sb += ((t.n_granules + RG_MP3_SYNTH_RUN - 1) / RG_MP3_SYNTH_RUN) * t.channels;  // runs of granules x channels
+            hb += (t.n_granules + RG_MP3_SYNTH_RUN - 1) / RG_MP3_SYNTH_RUN;
             t.main_base = mainb;
             ub += it.n_units;
             gb += t.n_granules;
@@ -95,7 +97,7 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
         if (units) {
             RG_HIP(c, c->d_mp3_is.reserve(units * 576));
             RG_HIP(c, c->d_mp3_units.reserve(units * sizeof(rg_mp3_unit)));
-            RG_HIP(c, c->d_mp3_hyb.reserve(units * 2 * 576));
+            RG_HIP(c, c->d_mp3_hyb.reserve(units * 576));
             RG_HIP(c, c->d_mp3_tracks.reserve(tr.size() * sizeof(RgMp3DevTrack)));
             if (any_recs) {
                 RG_HIP(c, c->d_mp3_recs.reserve(units * sizeof(RgMp3HuffRec)));
@@ -123,7 +125,7 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
                 RG_HIP(c, rg_launch_mp3_huffman(d_tab, d_huff, d_tr, (uint32_t)tr.size(), reinterpret_cast<const RgMp3HuffRec *>(c->d_mp3_recs.p),
                                                 c->d_mp3_main.p, reinterpret_cast<rg_mp3_unit *>(c->d_mp3_units.p), c->d_mp3_is.p, ub, s));
             }
-            RG_HIP(c, rg_launch_mp3_hybrid(d_tab, d_tr, (uint32_t)tr.size(), gb, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p),
+            RG_HIP(c, rg_launch_mp3_hybrid(d_tab, d_tr, (uint32_t)tr.size(), hb, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p),
                                            c->d_mp3_is.p, c->d_mp3_hyb.p, s));
             RG_HIP(c, rg_launch_mp3_synth(d_tab, d_tr, (uint32_t)tr.size(), sb, c->d_mp3_hyb.p, s));
             // the chunk buffers (and `tr`) are reused by the next chunk
@@ -167,7 +169,7 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
     // laid out for the upper bound "every walked frame decodes"
     RgMp3DevTrack *tr = reinterpret_cast<RgMp3DevTrack *>(staging + tracks_off);
     uint64_t ub = 0;
-    uint32_t gb = 0, sb = 0, tb = 0;
+    uint32_t gb = 0, sb = 0, tb = 0, hb = 0;
     for (size_t i = 0; i < n; ++i) {
         const RgMp3StreamItem &it = items[i];
         RgMp3DevTrack &t = tr[i];
@@ -186,19 +188,21 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
         t.ch1 = it.channels == 2 ? it.d_ch0 + (size_t)granules * 576 : nullptr;
         t.main_base = it.main_off;
         t.synth_base = sb;
+        t.hrun_base = hb;
         t.n_frames = it.n_frames;
         t.slots_base = it.slots_off;
         t.result_index = it.result_index;
         ub += (uint64_t)granules * it.channels;
         gb += granules;
         sb += ((granules + RG_MP3_SYNTH_RUN - 1) / RG_MP3_SYNTH_RUN) * it.channels;
+        hb += (granules + RG_MP3_SYNTH_RUN - 1) / RG_MP3_SYNTH_RUN;
     }
     // grow-only buffers; growing one frees the old allocation, which waits for the kernels still using it
     RG_HIP(c, c->d_mp3_stage[set].reserve(bytes + 64));
     if (ub) {
         RG_HIP(c, c->d_mp3_is.reserve(ub * 576));
         RG_HIP(c, c->d_mp3_units.reserve(ub * sizeof(rg_mp3_unit)));
-        RG_HIP(c, c->d_mp3_hyb.reserve(ub * 2 * 576));
+        RG_HIP(c, c->d_mp3_hyb.reserve(ub * 576));
         RG_HIP(c, c->d_mp3_recs.reserve(ub * sizeof(RgMp3HuffRec)));
         RG_HIP(c, c->d_mp3_tiles.reserve((size_t)tb * 2));
     }
@@ -220,7 +224,7 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
         RG_HIP(c, rg_launch_mp3_huffman(d_tab, d_huff, d_tr, (uint32_t)n, d_recs, d_chunk, reinterpret_cast<rg_mp3_unit *>(c->d_mp3_units.p),
                                         c->d_mp3_is.p, ub, s));
         if (ev) RG_HIP(c, hipEventRecord(ev[2], s));
-        RG_HIP(c, rg_launch_mp3_hybrid(d_tab, d_tr, (uint32_t)n, gb, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p), c->d_mp3_is.p,
+        RG_HIP(c, rg_launch_mp3_hybrid(d_tab, d_tr, (uint32_t)n, hb, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p), c->d_mp3_is.p,
                                        c->d_mp3_hyb.p, s));
         if (ev) RG_HIP(c, hipEventRecord(ev[3], s));
         RG_HIP(c, rg_launch_mp3_synth(d_tab, d_tr, (uint32_t)n, sb, c->d_mp3_hyb.p, s));

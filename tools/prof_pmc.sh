@@ -3,12 +3,13 @@
 #   e.g. tools/prof_pmc.sh cfg2 7938000000                      (bench.py's default workload, configs[2])
 #        tools/prof_pmc.sh cfg1 26460000 --tracks-per-rank 1 --minutes 10
 # Writes raw rocprofv3 output under gpurun_out/prof_<tag>/ and the summaries that are committed under profiles/:
-#   r02_<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the bench command
-#   r02_<tag>_span.json          per-kernel span / concurrency derived from the raw kernel trace
-#   r02_pmc_<tag>.json           per-launch PMC means of the dominant kernel (read by bench.py)
-#   r02_<tag>_pmc_summary.txt    every counter, every kernel
+#   <round>_<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the bench command
+#   <round>_<tag>_span.json          per-kernel span / concurrency derived from the raw kernel trace
+#   <round>_pmc_<tag>.json           per-launch PMC means of the dominant kernel (read by bench.py)
+#   <round>_<tag>_pmc_summary.txt    every counter, every kernel
 # Each counter group is its own rocprofv3 run (no trace domains combined with --pmc), each under a timeout.
 TAG=$1; FRAMES=$2; shift 2
+export PROF_ROUND=${PROF_ROUND:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=gpurun_out/prof_$TAG
 cd /tmp && export TMPDIR=/tmp
@@ -19,6 +20,8 @@ BENCH_ARGS="$*"
 run() { name=$1; shift; timeout ${PROF_TIMEOUT:-400} rocprofv3 "$@" -d $OUT/$name --output-format csv -- python bench.py --cpu-seconds 0 --no-configs1 $BENCH_ARGS $EXTRA > $OUT/$name.log 2>&1 || echo "$name failed/timeout"; }
 EXTRA="${KT_EXTRA:-}"
 run kt --kernel-trace --stats
+EXTRA="${KT_EXTRA:-} --slots 1"
+run kt1 --kernel-trace --stats   # one pipeline slot: every launch alone
 # the counter passes serialise the dispatches and write one row per dispatch and counter: a short pre-roll and few
 # timed steps keep them small (the counters are per dispatch, they do not depend on how many there are)
 EXTRA="${PMC_EXTRA:---pre-roll 0.01 --steps 6 --warmup 1}"
@@ -33,5 +36,5 @@ run pmc_tcc --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run pmc_lds --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT
 run pmc_lat --pmc SQ_INST_LEVEL_SMEM SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_BUSY_CU_CYCLES
 fi
-python tools/prof_summary.py $OUT $TAG $FRAMES "$BENCH_ARGS" > $PROFILES_DIR/r02_${TAG}_pmc_summary.txt 2>&1
-tail -5 $PROFILES_DIR/r02_${TAG}_pmc_summary.txt
+python tools/prof_summary.py $OUT $TAG $FRAMES "$BENCH_ARGS" > $PROFILES_DIR/${PROF_ROUND}_${TAG}_pmc_summary.txt 2>&1
+tail -5 $PROFILES_DIR/${PROF_ROUND}_${TAG}_pmc_summary.txt

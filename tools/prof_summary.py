@@ -3,11 +3,11 @@
 
     prof_summary.py <rawdir> <tag> <frames_per_launch> "<bench args>"
 
-  profiles/r02_<tag>_kernel_stats.csv  copy of rocprofv3's kernel_stats.csv
-  profiles/r02_<tag>_span.json         per kernel: launches, sum of durations, first-start-to-last-end span, concurrency
+  profiles/<round>_<tag>_kernel_stats.csv  copy of rocprofv3's kernel_stats.csv
+  profiles/<round>_<tag>_span.json         per kernel: launches, sum of durations, first-start-to-last-end span, concurrency
                                        (from the raw kernel trace: the stats file's average alone says nothing about
                                        throughput when launches of consecutive batches overlap)
-  profiles/r02_pmc_<tag>.json          per-launch PMC means of the dominant kernel; bench.py reads it
+  profiles/<round>_pmc_<tag>.json          per-launch PMC means of the dominant kernel; bench.py reads it
 """
 import csv
 import glob
@@ -18,6 +18,7 @@ import sys
 from collections import defaultdict
 
 d, tag, frames, bench_args = sys.argv[1], sys.argv[2], int(sys.argv[3]), (sys.argv[4] if len(sys.argv) > 4 else "")
+RND = os.environ.get("PROF_ROUND", "r03")
 prof = os.environ.get("PROFILES_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
 os.makedirs(prof, exist_ok=True)
 MAIN = "rg_tm_main_kernel"
@@ -34,7 +35,7 @@ def newest(pattern):
 
 
 for f in newest(f"{d}/kt/*/*kernel_stats.csv"):
-    shutil.copy(f, os.path.join(prof, f"r02_{tag}_kernel_stats.csv"))
+    shutil.copy(f, os.path.join(prof, f"{RND}_{tag}_kernel_stats.csv"))
     print("== kernel stats (rocprofv3 --kernel-trace --stats)")
     for r in csv.DictReader(open(f)):
         print(f"  {r['Name'][:60]:60s} calls {r['Calls']:>5s} avg_ns {float(r['AverageNs']):12.1f} pct {r['Percentage']}")
@@ -51,7 +52,7 @@ try:
 except OSError:
     pass
 if bench_line:
-    json.dump(bench_line, open(os.path.join(prof, f"r02_{tag}_bench_under_rocprofv3.json"), "w"))
+    json.dump(bench_line, open(os.path.join(prof, f"{RND}_{tag}_bench_under_rocprofv3.json"), "w"))
 steps = bench_line["steps"] if bench_line else None
 groups = bench_line["roofline"].get("launch_groups_per_step", 1) if bench_line else 1
 spans = {}
@@ -86,7 +87,15 @@ if spans:
                                   "hbm_frac_span": algo / (step_ms * 1e-3) / 8e12,
                                   "bench_line_frac_same_run": bench_line["roofline"]["frac"],
                                   "bench_line_kernel_ms_same_run": bench_line["roofline"]["kernel_ms"]}
-    json.dump(doc, open(os.path.join(prof, f"r02_{tag}_span.json"), "w"), indent=1)
+    # one launch alone: the same command with one pipeline slot (--slots 1), where launches cannot overlap (pass kt1)
+    for f in newest(f"{d}/kt1/*/*kernel_stats.csv"):
+        for r in csv.DictReader(open(f)):
+            if MAIN in r["Name"]:
+                doc["one_launch_alone"] = {"command": doc["command"] + " --slots 1", "calls": int(r["Calls"]),
+                                           "avg_duration_ms": float(r["AverageNs"]) / 1e6, "min_ms": float(r["MinNs"]) / 1e6,
+                                           "achieved_GBps": frames * 8 / (float(r["AverageNs"]) * 1e-9) / 1e9,
+                                           "hbm_frac": frames * 8 / (float(r["AverageNs"]) * 1e-9) / 8e12}
+    json.dump(doc, open(os.path.join(prof, f"{RND}_{tag}_span.json"), "w"), indent=1)
     print("== span", json.dumps(doc.get("dominant_kernel")))
 
 acc = defaultdict(lambda: defaultdict(list))
@@ -123,5 +132,5 @@ if main:
            "dispatches_averaged": {k: len(v) for k, v in cs.items() if k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64")},
            "command": f"rocprofv3 --pmc <one group per pass> -- python bench.py --cpu-seconds 0 --no-configs1 {bench_args} --pre-roll 0.01 --steps 6 --warmup 1".replace("  ", " "),
            "note": "PMC passes serialise the dispatches: these describe one launch alone"}
-    json.dump(out, open(os.path.join(prof, f"r02_pmc_{tag}.json"), "w"), indent=1)
-    print("wrote", f"profiles/r02_pmc_{tag}.json")
+    json.dump(out, open(os.path.join(prof, f"{RND}_pmc_{tag}.json"), "w"), indent=1)
+    print("wrote", f"profiles/{RND}_pmc_{tag}.json")
