@@ -163,6 +163,7 @@ struct rg_ctx {
     int gpu_mp3_decode = 3;                  // tuning key 6: 0 = host decoder, 1 = stages B-E of MP3 decoding run on the device,
                                              // 2 = scalefactors + Huffman too, 3 (default) = side-information parsing too: the host
                                              // only finds the frames and strips their headers (loader pipeline, rg_files.hip)
+    int32_t file_track_index = -1;           // Some(idx) of the file-level call in progress (src/replaygain.rs:838-851); -1 = None
     unsigned loader_threads = 0;             // tuning key 7: host threads of the file loaders; 0 = every core this process may use
     DevBuf<unsigned char> d_arena;           // staging for host PCM (synchronous API)
     DevBuf<unsigned char> d_ingest[2];       // streamed host ingest: two sub-batch arenas, one filling while the other is analysed

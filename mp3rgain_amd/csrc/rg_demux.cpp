@@ -300,12 +300,16 @@ int adts_walk(const uint8_t *d, size_t len, rg_adts_info *info, F &&on_frame) {
         const size_t sz = ((size_t)(d[6] & 0x7F) << 21) | ((size_t)(d[7] & 0x7F) << 14) | ((size_t)(d[8] & 0x7F) << 7) | (d[9] & 0x7F);
         pos = 10 + sz + ((d[5] & 0x10) ? 10 : 0);
     }
-    bool first = true;
+    bool first = true, synced = false;
     AdtsHdr h, nx;
     while (pos + 7 <= len) {
-        // a frame counts when the next one (or the end of the stream) follows where its length says
-        if (adts_header(d + pos, len - pos, &h) && pos + h.frame_len <= len &&
-            (pos + h.frame_len == len || pos + h.frame_len + 7 > len || (adts_header(d + pos + h.frame_len, len - pos - h.frame_len, &nx) && nx.fi == h.fi))) {
+        // In sync (the frame before ended right here) a valid header is a frame.  Out of sync -- the start of the stream,
+        // or after junk -- it also takes the next frame's header where this one's length says (or the end of the stream):
+        // twelve set bits alone occur in any data.
+        bool ok = adts_header(d + pos, len - pos, &h) && pos + h.frame_len <= len;
+        if (ok && !synced)
+            ok = pos + h.frame_len + 7 > len || (adts_header(d + pos + h.frame_len, len - pos - h.frame_len, &nx) && nx.fi == h.fi);
+        if (ok) {
             if (first) {
                 info->sample_rate = kAscRates[h.fi];
                 info->channels = h.cc == 7 ? 8 : h.cc;
@@ -318,8 +322,10 @@ int adts_walk(const uint8_t *d, size_t len, rg_adts_info *info, F &&on_frame) {
             info->raw_blocks += h.blocks;
             on_frame(pos + h.hdr_len, h.frame_len - h.hdr_len);
             pos += h.frame_len;
+            synced = true;
         } else {
             ++pos;
+            synced = false;
             if (!first) ++info->junk_bytes;
         }
     }

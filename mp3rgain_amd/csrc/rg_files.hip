@@ -34,6 +34,7 @@
 #include "../../include/mp3rgain_amd.h"
 #include "../../include/mp3rgain_amd_dec.h"
 #include "../../include/mp3rgain_amd_mp4.h"
+#include "../../include/mp3rgain_amd_demux.h"
 #include "rg_ctx.h"
 #include "rg_mp3dev.h"
 #include "rg_mp3dev_host.h"
@@ -221,6 +222,7 @@ struct LoadedAudio {
     std::vector<RgMp3HuffRec> recs;
     std::vector<uint8_t> file_bytes;  // the file as read
     bool is_mp4 = false;
+    uint32_t n_audio_tracks = 1;  // an MP4 file: what its sample tables say (include/mp3rgain_amd_demux.h); anything else has one
     // tuning key 6 = 3: the loader pipeline has decoded the stream into the arena already (planar f32 at arena_off);
     // `frames` is what the device found decodable
     bool staged = false;
@@ -232,7 +234,7 @@ struct LoadedAudio {
         wav.clear(); planar.clear(); is.clear(); units.clear(); main_stream.clear(); recs.clear(); file_bytes.clear();
         sample_rate = channels = 0; frames = 0; n_units = 0; lsf = 0;
         decoded = split = is_mp4 = staged = false;
-        arena_off = 0; walked_frames = 0; result_index = 0;
+        arena_off = 0; walked_frames = 0; result_index = 0; n_audio_tracks = 1;
     }
 };
 
@@ -459,7 +461,12 @@ std::string shell_quote(const char *s) {
 
 // Load one file (no device work; safe to call from several threads at once as long as `err` is per call).
 // RIFF/WAVE: the bytes; MPEG Layer III: decoded planar f32; anything else: the decoder command's stdout.
-int load_audio_for(const std::string &decoder_cmd, int gpu_decode, const char *path, LoadedAudio *out, std::string *err) {
+// an MP4 file whose selected track was MPEG audio has been replaced by that track's elementary stream (no ftyp box any more)
+static bool tr_is_mp3(const std::vector<uint8_t> &bytes, bool was_mp4) {
+    return was_mp4 && !(bytes.size() >= 8 && memcmp(bytes.data() + 4, "ftyp", 4) == 0);
+}
+
+int load_audio_for(const std::string &decoder_cmd, int gpu_decode, const char *path, LoadedAudio *out, std::string *err, int32_t track_index) {
     char msg[1024];
     auto fail = [&](int code, const char *fmt, const char *a, int b = 0) {
         snprintf(msg, sizeof msg, fmt, a, b);
@@ -480,7 +487,49 @@ int load_audio_for(const std::string &decoder_cmd, int gpu_decode, const char *p
     }
     const bool mp4 = bytes.size() >= 8 && memcmp(bytes.data() + 4, "ftyp", 4) == 0;
     out->is_mp4 = rg_mp4_is_mp4_data(bytes.data(), bytes.size()) != 0;  // detect_file_type, src/replaygain.rs:777-783
-    if (!mp4) {
+    int mp4_track = 0;
+    if (mp4) {
+        // ---- ISO base media: the audio tracks the reference would see (src/replaygain.rs:827-836), the one it would pick
+        // (:838-851), its rate (:854-857).  MPEG Layer III in MP4 is decoded here, from the sample table; AAC needs the
+        // decoder command.
+        rg_mp4_audio_track tr[32];
+        size_t n_audio = 0;
+        bool walked = rg_mp4_audio_tracks(bytes.data(), bytes.size(), tr, 32, &n_audio) == RG_DEMUX_OK;
+        // A file this walker cannot read (no moov box), or in which it finds no track of a codec the reference's build
+        // decodes, is still the decoder command's to try when there is one: the command is the user's decoder (ALAC in
+        // M4A, say), and the authority on what it can read.
+        if (!walked && decoder_cmd.empty()) return fail(RG_ERR_FORMAT, "Failed to probe format: %s", path);
+        if (walked && n_audio == 0) {
+            if (decoder_cmd.empty()) return fail(RG_ERR_FORMAT, "No audio track found%s", "");
+            walked = false;
+        }
+        if (walked) {
+            out->n_audio_tracks = (uint32_t)n_audio;
+            if (track_index >= 0 && (size_t)track_index >= n_audio) {
+                snprintf(msg, sizeof msg, "Track index %d out of range (file has %zu audio track(s))", track_index, n_audio);
+                *err = msg;
+                return RG_ERR_INVALID_ARG;
+            }
+            mp4_track = track_index < 0 ? 0 : track_index;
+            if (mp4_track >= 32) return fail(RG_ERR_INVALID_ARG, "Track index %d: more audio tracks than this library lists%s", "", mp4_track);
+            const rg_mp4_audio_track &t = tr[mp4_track];
+            if (t.sample_rate == 0) return fail(RG_ERR_FORMAT, "Unknown sample rate%s", "");
+            if (t.codec == RG_CODEC_MP3) {
+                // the track's samples are MPEG audio frames: laid end to end they are the stream the library's decoder takes
+                size_t n_au = 0;
+                if (rg_mp4_access_units(bytes.data(), bytes.size(), (size_t)mp4_track, nullptr, nullptr, 0, &n_au) != RG_DEMUX_OK)
+                    return fail(RG_ERR_FORMAT, "Failed to probe format: %s", path);
+                std::vector<uint64_t> off(n_au);
+                std::vector<uint32_t> sz(n_au);
+                size_t got = 0;
+                (void)rg_mp4_access_units(bytes.data(), bytes.size(), (size_t)mp4_track, off.data(), sz.data(), n_au, &got);
+                std::vector<uint8_t> es;
+                for (size_t i = 0; i < got && i < n_au; ++i) es.insert(es.end(), bytes.begin() + (ptrdiff_t)off[i], bytes.begin() + (ptrdiff_t)(off[i] + sz[i]));
+                bytes.swap(es);
+            }
+        }
+    }
+    if (!mp4 || tr_is_mp3(bytes, mp4)) {
         // the probe (src/replaygain.rs:815-822) and the packet loop (:881-904) for an MPEG audio stream
         rg_mp3_stream_info si;
         if (rg_mp3_scan(bytes.data(), bytes.size(), &si) == RG_MP3DEC_OK && si.audio_frames > 0) {
@@ -524,11 +573,15 @@ int load_audio_for(const std::string &decoder_cmd, int gpu_decode, const char *p
             return RG_OK;
         }
     }
-    if (decoder_cmd.empty())  // src/replaygain.rs:815-822: the probe knows no such format
-        return fail(RG_ERR_FORMAT, mp4 ? "Failed to probe format: %s (MP4/AAC: no AAC decoder is built; set a decoder command: rg_set_decoder_command)"
+    if (decoder_cmd.empty())  // src/replaygain.rs:861-863 (AAC: the probe succeeded, the codec is missing) / :815-822 (the probe knows no such format)
+        return fail(RG_ERR_FORMAT, mp4 ? "Failed to create decoder: %s (an AAC track; no AAC decoder is built into this library: set a decoder command, rg_set_decoder_command)"
                                        : "Failed to probe format: %s (neither MPEG Layer III nor RIFF/WAVE, and no decoder command is set: rg_set_decoder_command)",
                     path);
     std::string cmd = decoder_cmd;
+    {   // "{track}" = index of the selected audio track (ffmpeg: -map 0:a:{track})
+        const std::string tn = std::to_string(mp4_track);
+        for (size_t at = cmd.find("{track}"); at != std::string::npos; at = cmd.find("{track}", at + tn.size())) cmd.replace(at, 7, tn);
+    }
     const std::string q = shell_quote(path);
     size_t at = cmd.find("{}");
     if (at == std::string::npos) cmd += " " + q;
@@ -680,6 +733,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
     std::vector<PipeFile> pf(n);
     std::atomic<uint64_t> t_read{0}, t_compact{0}, t_wait{0}, t_copy{0};  // trace: microseconds summed over the loader threads
     const std::string cmd = c->decoder_cmd;
+    const int32_t track_index = c->file_track_index;
     const int device = c->device;
     std::atomic<size_t> next_file{0};
 
@@ -721,7 +775,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         uint64_t main_len = 0;
         const double tl1 = trace ? now() : 0.0;
         if (mp4 || rg_mp3_compact_stream(sc.p, len, &sc.slots, &sc.tiles, &main_len, &si) != RG_MP3DEC_OK || si.audio_frames == 0) {
-            (*rcs)[i] = load_audio_for(cmd, 2, path, &la, &err);  // the decoder command, or the reference's probe error
+            (*rcs)[i] = load_audio_for(cmd, 2, path, &la, &err, track_index);  // the decoder command, or the reference's probe error
             return;
         }
         la.sample_rate = si.sample_rate;
@@ -946,9 +1000,10 @@ int load_many(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedA
         if (workers > n) workers = (unsigned)n;
         std::atomic<size_t> next{0};
         const std::string cmd = c->decoder_cmd;
+        const int32_t track_index = c->file_track_index;
         const int gpu_decode = c->gpu_mp3_decode;
         auto work = [&]() {
-            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) rcs[i] = load_audio_for(cmd, gpu_decode, paths[i], &(*out)[i], &errs[i]);  // (*out) holds >= n entries
+            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) rcs[i] = load_audio_for(cmd, gpu_decode, paths[i], &(*out)[i], &errs[i], track_index);  // (*out) holds >= n entries
         };
         if (workers <= 1) {
             work();
@@ -969,9 +1024,9 @@ int load_many(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedA
 }
 
 // Some(idx) selects among the audio tracks of a container (src/replaygain.rs:838-851); a WAV stream has one
-int check_track_index(rg_ctx *c, int32_t track_index) {
-    if (track_index > 0)
-        return rg_set_err(c, RG_ERR_INVALID_ARG, "Track index %d out of range (file has 1 audio track(s))", track_index);
+int check_track_index(rg_ctx *c, int32_t track_index, uint32_t n_audio_tracks) {
+    if (track_index >= 0 && (uint32_t)track_index >= n_audio_tracks)
+        return rg_set_err(c, RG_ERR_INVALID_ARG, "Track index %d out of range (file has %u audio track(s))", track_index, n_audio_tracks);
     return RG_OK;
 }
 
@@ -1006,9 +1061,11 @@ extern "C" int rg_analyze_wav_batch(rg_ctx *c, const void *const *wav, const siz
 extern "C" int rg_analyze_track(rg_ctx *c, const char *path, int32_t track_index, rg_track_result *out) {
     if (!c || !out) return RG_ERR_INVALID_ARG;
     std::vector<LoadedAudio> &in = file_pool(c, 1);
+    c->file_track_index = track_index;
     int rc = load_one(c, path, &in);
+    c->file_track_index = -1;
     if (rc != RG_OK) return rc;
-    rc = check_track_index(c, track_index);
+    rc = check_track_index(c, track_index, in[0].n_audio_tracks);
     if (rc != RG_OK) return rc;
     std::vector<rg_track_desc> descs;
     size_t arena_bytes = 0;
@@ -1054,9 +1111,9 @@ static int file_outcome(const LoadedAudio &la, int load_rc, const std::string &l
         *msg = load_err;
         return load_rc;
     }
-    if (track_index > 0) {
+    if (track_index >= 0 && (uint32_t)track_index >= la.n_audio_tracks) {
         char m[128];
-        snprintf(m, sizeof m, "Track index %d out of range (file has 1 audio track(s))", track_index);
+        snprintf(m, sizeof m, "Track index %d out of range (file has %u audio track(s))", track_index, la.n_audio_tracks);
         *msg = m;
         return RG_ERR_INVALID_ARG;
     }
@@ -1106,7 +1163,9 @@ extern "C" int rg_analyze_album_begin(rg_ctx *c, const char *const *paths, size_
         const double t0 = now();
         std::vector<int> rcs;
         std::vector<std::string> errs;
+        c->file_track_index = track_index;
         rc = load_many(c, paths + first, cnt, &in, &rcs, &errs);
+        c->file_track_index = -1;
         if (rc != RG_OK) return fail_at(first, rc);
         for (size_t i = 0; i < cnt; ++i) {
             std::string msg;
@@ -1152,7 +1211,9 @@ static int analyze_tracks_group(rg_ctx *c, const char *const *paths, size_t firs
     std::vector<LoadedAudio> &in = file_pool(c, n);
     std::vector<int> rcs;
     std::vector<std::string> errs;
+    c->file_track_index = track_index;
     int rc = load_many(c, paths, n, &in, &rcs, &errs);
+    c->file_track_index = -1;
     if (rc != RG_OK) return rc;
     // the batch holds the files that loaded and whose rate the analysis knows; `slot` maps them back
     std::vector<size_t> slot;
