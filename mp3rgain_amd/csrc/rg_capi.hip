@@ -180,9 +180,8 @@ extern "C" rg_ctx *rg_create(int device) {
         // streams (slot k runs on stream k mod RG_SLOT_STREAMS).  A slot's buffers are reused n_slots batches
         // later, so with more slots than streams a batch never waits in its queue for the album tail (collective
         // + percentile on the caller's stream) of the batch that had the buffers before it.
-        const int nstreams_dbg = getenv("RG_DBG_STREAMS") ? atoi(getenv("RG_DBG_STREAMS")) : RG_SLOT_STREAMS;  // EXPERIMENT
-        if (k < nstreams_dbg) e = hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking);
-        else S.stream = c->slots[k % nstreams_dbg].stream;
+        if (k < RG_SLOT_STREAMS) e = hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking);
+        else S.stream = c->slots[k % RG_SLOT_STREAMS].stream;
         if (e == hipSuccess) e = hipEventCreateWithFlags(&S.staging_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&S.batch_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&S.album_done, hipEventDisableTiming);
@@ -245,7 +244,7 @@ extern "C" void rg_destroy(rg_ctx *c) {
         if (S.staging_done) (void)hipEventDestroy(S.staging_done);
         if (S.batch_done) (void)hipEventDestroy(S.batch_done);
         if (S.album_done) (void)hipEventDestroy(S.album_done);
-        if (S.stream && k < (getenv("RG_DBG_STREAMS") ? atoi(getenv("RG_DBG_STREAMS")) : RG_SLOT_STREAMS)) (void)hipStreamDestroy(S.stream);
+        if (S.stream && k < RG_SLOT_STREAMS) (void)hipStreamDestroy(S.stream);
     }
     if (c->user_ev) (void)hipEventDestroy(c->user_ev);
     c->d_coefs.release();

@@ -235,7 +235,7 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
         double lanes = 0;
         for (uint32_t id : g.ids) lanes += (double)((tracks[id].frames + stride - 1) / stride) * g.nch;
         double waves = ceil(lanes / block) * (block / 64);  // blocks run through track boundaries: no per-track padding
-        waves *= getenv("RG_DBG_STREAMS") ? atoi(getenv("RG_DBG_STREAMS")) : (c->n_slots < RG_SLOT_STREAMS ? c->n_slots : RG_SLOT_STREAMS);  // batches in flight = streams
+        waves *= c->n_slots < RG_SLOT_STREAMS ? c->n_slots : RG_SLOT_STREAMS;  // batches in flight = streams
         const double cost = (double)stride * 28.0 + (double)L * 2.0 + (double)std::min(L, H10) * 10.0 + 1500.0 + 1500.0 + 60.0 * (m - 1);
         // residency: the LDS image of the response tables + one 4 KiB tile per wave bound the blocks per CU
         const double lds = (double)rg_tm_lds_bytes(L, Hl, block);
@@ -495,7 +495,6 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
                                         gl.total_windows, S.d_nonfinite.p, cleared ? nullptr : S.d_hist.p, (uint64_t)acc_words, s));
             if (gl.main_grid != 0) cleared = true;
             if (e1) RG_HIP(c, hipEventRecord(e1, s));
-            if (!getenv("RG_DBG_NOFIX"))  // EXPERIMENT
             RG_HIP(c, rg_launch_tm_fix(gl.nch, &gl.tb->geom, &gl.tb->fix, d_tm_tracks + gl.list_off,
                                        (uint32_t)gl.list_n, gl.fix_grid, S.d_tm_rec.p, gl.total_recs, S.d_tm_win.p,
                                        gl.total_windows, S.d_nonfinite.p, S.d_imprecise.p, S.d_hist.p, S.peak_ptr, done_ptr, S.d_results.p, s));
