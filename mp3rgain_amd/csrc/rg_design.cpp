@@ -123,6 +123,31 @@ void matmul_ld(int n, const ld *A, const ld *B, ld *C) {
     memcpy(C, t.data(), sizeof(ld) * n * n);
 }
 
+// G = R'R, R upper triangular; false when G is not (numerically) positive definite
+bool cholesky_ld(int n, const ld *G, ld *R) {
+    for (int i = 0; i < n * n; ++i) R[i] = 0.0L;
+    for (int i = 0; i < n; ++i) {
+        ld d = G[i * n + i];
+        for (int k = 0; k < i; ++k) d -= R[k * n + i] * R[k * n + i];
+        if (!(d > 0.0L)) return false;
+        R[i * n + i] = sqrtl(d);
+        for (int j = i + 1; j < n; ++j) {
+            ld v = G[i * n + j];
+            for (int k = 0; k < i; ++k) v -= R[k * n + i] * R[k * n + j];
+            R[i * n + j] = v / R[i * n + i];
+        }
+    }
+    return true;
+}
+// x := x R^-1 for a row vector x (R upper triangular)
+void row_times_inverse_ld(int n, ld *x, const ld *R) {
+    for (int j = 0; j < n; ++j) {
+        ld v = x[j];
+        for (int k = 0; k < j; ++k) v -= x[k] * R[k * n + j];
+        x[j] = v / R[j * n + j];
+    }
+}
+
 ld maxabs(const ld *A, int n) {
     ld m = 0;
     for (int i = 0; i < n; ++i) m = fabsl(A[i]) > m ? fabsl(A[i]) : m;
@@ -198,32 +223,85 @@ void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out, uint32_
     hp[10] = h[10];
     hp[11] = h[11];
 
-    // T'[n] = h' F'^n  (row vector iteration), prefix Gram matrices alongside
+    // T'[n] = h' F'^n  (row vector iteration)
+    std::vector<ld> Tl((size_t)L * 12);
+    {
+        ld row[12];
+        memcpy(row, hp, sizeof row);
+        for (uint32_t n = 0; n < L; ++n) {
+            for (int j = 0; j < 12; ++j) Tl[(size_t)n * 12 + j] = row[j];
+            ld nr[12];
+            for (int j = 0; j < 10; ++j) {
+                ld s = 0;
+                for (int i = 0; i < 10; ++i) s += row[i] * Fy[i * 10 + j];
+                nr[j] = s;
+            }
+            for (int j = 0; j < 2; ++j) nr[10 + j] = row[10] * Fb[0 * 2 + j] + row[11] * Fb[1 * 2 + j];
+            memcpy(row, nr, sizeof row);
+        }
+    }
+    // ---- whitening (64 / 96 kHz).  There the Yule-Walker poles crowd z = 1: in DF2T coordinates the responses to the ten
+    // fast states are nearly parallel, a unit state reaches the output with gain 71 / 478, and sigma'G sigma is the small
+    // difference of terms 10^4 - 10^5 times its size.  Each block is therefore carried in coordinates in which its own Gram
+    // matrix over the segment's first window is the identity: G_ff = R'R (Cholesky), sigma_f := R sigma_f, T_f := T_f R^-1,
+    // Phi_f := R Phi_f R^-1, likewise the slow pair.  The main kernel is unchanged (it multiplies by whatever table it is
+    // given and hands over its DF2T end state); the fix-up kernel applies R once per segment (Wf / Xs below).
+    ld Rf[100], Rs[4];
+    for (int i = 0; i < 100; ++i) Rf[i] = (i / 10 == i % 10) ? 1.0L : 0.0L;
+    Rs[0] = Rs[3] = 1.0L; Rs[1] = Rs[2] = 0.0L;
+    out->whiten = false;
+    if (rc.sample_rate > 48000) {
+        ld Gf[100] = {0}, Gs[4] = {0};
+        for (uint32_t n = 0; n < L; ++n) {
+            const ld *r = &Tl[(size_t)n * 12];
+            for (int i = 0; i < 10; ++i)
+                for (int j = 0; j < 10; ++j) Gf[i * 10 + j] += r[i] * r[j];
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 2; ++j) Gs[i * 2 + j] += r[10 + i] * r[10 + j];
+        }
+        ld Rf2[100], Rs2[4];
+        if (cholesky_ld(10, Gf, Rf2) && cholesky_ld(2, Gs, Rs2)) {
+            memcpy(Rf, Rf2, sizeof Rf);
+            memcpy(Rs, Rs2, sizeof Rs);
+            out->whiten = true;
+            for (uint32_t n = 0; n < L; ++n) {
+                row_times_inverse_ld(10, &Tl[(size_t)n * 12], Rf);
+                row_times_inverse_ld(2, &Tl[(size_t)n * 12 + 10], Rs);
+            }
+            // Phi := R Phi R^-1 (one step; its powers follow)
+            ld A[100];
+            matmul_ld(10, Rf, Fy, A);
+            for (int i = 0; i < 10; ++i) row_times_inverse_ld(10, &A[i * 10], Rf);
+            memcpy(Fy, A, sizeof A);
+            ld B2[4];
+            matmul_ld(2, Rs, Fb, B2);
+            for (int i = 0; i < 2; ++i) row_times_inverse_ld(2, &B2[i * 2], Rs);
+            memcpy(Fb, B2, sizeof B2);
+        }
+    }
+    for (int i = 0; i < 100; ++i) out->Wf[i] = (double)Rf[i];
+    // Xs = [Rs X | Rs]: slow pair of a DF2T end state (s, t) in the carried coordinates = Rs (t + X s)
+    for (int q = 0; q < 2; ++q) {
+        for (int j = 0; j < 10; ++j) out->Xs[q][j] = (double)(Rs[q * 2 + 0] * X[0][j] + Rs[q * 2 + 1] * X[1][j]);
+        out->Xs[q][10] = (double)Rs[q * 2 + 0];
+        out->Xs[q][11] = (double)Rs[q * 2 + 1];
+    }
+    // the rounded table and the prefix Gram matrices (the kernel multiplies by the rounded table, so the Gram matrices use
+    // the rounded values too)
     out->T.resize((size_t)L * 12);
     out->Gp.resize((size_t)L * RG_TM_GRAM);
     std::vector<ld> gram(RG_TM_GRAM, 0.0L);
-    ld row[12];
-    memcpy(row, hp, sizeof row);
     ld tmax = 0;
     for (uint32_t n = 0; n < L; ++n) {
         for (int j = 0; j < 12; ++j) {
-            out->T[(size_t)n * 12 + j] = (double)row[j];
-            if (j < 10 && fabsl(row[j]) > tmax) tmax = fabsl(row[j]);
+            out->T[(size_t)n * 12 + j] = (double)Tl[(size_t)n * 12 + j];
+            if (j < 10 && fabsl(Tl[(size_t)n * 12 + j]) > tmax) tmax = fabsl(Tl[(size_t)n * 12 + j]);
         }
-        // the kernel multiplies by the rounded table, so the Gram matrix uses the rounded values too
         int p = 0;
         for (int j = 0; j < 12; ++j)
             for (int k = j; k < 12; ++k, ++p)
                 gram[p] += (ld)out->T[(size_t)n * 12 + j] * (ld)out->T[(size_t)n * 12 + k];
         for (int q = 0; q < RG_TM_GRAM; ++q) out->Gp[(size_t)n * RG_TM_GRAM + q] = (double)gram[q];
-        ld nr[12];
-        for (int j = 0; j < 10; ++j) {
-            ld s = 0;
-            for (int i = 0; i < 10; ++i) s += row[i] * Fy[i * 10 + j];
-            nr[j] = s;
-        }
-        for (int j = 0; j < 2; ++j) nr[10 + j] = row[10] * Fb[0 * 2 + j] + row[11] * Fb[1 * 2 + j];
-        memcpy(row, nr, sizeof row);
     }
     // H10: first multiple of 4 after which every fast response stays below 1e-13 of its maximum
     uint32_t H10 = 0;
@@ -267,12 +345,20 @@ void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out, uint32_
     out->PhiY.resize((size_t)rounds * 100);
     out->PhiB.resize((size_t)rounds * 4);
 
-    // track-start state: every DF2T state holds the +1e-10 offset once (see rg_tm.h), then t' = t + X s
+    // track-start state: every DF2T state holds the +1e-10 offset once (see rg_tm.h), then t' = t + X s, then the carried
+    // coordinates (the identity below 64 kHz)
     const ld c = 1e-10L;
-    for (int j = 0; j < 12; ++j) out->sigma0[j] = (double)c;
+    ld s0[12];
+    for (int j = 0; j < 10; ++j) s0[j] = c;
     for (int i = 0; i < 2; ++i) {
         ld s = c;
         for (int j = 0; j < 10; ++j) s += X[i][j] * c;
-        out->sigma0[10 + i] = (double)s;
+        s0[10 + i] = s;
     }
+    for (int i = 0; i < 10; ++i) {
+        ld v = 0;
+        for (int j = 0; j < 10; ++j) v += Rf[i * 10 + j] * s0[j];
+        out->sigma0[i] = (double)v;
+    }
+    for (int i = 0; i < 2; ++i) out->sigma0[10 + i] = (double)(Rs[i * 2 + 0] * s0[10] + Rs[i * 2 + 1] * s0[11]);
 }

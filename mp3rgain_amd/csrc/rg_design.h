@@ -29,6 +29,9 @@ struct RgTmDesign {
     std::vector<double> PhiY;    // [rounds][10][10]  (F_y^L)^(2^r)
     std::vector<double> PhiB;    // [rounds][2][2]    (F_b^L)^(2^r)
     double X[2][10];             // coordinate change: t' = t + X s
+    bool whiten = false;         // 64 / 96 kHz: each block is carried in coordinates in which its Gram matrix is the identity
+    double Wf[100];              // [10][10] upper triangular: fast block of a DF2T end state -> carried coordinates (identity if !whiten)
+    double Xs[2][12];            // slow pair of a DF2T end state (s, t) -> carried coordinates: Rs (t + X s) = Xs [s; t]
     double sigma0[12];           // track-start state in block-diagonal coordinates
     double resid;                // Sylvester residual (diagnostic)
     bool ok = false;

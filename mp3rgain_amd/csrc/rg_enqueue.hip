@@ -127,15 +127,16 @@ int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out, u
     if (!D.ok) return RG_ERR_INVALID_ARG;
     const size_t nT = D.T.size(), nG = D.Gp.size(), nY = D.PhiY.size(), nB = D.PhiB.size();
     const size_t nL = (size_t)D.H10 * 12 + (size_t)(D.L - D.H10) * 2;
-    const size_t total = nT + nG + nY + nB + 20 + 12 + 8 + nL + 2;
+    const size_t total = nT + nG + nY + nB + 24 + 12 + 100 + 8 + nL + 2;
     std::vector<double> blob(total, 0.0);
     size_t o = 0;
     const size_t oT = o; memcpy(&blob[o], D.T.data(), nT * 8); o += nT;
     const size_t oG = o; memcpy(&blob[o], D.Gp.data(), nG * 8); o += nG;
     const size_t oY = o; if (nY) memcpy(&blob[o], D.PhiY.data(), nY * 8); o += nY;
     const size_t oB = o; if (nB) memcpy(&blob[o], D.PhiB.data(), nB * 8); o += nB;
-    const size_t oX = o; memcpy(&blob[o], &D.X[0][0], 20 * 8); o += 20;
+    const size_t oX = o; memcpy(&blob[o], &D.Xs[0][0], 24 * 8); o += 24;
     const size_t oS = o; memcpy(&blob[o], D.sigma0, 12 * 8); o += 12;
+    memcpy(&blob[o], D.Wf, 100 * 8); o += 100;  // [last Gram | PhiY | PhiB | Xs | sigma0 | Wf] is one image for the fix-up kernel
     o = (o + 1) & ~(size_t)1;  // 16-byte alignment of the LDS image
     const size_t oL = o;
     for (uint32_t n = 0; n < D.H10; ++n)
@@ -154,6 +155,7 @@ int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out, u
     g.fix_windows = (RG_TM_BLOCK - g.warm) / g.k;
     g.block = rg_tm_choose_block(D.L, D.H10);
     g.m = m;
+    g.whiten = D.whiten ? 1u : 0u;
     if (m > 1 && rg_tm_lds_bytes(D.L, D.H10, g.block) > RG_TM_LDS_BYTES) {  // multi-window segments run on the LDS path only
         tb->design.ok = false;
         return RG_ERR_INVALID_ARG;
@@ -351,14 +353,13 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
     for (size_t t = 0; t < n; ++t) {
         fill_common(c, tracks[t], base, (uint32_t)t, c->h_tracks[t]);
         const int ri = rg_rate_index(tracks[t].sample_rate);
-        // Auto mode keeps variant 2 to the rates where its state representation is well conditioned.  At 64 and
-        // 96 kHz the Yule-Walker poles crowd z = 1: unit DF2T states reach the output with gains of 71 and 478
-        // (<= 9 at 48 kHz and below, rg_tm_design), so after an impulse or with a DC offset the moments cancel
-        // to ~1e-8 of the state energy and a nearly silent window can land a few bins off.  Variant 1 follows the
-        // reference's own evaluation order and is exact at every rate (0 of 4000 random tracks differ; variant 2:
-        // 14, all at these two rates), at 1/20 of the speed -- and no MP3 has these rates.
-        const bool tm_rate = (c->kernel_variant == 2 || tracks[t].sample_rate <= 48000u) &&
-                             !(c->force_exact.size() == n && c->force_exact[t]);
+        // Every stable rate runs on variant 2.  (Until round 3 auto mode kept 64 and 96 kHz on variant 1: there the Yule-Walker
+        // poles crowd z = 1, unit DF2T states reach the output with gains of 71 and 478, and with the state carried in DF2T
+        // coordinates the moments cancelled to ~1e-8 of their terms -- 14 of 4000 random tracks had a displaced window and the
+        // self-check missed 83 of 1200 pathological ones.  The fix-up kernel now carries each block in coordinates in which
+        // its Gram matrix is the identity (rg_design.cpp: whitening): 0 of 2227 random 64 / 96 kHz tracks differ, 1 of 2400
+        // pathological ones does and is flagged, so the exact repeat covers it like at every other rate.)
+        const bool tm_rate = !(c->force_exact.size() == n && c->force_exact[t]);
         if (use_tm && tm_rate && c->design[ri].stable) {
             const int nch = tracks[t].channels >= 2 ? 2 : 1;
             TmGroup *g = nullptr;

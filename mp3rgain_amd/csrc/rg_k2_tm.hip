@@ -647,17 +647,18 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     // ---- the wave-uniform tables, one contiguous image in the design blob (rg_enqueue.hip: the last prefix
     // Gram matrix is followed by PhiY, PhiB, X, sigma0), copied to LDS under the record loads: as scalar
     // loads they missed the constant cache in every wave and sat on the critical path of each scan round
-    __shared__ double ftab[RG_TM_GRAM + RG_TM_MAX_ROUNDS * 104 + 32];
+    __shared__ double ftab[RG_TM_GRAM + RG_TM_MAX_ROUNDS * 104 + 36 + 100];
     {
         const double *__restrict__ src = FT.Gp + (size_t)(G.L - 1) * RG_TM_GRAM;
-        const int n = RG_TM_GRAM + (int)G.rounds * 104 + 32;
+        const int n = RG_TM_GRAM + (int)G.rounds * 104 + 36 + (G.whiten ? 100 : 0);
         for (int q = i; q < n; q += RG_TM_BLOCK) ftab[q] = src[q];
     }
     const double *const Gfull = ftab;
     const double *const PhiY = ftab + RG_TM_GRAM;
     const double *const PhiB = PhiY + G.rounds * 100;
     const double *const X = PhiB + G.rounds * 4;
-    const double *const S0 = X + 20;
+    const double *const S0 = X + 24;
+    const double *const Wf = S0 + 12;
 
     // ---- zero-state end states of this segment, all channels (the moments are fetched where they are used:
     // the kernel is latency bound and lives on occupancy, so the live register set is kept small) ----------
@@ -675,12 +676,26 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     const bool vstart = in_block && seg == -1;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
+        double tq[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            double acc = w[c][10 + q];
+            // below 64 kHz Xs = [X | I]: t' = t + X s, summed as it always was; above, the pair's own 2 x 2 comes with it
+            double acc = G.whiten ? fma(X[q * 12 + 10], w[c][10], X[q * 12 + 11] * w[c][11]) : w[c][10 + q];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) acc = fma(X[q * 10 + j], w[c][j], acc);
-            w[c][10 + q] = acc;
+            for (int j = 0; j < 10; ++j) acc = fma(X[q * 12 + j], w[c][j], acc);
+            tq[q] = acc;
+        }
+        w[c][10] = tq[0];
+        w[c][11] = tq[1];
+        if (G.whiten) {  // the fast block into the coordinates it is carried in: Wf is upper triangular, row i needs w[i..9]
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < 10; ++j)
+                    if (j >= i) acc = fma(Wf[i * 10 + j], w[c][j], acc);
+                w[c][i] = acc;
+            }
         }
         if (vstart) {
 #pragma unroll

@@ -83,13 +83,14 @@ struct RgTmGeom {
                            // whole windows, the transient moments only over the first -- by the second window the
                            // start state has decayed below 1e-30 of itself -- and hands windows 2..m over as plain
                            // energies, which rg_tm_direct_kernel bins)
+    uint32_t whiten;       // 64 / 96 kHz: the fix-up kernel takes a DF2T end state's fast block through Wf (rg_design.cpp)
     const double *T;       // [L][12] homogeneous responses, block-diagonal coordinates
     const double *Tlds;    // the same packed for LDS: [H10][12] then [L - H10][2] (only the slow pair)
 };
 
 // device tables of the fix-up kernel (passed by value; all wave-uniform reads)
 struct RgTmFixTables {
-    const double *X;       // [2][10]  coordinate change t' = t + X s
+    const double *X;       // [2][12]  slow pair of a DF2T end state (s, t) in the carried coordinates: Xs [s; t] (= t + X s below 64 kHz)
     const double *sigma0;  // [12]     state at the start of a track
     const double *PhiY;    // [rounds][10][10]  (F_y^L)^(2^r)
     const double *PhiB;    // [rounds][2][2]    (F_b^L)^(2^r)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Throughput across sample rates and channel counts (device-resident synthetic PCM), auto mode: variant 2 up to
-48 kHz, the order-faithful kernel at 64 / 96 kHz.   python tools/rate_sweep.py [tracks] [minutes]"""
+"""Throughput across sample rates and channel counts (device-resident synthetic PCM), auto mode (variant 2 at every stable
+rate since round 3; until then the order-faithful kernel at 64 / 96 kHz).   python tools/rate_sweep.py [tracks] [minutes]"""
 import sys
 import time
 from pathlib import Path
