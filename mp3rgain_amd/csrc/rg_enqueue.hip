@@ -153,7 +153,7 @@ int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out, u
     g.rounds_fast = D.rounds_fast;
     g.warm = 1u << D.rounds;
     g.fix_windows = (RG_TM_BLOCK - g.warm) / g.k;
-    g.block = rg_tm_choose_block(D.L, D.H10);
+    g.block = rg_tm_choose_block(D.L, D.H10, m);
     g.m = m;
     g.whiten = D.whiten ? 1u : 0u;
     if (m > 1 && rg_tm_lds_bytes(D.L, D.H10, g.block) > RG_TM_LDS_BYTES) {  // multi-window segments run on the LDS path only
@@ -232,7 +232,7 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
     for (size_t i = 0; i < cand.size(); ++i) {
         const uint32_t L = cand[i].L, m = cand[i].m;
         const uint32_t Hl = H10 >= L ? L : H10;
-        const uint32_t block = rg_tm_choose_block(L, Hl);
+        const uint32_t block = rg_tm_choose_block(L, Hl, m);
         const uint64_t stride = (uint64_t)L * m;
         double lanes = 0;
         for (uint32_t id : g.ids) lanes += (double)((tracks[id].frames + stride - 1) / stride) * g.nch;
@@ -243,7 +243,7 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
         const double lds = (double)rg_tm_lds_bytes(L, Hl, block);
         if (m > 1 && lds > (double)RG_TM_LDS_BYTES) continue;
         // waves per SIMD that can be resident: three narrow blocks, or one wide block, per CU
-        const double blocks_cu = block == RG_TM_BLOCK ? std::max(1.0, std::min(3.0, floor((double)RG_TM_LDS_BYTES / lds))) : 3.0;
+        const double blocks_cu = block == RG_TM_BLOCK ? std::max(1.0, std::min(3.0, floor((double)RG_TM_LDS_BYTES / lds))) : (double)block / 256.0;
         const double cap = 1024.0 * blocks_cu;
         const double rounds = waves <= cap ? ceil(waves / 1024.0) : waves / 1024.0 + 1.0;
         // FP64 issue efficiency by waves per SIMD (tools/ubench/frame.hip: 188 / 160 / 147 cycles per frame)

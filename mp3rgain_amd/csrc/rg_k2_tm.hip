@@ -386,7 +386,7 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
 // MULTI = multi-window segments (G.m > 1); a separate instantiation, so that the one-window kernel's register
 // allocation is not disturbed by the window loop
 template <int FMT, bool MULTI>
-__global__ void __launch_bounds__(RG_TM_BLOCK_WIDE)
+__global__ void __launch_bounds__(MULTI ? RG_TM_BLOCK_WIDE_MULTI : RG_TM_BLOCK_WIDE)
 rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restrict__ tracks, uint32_t n_tracks,
                   double *__restrict__ rec, uint32_t total_recs, double *__restrict__ win_energy /* [channels][total_windows], m > 1 */,
                   uint32_t total_windows, uint32_t *__restrict__ nonfinite, uint32_t lds_tables,

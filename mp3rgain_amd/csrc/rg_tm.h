@@ -30,6 +30,11 @@
 // Main kernel only: when the LDS image of the response tables is so large that fewer than three 256-thread
 // blocks fit a CU (160 KiB), one 768-thread block shares a single image and still puts 3 waves on each SIMD.
 #define RG_TM_BLOCK_WIDE 768
+#ifndef RG_TM_BLOCK_WIDE_MULTI
+#define RG_TM_BLOCK_WIDE_MULTI 768   // multi-window segments (the m > 1 instantiation of the main kernel).  1024 = 128 VGPRs = four
+                                     // waves per SIMD was tried in round 3: 204 bytes per lane spill into the frame loop, 20.8 ms per
+                                     // step against 18.7; the loop without the moments alone needs 139 registers
+#endif
 #define RG_TM_WAVE_TILE_BYTES 4096  // PCM staging tile of one wave: 64 rows x 16 frames x 4 B
 #define RG_TM_LDS_BYTES (160u * 1024u)
 // Self-check of the fix-up kernel.  A window's energy S = A + 2 B.sigma + sigma'G sigma is assembled from
@@ -101,8 +106,9 @@ struct RgTmFixTables {
 static inline size_t rg_tm_lds_bytes(uint32_t L, uint32_t H10, uint32_t block) {
     return ((size_t)H10 * 12 + (size_t)(L - H10) * 2) * sizeof(double) + (size_t)(block / 64) * RG_TM_WAVE_TILE_BYTES;
 }
-static inline uint32_t rg_tm_choose_block(uint32_t L, uint32_t H10) {
+static inline uint32_t rg_tm_choose_block(uint32_t L, uint32_t H10, uint32_t m = 1) {
     if (3 * rg_tm_lds_bytes(L, H10, RG_TM_BLOCK) <= RG_TM_LDS_BYTES) return RG_TM_BLOCK;
-    if (rg_tm_lds_bytes(L, H10, RG_TM_BLOCK_WIDE) <= RG_TM_LDS_BYTES) return RG_TM_BLOCK_WIDE;
+    const uint32_t wide = m > 1 ? RG_TM_BLOCK_WIDE_MULTI : RG_TM_BLOCK_WIDE;
+    if (rg_tm_lds_bytes(L, H10, wide) <= RG_TM_LDS_BYTES) return wide;
     return RG_TM_BLOCK;
 }
