@@ -234,6 +234,7 @@ def main() -> int:
     ap.add_argument("--tm-segment", type=int, default=0, help="force variant 2 segment length (tuning)")
     ap.add_argument("--tm-windows", type=int, default=0, help="most windows per lane of variant 2 (tuning; 0 = library default, 1 = one)")
     ap.add_argument("--slots", type=int, default=0, help="pipeline slots of the library (0 = default)")
+    ap.add_argument("--tm-split", type=int, default=-1, help="tuning key 9: 1 = windows 2..m of multi-window segments in a kernel of their own")
     ap.add_argument("--mixed", action="store_true",
                     help="BASELINE configs[4]'s PCM side instead: half the tracks at 44.1 kHz, half at 48 kHz, every 10th mono, "
                          "every 20th with full-scale (clipped) peaks")
@@ -291,6 +292,8 @@ def main() -> int:
         an.set_tuning(3, args.slots)
     if args.tm_windows:
         an.set_tuning(4, args.tm_windows)
+    if args.tm_split >= 0:
+        an.set_tuning(9, args.tm_split)
     # No caller stream is attached: every batch, its album tail and the collective in between run on the
     # context's own pipeline streams (rg_batch_stream), which costs no cross-stream event per step.
 

@@ -185,7 +185,9 @@ int rg_set_kernel(rg_ctx *ctx, int variant);
  * the host's cores, the rest on the GPU; 0 = the host decoder.  (An album of 64 three-minute 320 kb/s files:
  * 0.96 s / 0.25 s / 0.04 s / 0.017 s for 0 / 1 / 2 / 3.),
  * key 7 = host threads the file-level entry points load files with (0 = every core this process may use; a node of
- * several contexts gives each its share, mp3rgain_amd_node.h). */
+ * several contexts gives each its share, mp3rgain_amd_node.h),
+ * key 9 = 1: windows 2..m of variant 2's multi-window segments run in a kernel of their own at four waves per SIMD instead of
+ * three (same results; measured +0.3 % on configs[2]: the path is power-bound; default 0). */
 int rg_set_tuning(rg_ctx *ctx, int key, int64_t value);
 /* diagnostic (host only): variant 2's design for one rate and segment length.  T_out: [L][12],
  * gram_last_out: [78]; either may be NULL.  RG_ERR_INVALID_ARG when no design exists. */

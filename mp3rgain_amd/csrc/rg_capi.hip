@@ -320,6 +320,7 @@ extern "C" int rg_set_tuning(rg_ctx *c, int key, int64_t value) {
         case RG_TUNE_TM_WINDOWS: c->tune_tm_windows = (uint32_t)(value > 255 ? 255 : value); return RG_OK;
         case RG_TUNE_INGEST_CHUNK_KIB: c->tune_ingest_chunk_kib = (uint64_t)value; return RG_OK;
         case RG_TUNE_GPU_MP3_DECODE: c->gpu_mp3_decode = value > 3 ? 3 : (int)value; return RG_OK;
+        case RG_TUNE_TM_SPLIT: c->tm_split = value ? 1 : 0; return RG_OK;
         case RG_TUNE_LOADER_THREADS: c->loader_threads = (unsigned)(value > 1024 ? 1024 : value); return RG_OK;
         case RG_TUNE_PIPELINE_SLOTS: {
             if (sync_all(c) != RG_OK) return RG_ERR_DEVICE;

@@ -25,7 +25,7 @@ hipError_t rg_launch_track_results(const uint32_t *, const unsigned long long *,
 hipError_t rg_launch_album_merge(const uint32_t *, const unsigned long long *, uint32_t, uint32_t *, double *,
                                  hipStream_t);
 hipError_t rg_launch_tm_main(int fmt, int nch, const RgTmCoef *, const RgTmGeom *, const RgTmTrack *, uint32_t, uint32_t,
-                             double *, uint32_t, double *, uint32_t, uint32_t *, uint32_t *, uint64_t, hipStream_t);
+                             double *, uint32_t, double *, uint32_t, uint32_t *, uint32_t *, uint64_t, int, hipStream_t);
 hipError_t rg_launch_tm_fix(int nch, const RgTmGeom *, const RgTmFixTables *, const RgTmTrack *, uint32_t, uint32_t,
                             const double *, uint32_t, const double *, uint32_t, uint32_t *, uint32_t *, uint32_t *,
                             unsigned long long *, uint32_t *, rg_track_result *, hipStream_t);
@@ -493,7 +493,7 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
             if (rc != RG_OK) return rc;
             RG_HIP(c, rg_launch_tm_main(gl.fmt, gl.nch, &gl.K, &gl.tb->geom, d_tm_tracks + gl.list_off,
                                         (uint32_t)gl.list_n, gl.main_grid, S.d_tm_rec.p, gl.total_recs, S.d_tm_win.p,
-                                        gl.total_windows, S.d_nonfinite.p, cleared ? nullptr : S.d_hist.p, (uint64_t)acc_words, s));
+                                        gl.total_windows, S.d_nonfinite.p, cleared ? nullptr : S.d_hist.p, (uint64_t)acc_words, c->tm_split, s));
             if (gl.main_grid != 0) cleared = true;
             if (e1) RG_HIP(c, hipEventRecord(e1, s));
             RG_HIP(c, rg_launch_tm_fix(gl.nch, &gl.tb->geom, &gl.tb->fix, d_tm_tracks + gl.list_off,

@@ -52,8 +52,9 @@ def _ctx(capi):
 #   (2, -2)   transient-moment kernels, one segment per window
 #   (2, -3)   transient-moment kernels, four windows per segment (moments over the first, plain energies for the rest)
 #   (2, -4)   transient-moment kernels, sixteen windows per segment
-@pytest.fixture(params=[(1, 0), (2, 0), (2, -1), (2, -2), (2, -3), (2, -4)],
-                ids=["halo", "tm-auto", "tm-short", "tm-window", "tm-multi4", "tm-multi16"])
+#   (2, -5)   four windows per segment, windows 2..4 in the kernel of their own (tuning key 9: rg_tm_plain_kernel)
+@pytest.fixture(params=[(1, 0), (2, 0), (2, -1), (2, -2), (2, -3), (2, -4), (2, -5)],
+                ids=["halo", "tm-auto", "tm-short", "tm-window", "tm-multi4", "tm-multi16", "tm-multi4-split"])
 def analyzer(_ctx, request):
     variant, seg = request.param
     _ctx.set_kernel(variant)
@@ -71,7 +72,12 @@ def analyzer(_ctx, request):
     elif seg == -4:
         _ctx.set_tuning(2, 1)
         _ctx.set_tuning(4, 16)
+    elif seg == -5:
+        _ctx.set_tuning(2, 1)
+        _ctx.set_tuning(4, 4)
+        _ctx.set_tuning(9, 1)
     yield _ctx
+    _ctx.set_tuning(9, 0)
     _ctx.set_kernel(0)
     _ctx.set_tuning(1, 0)
     _ctx.set_tuning(2, 0)

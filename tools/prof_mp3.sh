@@ -23,3 +23,4 @@ run pmc_grbm --pmc GRBM_GUI_ACTIVE GRBM_COUNT
 run pmc_lds --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT
 python tools/prof_mp3_summary.py $OUT $P > $P/${PROF_ROUND}_mp3dev_pmc_summary.txt 2>&1
 tail -30 $P/${PROF_ROUND}_mp3dev_pmc_summary.txt
+[ -n "$KEEP_RAW" ] || rm -rf $OUT

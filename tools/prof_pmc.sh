@@ -17,7 +17,7 @@ export PROFILES_DIR=$R/gpurun_out/profiles   # only gpurun_out/ travels back: co
 mkdir -p $R/$OUT $PROFILES_DIR
 cd $R
 BENCH_ARGS="$*"
-run() { name=$1; shift; timeout ${PROF_TIMEOUT:-400} rocprofv3 "$@" -d $OUT/$name --output-format csv -- python bench.py --cpu-seconds 0 --no-configs1 $BENCH_ARGS $EXTRA > $OUT/$name.log 2>&1 || echo "$name failed/timeout"; }
+run() { name=$1; shift; timeout ${PROF_TIMEOUT:-400} rocprofv3 "$@" -d $OUT/$name --output-format csv -- python bench.py --cpu-seconds 0 --no-configs1 --no-mp3 $BENCH_ARGS $EXTRA > $OUT/$name.log 2>&1 || echo "$name failed/timeout"; }
 EXTRA="${KT_EXTRA:-}"
 run kt --kernel-trace --stats
 EXTRA="${KT_EXTRA:-} --slots 1"
@@ -38,3 +38,5 @@ run pmc_lat --pmc SQ_INST_LEVEL_SMEM SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM SQ_INSTS_V
 fi
 python tools/prof_summary.py $OUT $TAG $FRAMES "$BENCH_ARGS" > $PROFILES_DIR/${PROF_ROUND}_${TAG}_pmc_summary.txt 2>&1
 tail -5 $PROFILES_DIR/${PROF_ROUND}_${TAG}_pmc_summary.txt
+# only the summaries travel back (gpurun merges at most 64 MiB): the raw traces stay unless asked for
+[ -n "$KEEP_RAW" ] || rm -rf $OUT

@@ -74,7 +74,7 @@ for f in newest(f"{d}/kt/*/*kernel_trace.csv"):
                     "concurrency": tot / span if span else 1.0, "span_per_launch_ms": span / 1e6 / len(keep)}
 if spans:
     m = next((v for k, v in spans.items() if MAIN in k), None)
-    doc = {"command": f"rocprofv3 --kernel-trace --stats -- python bench.py --cpu-seconds 0 --no-configs1 {bench_args}".strip(),
+    doc = {"command": f"rocprofv3 --kernel-trace --stats -- python bench.py --cpu-seconds 0 --no-configs1 --no-mp3 {bench_args}".strip(),
            "frames_per_step": frames, "timed_steps": steps, "launch_groups_per_step": groups, "kernels": spans,
            "note": "launches_counted = the timed region's launches (the last steps x groups of the kernel); "
                    "span = first start to last end of those; concurrency = sum of durations / span"}
@@ -130,7 +130,7 @@ if main:
            "cvt_insts_per_launch": mean("SQ_INSTS_VALU_CVT"),
            "waves_per_launch": mean("SQ_WAVES"),
            "dispatches_averaged": {k: len(v) for k, v in cs.items() if k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64")},
-           "command": f"rocprofv3 --pmc <one group per pass> -- python bench.py --cpu-seconds 0 --no-configs1 {bench_args} --pre-roll 0.01 --steps 6 --warmup 1".replace("  ", " "),
+           "command": f"rocprofv3 --pmc <one group per pass> -- python bench.py --cpu-seconds 0 --no-configs1 --no-mp3 {bench_args} --pre-roll 0.01 --steps 6 --warmup 1".replace("  ", " "),
            "note": "PMC passes serialise the dispatches: these describe one launch alone"}
     json.dump(out, open(os.path.join(prof, f"{RND}_pmc_{tag}.json"), "w"), indent=1)
     print("wrote", f"profiles/{RND}_pmc_{tag}.json")
