@@ -162,9 +162,10 @@ int rg_wait_user_stream(rg_ctx *ctx);
  * and the tail in plain stream order: no cross-stream events per step.  This is the fast multi-GPU form --
  * other batches keep running on the context's other pipeline streams meanwhile. */
 void *rg_batch_stream(rg_ctx *ctx);
-/* kernel variant: 0 = auto (the transient-moment kernels up to 48 kHz, the order-faithful kernel for 64 / 88.2 /
- * 96 kHz), 1 = halo-tiled order-faithful kernel everywhere, 2 = transient-moment kernels wherever the rate's
- * filter is stable */
+/* kernel variant: 0 = auto (the transient-moment kernels at every rate whose filter is stable -- all but 88.2 kHz, whose
+ * coefficient row diverges in the reference as written and runs on the order-faithful kernel -- with flagged tracks repeated
+ * on the order-faithful kernel by the synchronous entry points), 1 = halo-tiled order-faithful kernel everywhere,
+ * 2 = transient-moment kernels wherever the rate's filter is stable, no repeat */
 int rg_set_kernel(rg_ctx *ctx, int variant);
 
 /* tuning knobs (0 restores the default): key 1 = segment length of variant 2 in frames (must divide

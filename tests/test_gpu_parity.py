@@ -364,7 +364,7 @@ def _differential(an, oracle, cases, exact_above_48k):
 
 
 def test_randomised_differential_auto_mode_is_exact_at_every_rate(_ctx, oracle):
-    """The library's default routing (variant 2 up to 48 kHz, the order-faithful kernel above): 600 random tracks,
+    """The library's default routing (variant 2 at every stable rate + exact repeat of flagged tracks): 600 random tracks,
     every bin equal to the oracle's at every rate."""
     import os
 
