@@ -53,7 +53,7 @@ def test_pcm_matches_ffmpeg(path):
 def test_dense_streams_are_what_the_encoder_makes_and_decode_to_the_music():
     """tests/golden/mp3/dense_*.mp3 (tools/make_mp3_dense.py): tens of seconds of synthetic music through a real encoder
     chain (oracle/mp3_encoder.py).  The shortest is re-encoded here and must be the committed bytes; every one decodes to
-    the piece it was made from (SNR >= 20 dB at the chain's delay -- there is no psychoacoustic model), uses window
+    the piece it was made from (SNR >= 18 dB at the chain's delay -- there is no psychoacoustic model), uses window
     switching at its attacks, and the joint-stereo one switches mid/side per frame."""
     sys.path.insert(0, str(ROOT / "tools"))
     import make_mp3_dense as M
@@ -69,7 +69,7 @@ def test_dense_streams_are_what_the_encoder_makes_and_decode_to_the_music():
         d = 1057  # analysis + synthesis filterbank (481) and one granule of MDCT overlap (576)
         m = min(dec.shape[1] - d, pcm.shape[1])
         err = dec[:, d:d + m] - pcm[:, :m]
-        assert 10 * np.log10((pcm[:, :m] ** 2).sum() / (err ** 2).sum()) >= 20.0
+        assert 10 * np.log10((pcm[:, :m] ** 2).sum() / (err ** 2).sum()) >= 18.0
         _, units, _ = mp3dec.parse_units(data)
         kinds = {int(u.block_type) for u in units}
         assert kinds == {0, 1, 2, 3}, kinds

@@ -109,6 +109,9 @@ CASES = [
     ("dense_44k_joint_128", 44100, 2, 24.0, 128, 11, True),
     ("dense_48k_stereo_192", 48000, 2, 8.0, 192, 12, False),
     ("dense_22k_mono_56", 22050, 1, 10.0, 56, 13, False),
+    ("dense_32k_joint_96", 32000, 2, 6.0, 96, 14, True),     # MPEG-1 at its lowest rate, mid/side
+    ("dense_24k_joint_64", 24000, 2, 6.0, 64, 15, True),     # MPEG-2 (one granule per frame), mid/side, short blocks in the LSF syntax
+    ("dense_11k_stereo_32", 11025, 2, 6.0, 32, 16, False),   # MPEG-2.5
 ]
 
 
