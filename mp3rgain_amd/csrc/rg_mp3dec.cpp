@@ -1132,7 +1132,7 @@ extern "C" int rg_mp3_index_selfcheck(const void *data, size_t len) {
     const int rc2 = rg_mp3_compact_stream(copy.data(), len, &slots, &tiles, &main_len, &ib);
     if (rc != rc2) return 1;
     if (rc != RG_MP3DEC_OK) return rc;
-    if (main_len != main_a.size() || memcmp(copy.data(), main_a.data(), main_len) != 0) return 1;
+    if (main_len != main_a.size() || (main_len != 0 && memcmp(copy.data(), main_a.data(), main_len) != 0)) return 1;
     uint64_t have = 0;
     uint32_t decoded = 0;
     const size_t nframes = slots.size() / RG_MP3_SLOT_BYTES;
