@@ -461,11 +461,6 @@ std::string shell_quote(const char *s) {
 
 // Load one file (no device work; safe to call from several threads at once as long as `err` is per call).
 // RIFF/WAVE: the bytes; MPEG Layer III: decoded planar f32; anything else: the decoder command's stdout.
-// an MP4 file whose selected track was MPEG audio has been replaced by that track's elementary stream (no ftyp box any more)
-static bool tr_is_mp3(const std::vector<uint8_t> &bytes, bool was_mp4) {
-    return was_mp4 && !(bytes.size() >= 8 && memcmp(bytes.data() + 4, "ftyp", 4) == 0);
-}
-
 int load_audio_for(const std::string &decoder_cmd, int gpu_decode, const char *path, LoadedAudio *out, std::string *err, int32_t track_index) {
     char msg[1024];
     auto fail = [&](int code, const char *fmt, const char *a, int b = 0) {
@@ -488,6 +483,7 @@ int load_audio_for(const std::string &decoder_cmd, int gpu_decode, const char *p
     const bool mp4 = bytes.size() >= 8 && memcmp(bytes.data() + 4, "ftyp", 4) == 0;
     out->is_mp4 = rg_mp4_is_mp4_data(bytes.data(), bytes.size()) != 0;  // detect_file_type, src/replaygain.rs:777-783
     int mp4_track = 0;
+    bool mp4_mpeg_audio = false;  // the selected track of an MP4 file is MPEG audio: `bytes` now holds its elementary stream
     if (mp4) {
         // ---- ISO base media: the audio tracks the reference would see (src/replaygain.rs:827-836), the one it would pick
         // (:838-851), its rate (:854-857).  MPEG Layer III in MP4 is decoded here, from the sample table; AAC needs the
@@ -526,10 +522,11 @@ int load_audio_for(const std::string &decoder_cmd, int gpu_decode, const char *p
                 std::vector<uint8_t> es;
                 for (size_t i = 0; i < got && i < n_au; ++i) es.insert(es.end(), bytes.begin() + (ptrdiff_t)off[i], bytes.begin() + (ptrdiff_t)(off[i] + sz[i]));
                 bytes.swap(es);
+                mp4_mpeg_audio = true;
             }
         }
     }
-    if (!mp4 || tr_is_mp3(bytes, mp4)) {
+    if (!mp4 || mp4_mpeg_audio) {
         // the probe (src/replaygain.rs:815-822) and the packet loop (:881-904) for an MPEG audio stream
         rg_mp3_stream_info si;
         if (rg_mp3_scan(bytes.data(), bytes.size(), &si) == RG_MP3DEC_OK && si.audio_frames > 0) {
@@ -573,6 +570,8 @@ int load_audio_for(const std::string &decoder_cmd, int gpu_decode, const char *p
             return RG_OK;
         }
     }
+    if (mp4_mpeg_audio)  // an MPEG audio track whose samples are not Layer III frames this decoder takes (Layer I / II, say)
+        return fail(RG_ERR_FORMAT, "Failed to create decoder: %s (the selected track's MPEG audio is not Layer III)", path);
     if (decoder_cmd.empty())  // src/replaygain.rs:861-863 (AAC: the probe succeeded, the codec is missing) / :815-822 (the probe knows no such format)
         return fail(RG_ERR_FORMAT, mp4 ? "Failed to create decoder: %s (an AAC track; no AAC decoder is built into this library: set a decoder command, rg_set_decoder_command)"
                                        : "Failed to probe format: %s (neither MPEG Layer III nor RIFF/WAVE, and no decoder command is set: rg_set_decoder_command)",

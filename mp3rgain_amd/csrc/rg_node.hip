@@ -21,7 +21,7 @@
 #include "rg_ctx.h"
 
 namespace {
-std::string g_node_create_error;
+thread_local std::string g_node_create_error;  // what rg_node_last_error(NULL) returns to the thread whose create failed
 
 // ---- the built-in engine: one rg_ctx -------------------------------------------------------------------------------
 void *ctx_open(int device, void *) { return rg_create(device); }
