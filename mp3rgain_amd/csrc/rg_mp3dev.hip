@@ -103,7 +103,6 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
                      const rg_mp3_unit *__restrict__ units, const int16_t *__restrict__ is, float *__restrict__ sub) {
     constexpr int R = RG_MP3_SYNTH_RUN;
     __shared__ float xrb[2][2][576];   // [buffer][channel][line]
-    __shared__ float tmp[576];
     __shared__ __attribute__((aligned(16))) rg_mp3_unit Ub[3][2];  // units of the granules in the pipeline, slot = step % 3
     __shared__ int band_nz[64];
     __shared__ short band_mode[64];
@@ -113,9 +112,14 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
     // written by that thread alone; in registers it cost the kernel half its occupancy)
     __shared__ float ovl[18][64];
     __shared__ float gain_l[RG_MP3_GAIN_Q_MAX - RG_MP3_GAIN_Q_MIN + 1];
-    constexpr int kPowLds = 512;       // x^(4/3) for the values that occur; larger ones go to the table in memory
+#ifndef RG_HYB_POW_LDS
+#define RG_HYB_POW_LDS 256
+#endif
+    constexpr int kPowLds = RG_HYB_POW_LDS;  // x^(4/3) for the values that occur; larger ones go to the table in memory
     __shared__ float pow_l[kPowLds];
     __shared__ uint16_t sfbl_l[24], sfbs_l[16];
+    __shared__ float gtab[2][64];      // the granule's gains per channel: 22 long bands, then 3 * band + window of the short ones
+    __shared__ __attribute__((aligned(4))) uint8_t sidx_l[576];  // short_idx_of_line of the stream's rate
     constexpr int NT = RG_MP3_HYB_THREADS;
     const int tid = threadIdx.x;
     uint32_t ti = 0;
@@ -144,6 +148,7 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
     for (int e = tid; e < kPowLds; e += NT) pow_l[e] = T->pow43[e];
     if (tid >= 32 && tid < 56) sfbl_l[tid - 32] = T->sfb_long[rr][tid - 32];
     if (tid >= 64 && tid < 80) sfbs_l[tid - 64] = T->sfb_short[rr][tid - 64];
+    for (int e = tid; e < 144; e += NT) reinterpret_cast<uint32_t *>(sidx_l)[e] = reinterpret_cast<const uint32_t *>(T->short_idx_of_line[rr])[e];
     // ---- roles ----------------------------------------------------------------------------------------------------
     const bool imdct_thread = tid < 32 * nch;          // wave 0 (half of it for a mono stream)
     const int my_c = tid >> 5, my_sb = tid & 31;
@@ -201,12 +206,41 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
             if (rq) {
                 // ---- stage B: requantisation (rg_mp3dec.cpp: requantize).  The gain of a line is 2^(e),
                 // e = (global_gain - 210)/4 - mult (sf + preflag pretab) [- 2 subblock_gain], a multiple of 1/4 exactly:
-                // the table is indexed by 4e
+                // the table is indexed by 4e.  A line's gain depends on its band (and window) only, so the wave first
+                // writes the granule's 22 long-band and 39 (short band, window) gains per channel and a line then costs
+                // one look-up; what is the same for the whole granule sits in scalar registers (the branches on it are
+                // scalar branches: a long block runs straight through).
                 uint2 raw[kRounds][2];
 #pragma unroll
                 for (int r = 0; r < kRounds; ++r) { raw[r][0] = rq_next[r][0]; raw[r][1] = rq_next[r][1]; }
                 if (k + 1 < nsteps) fetch_spectra(k + 1);
-                const int ms_n = (nch == 2 && (UP[0].mode_ext & 3) == 2) ? (UP[0].nz > UP[1].nz ? (int)UP[0].nz : (int)UP[1].nz) : 0;
+                int bt_s[2] = {0, 0}, ll_s[2] = {0, 0}, so_s[2] = {0, 0};
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (c >= nch) continue;
+                    const rg_mp3_unit &u = UP[c];
+                    const int m4 = u.scalefac_scale ? 4 : 2;  // 4 * mult
+                    const int base4 = (int)u.global_gain - 210;
+                    int q;
+                    if (rq_lane < 22) {
+                        q = base4 - m4 * ((int)u.sf[rq_lane] + (u.preflag ? (int)ptab[rq_lane] : 0));
+                    } else {
+                        const int kk = rq_lane - 22;  // 3 * band + window
+                        const int band = kk / 3, win = kk - 3 * band;
+                        const int rel = kk - 3 * (int)u.short_start;
+                        const int sv = (band < 12 && rel >= 0) ? (int)u.sf[(int)u.long_end + rel] : 0;
+                        q = base4 - 8 * (int)u.subblock_gain[win] - m4 * sv;
+                    }
+                    q = q < RG_MP3_GAIN_Q_MIN ? RG_MP3_GAIN_Q_MIN : (q > RG_MP3_GAIN_Q_MAX ? RG_MP3_GAIN_Q_MAX : q);  // entries no line of this granule uses
+                    gtab[c][rq_lane] = rq_lane < 61 ? gain_l[q - RG_MP3_GAIN_Q_MIN] : 0.0f;  // a short band past the twelfth: 0
+                    bt_s[c] = __builtin_amdgcn_readfirstlane((int)u.block_type);
+                    ll_s[c] = __builtin_amdgcn_readfirstlane((int)sfbl_l[u.long_end]);  // lines coded as long bands when the block is short; 0 when long_end == 0
+                    so_s[c] = __builtin_amdgcn_readfirstlane(3 * (int)sfbs_l[u.short_start < 13 ? u.short_start : 13]);
+                }
+                const int ms_n = __builtin_amdgcn_readfirstlane(
+                    (nch == 2 && (UP[0].mode_ext & 3) == 2) ? (UP[0].nz > UP[1].nz ? (int)UP[0].nz : (int)UP[1].nz) : 0);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // the gains are read by other lanes of this wave only
 #pragma unroll
                 for (int r = 0; r < kRounds; ++r) {
                     const int piece = rq_lane + 64 * r;
@@ -216,35 +250,37 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
                         if (c >= nch) continue;
-                        const rg_mp3_unit &u = UP[c];
-                        const int m4 = u.scalefac_scale ? 4 : 2;  // 4 * mult
-                        const int base4 = (int)u.global_gain - 210;
-                        const int long_lines = (int)sfbl_l[u.long_end];  // 0 when long_end == 0
-                        const int short_off = 3 * (int)sfbs_l[u.short_start < 13 ? u.short_start : 13];
                         const uint32_t w[2] = {raw[r][c].x, raw[r][c].y};
+                        float gv[4];
+                        if (bt_s[c] != 2) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) gv[j] = gtab[c][(rq_lb[r] >> (8 * j)) & 0xFFu];
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int line = rq_l0 + j;
+                                const int idx = line < ll_s[c] ? (int)((rq_lb[r] >> (8 * j)) & 0xFFu) : 22 + (int)sidx_l[line - ll_s[c] + so_s[c]];
+                                gv[j] = gtab[c][idx];
+                            }
+                        }
+                        int v[4], a[4];
+                        float m[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const int line = rq_l0 + j;
-                            float gv;
-                            if (u.block_type != 2 || line < long_lines) {
-                                const int band = (int)((rq_lb[r] >> (8 * j)) & 0xFFu);
-                                const int q = base4 - m4 * ((int)u.sf[band] + (u.preflag ? (int)ptab[band] : 0));
-                                gv = gain_l[q - RG_MP3_GAIN_Q_MIN];
-                            } else {
-                                const int kk = (int)T->short_idx_of_line[rr][line - long_lines + short_off] - 3 * (int)u.short_start;  // (band - short_start) * 3 + window
-                                const int band = (int)u.short_start + kk / 3, win = kk % 3;
-                                gv = 0.0f;
-                                if (band < 13) {
-                                    const int sv = band < 12 ? (int)u.sf[(int)u.long_end + kk] : 0;
-                                    const int q = base4 - 8 * (int)u.subblock_gain[win] - m4 * sv;
-                                    gv = gain_l[q - RG_MP3_GAIN_Q_MIN];
-                                }
-                            }
-                            const int v = (int)(int16_t)(w[j >> 1] >> (16 * (j & 1)));
-                            const int a = v < 0 ? -v : v;
-                            const float m = a < kPowLds ? pow_l[a] : T->pow43[a];
-                            const float t = m * gv;
-                            val[c][j] = v < 0 ? -t : t;
+                            v[j] = (int)(int16_t)(w[j >> 1] >> (16 * (j & 1)));
+                            a[j] = v[j] < 0 ? -v[j] : v[j];
+                            m[j] = pow_l[a[j] < kPowLds ? a[j] : 0];
+                        }
+                        const int amax = (a[0] > a[1] ? a[0] : a[1]) > (a[2] > a[3] ? a[2] : a[3]) ? (a[0] > a[1] ? a[0] : a[1]) : (a[2] > a[3] ? a[2] : a[3]);
+                        if (amax >= kPowLds) {  // rare: an escape value beyond the LDS part of the table
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (a[j] >= kPowLds) m[j] = T->pow43[a[j]];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float t = m[j] * gv[j];  // >= +0; a negative value takes its sign (-t, also of a product that underflowed)
+                            val[c][j] = __uint_as_float((__float_as_uint(t) & 0x7FFFFFFFu) | ((uint32_t)v[j] & 0x80000000u));
                         }
                     }
                     // ---- stage C, the plain case: mid/side on every line below the longer channel's end (rg_mp3dec.cpp: stereo)
@@ -455,6 +491,7 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
             const rg_mp3_unit &u = UP[c];
             if (u.block_type != 2) continue;
             float *X = XP[c];
+            float *const tmp = xrb[pb ^ 1][0];  // free: the transform of granule k - 1 is behind the barrier, granule k + 1 not yet here
             const int long_lines = u.mixed ? (int)sfbl_l[u.long_end] : 0;
             const int short_off = 3 * (int)sfbs_l[u.short_start];
             for (int line = tid; line < 576; line += NT)
@@ -592,7 +629,10 @@ rg_mp3_synth_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *_
 // thread then parses granule 0's scalefactors first, which is cheaper than chaining the two granules in one thread.
 namespace {
 
-constexpr int kHuffThreads = 512;
+#ifndef RG_HUFF_THREADS
+#define RG_HUFF_THREADS 512
+#endif
+constexpr int kHuffThreads = RG_HUFF_THREADS;
 
 // 96 bits of the track's main data around the read position, big-endian words; bits at or past `limit` (the end of the
 // frame's own main data) read as zero, which is what the host decoder's private copy of the frame's data does.  All

@@ -1,0 +1,9 @@
+#!/bin/bash
+# tools/ab_chain.sh lib1 lib2 ... : tools/mp3_chain.py with each library in turn, twice (boards differ; compare within one call)
+for round in 1 2; do
+  for lib in "$@"; do
+    echo "== $lib (round $round)"
+    if [ "$lib" = default ]; then python tools/mp3_chain.py 2>&1 | grep "ms per 256K"
+    else MP3RGAIN_AMD_LIB=build_ab/lib$lib.so python tools/mp3_chain.py 2>&1 | grep "ms per 256K"; fi
+  done
+done
