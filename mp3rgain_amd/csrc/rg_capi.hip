@@ -256,7 +256,6 @@ extern "C" void rg_destroy(rg_ctx *c) {
     c->d_mp3_tab.release();
     c->d_mp3_is.release();
     c->d_mp3_units.release();
-    c->d_mp3_hyb.release();
     c->d_mp3_tracks.release();
     c->d_mp3_huff.release();
     c->d_mp3_recs.release();

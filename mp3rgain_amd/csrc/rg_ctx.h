@@ -139,7 +139,6 @@ struct rg_ctx {
     DevBuf<unsigned char> d_mp3_tab;
     DevBuf<int16_t> d_mp3_is;
     DevBuf<unsigned char> d_mp3_units;
-    DevBuf<float> d_mp3_hyb;                 // subband samples between the hybrid and the synthesis kernel
     DevBuf<unsigned char> d_mp3_tracks;
     DevBuf<unsigned char> d_mp3_huff;        // Huffman look-up tables (device Huffman stage)
     DevBuf<unsigned char> d_mp3_recs;
@@ -153,7 +152,7 @@ struct rg_ctx {
     DevBuf<uint32_t> d_mp3_results;
     DevBuf<uint32_t> d_mp3_tiles;            // frame parser: per tile, granule-channels found and their prefix
     PinnedBuf<uint32_t> h_mp3_results;
-    hipEvent_t *mp3_bench_ev = nullptr;      // rg_mp3_decode_bench: five events recorded around the four decode kernels of a chunk
+    hipEvent_t *mp3_bench_ev = nullptr;      // rg_mp3_decode_bench: four events recorded around the three decode stages of a chunk
     void *mp3_pipe = nullptr;                // rg_files.hip: pinned staging blocks of the loader pipeline
     void (*mp3_pipe_free)(void *) = nullptr;
     // host buffers of the file layer (rg_files.hip), kept between calls: freeing and re-mapping hundreds of MB that

@@ -602,7 +602,7 @@ int load_audio_for(const std::string &decoder_cmd, int gpu_decode, const char *p
 // Host threads do the least an MPEG stream allows: read the file, walk its frame headers, and strip headers and side
 // information from the main data (rg_mp3_compact_stream).  Each stream's main data and slots go into a pinned staging
 // block; a block that is full (or holds enough granules to fill the GPU) is a chunk, and the calling thread sends chunks
-// to the device as they close: one H2D copy on the copy stream, then the frame parser, Huffman, hybrid and synthesis
+// to the device as they close: one H2D copy on the copy stream, then the frame parser, Huffman and back-half
 // kernels on the file stream, writing PCM straight into the analysis arena.  Three staging blocks and two device copies
 // rotate, so reading files, copying chunk k + 1 and decoding chunk k overlap.  How many frames of a stream decode is the
 // device's finding (rg_mp3_frames_kernel); the arena is laid out for "all of them" and the counts come back at the end.
@@ -1295,10 +1295,10 @@ extern "C" int rg_find_peak_amplitude(rg_ctx *c, const char *path, rg_peak_resul
 
 // Measurement hook (bench.py, tools/): the device decode chain alone.  `copies` copies of one MPEG Layer III stream form ONE
 // chunk of the default route (compacted by the host once, staged in pinned memory, copied H2D per repetition on the copy
-// stream), and the chunk's four kernels -- frame parser, Huffman, hybrid, synthesis -- are bracketed with HIP events on the
-// stream they run on.  ms_out[0..3] = average duration of each kernel over `reps` repetitions, ms_out[4] = first event to
-// last (the chain); the PCM lands in the analysis arena as in a real call and is not copied back.
-extern "C" int rg_mp3_decode_bench(rg_ctx *c, const void *data, size_t len, uint32_t copies, uint32_t reps, double *ms_out /* 5 */,
+// stream), and the chunk's three stages -- frame parser (three launches), Huffman, back half -- are bracketed with HIP events
+// on the stream they run on.  ms_out[0..2] = average duration of each stage over `reps` repetitions, ms_out[3] = first event
+// to last (the chain); the PCM lands in the analysis arena as in a real call and is not copied back.
+extern "C" int rg_mp3_decode_bench(rg_ctx *c, const void *data, size_t len, uint32_t copies, uint32_t reps, double *ms_out /* 4 */,
                                    uint64_t *units_out, uint64_t *compressed_bytes_out, uint64_t *frames_out) {
     if (!c || !data || !ms_out || copies == 0 || reps == 0) return RG_ERR_INVALID_ARG;
     int rc = rg_bind_device(c);
@@ -1354,29 +1354,29 @@ extern "C" int rg_mp3_decode_bench(rg_ctx *c, const void *data, size_t len, uint
     // one set of events per repetition: the repetitions are enqueued back to back (a synchronise after each would let the
     // clocks fall between them) and read out at the end
     if (reps > 256) reps = 256;
-    std::vector<hipEvent_t> ev((size_t)5 * (reps + 1), nullptr);
+    std::vector<hipEvent_t> ev((size_t)4 * (reps + 1), nullptr);
     for (hipEvent_t &e : ev) RG_HIP(c, hipEventCreate(&e));
-    double sum[5] = {0, 0, 0, 0, 0};
+    double sum[4] = {0, 0, 0, 0};
     rc = rg_mp3dev_reserve_results(c, copies, fs);
     for (uint32_t r = 0; r < reps + 1 && rc == RG_OK; ++r) {  // the first repetition is not counted
-        c->mp3_bench_ev = &ev[(size_t)5 * r];
+        c->mp3_bench_ev = &ev[(size_t)4 * r];
         rc = rg_mp3dev_enqueue_chunk(c, (int)(r & 1), st.p, total, tracks_off, st.staged, items.data(), copies, fs);
         c->mp3_bench_ev = nullptr;
     }
     if (rc == RG_OK && hipStreamSynchronize(fs) != hipSuccess) rc = rg_set_err(c, RG_ERR_DEVICE, "decode bench: stream synchronise failed");
     for (uint32_t r = 1; r < reps + 1 && rc == RG_OK; ++r) {
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 3; ++k) {
             float ms = 0.0f;
-            (void)hipEventElapsedTime(&ms, ev[(size_t)5 * r + k], ev[(size_t)5 * r + k + 1]);
+            (void)hipEventElapsedTime(&ms, ev[(size_t)4 * r + k], ev[(size_t)4 * r + k + 1]);
             sum[k] += ms;
         }
         float ms = 0.0f;
-        (void)hipEventElapsedTime(&ms, ev[(size_t)5 * r], ev[(size_t)5 * r + 4]);
-        sum[4] += ms;
+        (void)hipEventElapsedTime(&ms, ev[(size_t)4 * r], ev[(size_t)4 * r + 3]);
+        sum[3] += ms;
     }
     for (hipEvent_t &e : ev) (void)hipEventDestroy(e);
     if (rc != RG_OK) return rc;
-    for (int k = 0; k < 5; ++k) ms_out[k] = sum[k] / reps;
+    for (int k = 0; k < 4; ++k) ms_out[k] = sum[k] / reps;
     const uint64_t per_frame = si.mpeg_version == 1 ? 2u : 1u;
     if (units_out) *units_out = (uint64_t)si.audio_frames * per_frame * si.channels * copies;
     if (compressed_bytes_out) *compressed_bytes_out = (uint64_t)(main_len + sc.slots.size()) * copies;

@@ -9,7 +9,11 @@
 #define RG_MP3_GAIN_Q_MIN (-512)   // requantisation gains 2^(q/4) are tabulated for q in [RG_MP3_GAIN_Q_MIN, RG_MP3_GAIN_Q_MAX]
 #define RG_MP3_GAIN_Q_MAX 64
 #define RG_MP3_HUFF_LDS_ENTRIES 7808  // room for the flattened Huffman tables in the Huffman kernel's LDS (they have 7752 entries)
-#define RG_MP3_SYNTH_RUN 6        // consecutive granules per block of the hybrid kernel (both channels) and of the synthesis kernel (one)
+#define RG_MP3_RUN 32             // consecutive granules per block of the back-half kernel (both channels)
+#ifndef RG_MP3_IS_GROUP_LOG2
+#define RG_MP3_IS_GROUP_LOG2 3    // 2^3 units interleaved 16-byte piece by piece in the Huffman kernel's output (rg_mp3dev.hip: rg_mp3_is_index)
+#endif
+#define RG_MP3_IS_GROUP (1u << RG_MP3_IS_GROUP_LOG2)
 
 // Every constant the device stages use, built once on the host from the very tables the host decoder uses, so that
 // the two halves work with identical numbers.
@@ -75,18 +79,18 @@ struct RgMp3DevTrack {
     uint32_t channels;
     uint32_t rate_row;
     uint32_t lsf;
-    uint32_t hrun_base;      // first block of the track in the hybrid kernel's grid (one block per run of RG_MP3_SYNTH_RUN granules)
+    uint32_t run_base;       // first block of the track in the back-half kernel's grid (one block per run of RG_MP3_RUN granules)
     float *ch0;              // PCM outputs (planar); 576 frames per granule
     float *ch1;
     uint64_t main_base;      // device Huffman stage: byte offset of the track's main-data stream in the chunk buffer
-    uint32_t synth_base;     // first block of the track in the synthesis kernel's grid
+    uint32_t reserved_;
     uint32_t n_frames;       // tuning key 6 = 3: frames the host walked (slots); the device decides which decode
     uint64_t slots_base;     //   byte offset of the track's slots (rg_mp3_frame.h) in the chunk buffer
     uint32_t result_index;   //   where the frame parser reports the granules it found decodable
     uint32_t tile_base;      //   first tile (RG_MP3_FRAME_TILE frames) of the track in the chunk's tile numbering
     uint64_t tiles_base;     //   byte offset of the track's tile table (uint64 per tile: main-data bytes before the tile)
 };
-// With the device-side frame parser (rg_mp3_frames_kernel) unit_base / granule_base / fc_base / synth_base and the grids
+// With the device-side frame parser (rg_mp3_frames_kernel) unit_base / granule_base / run_base and the grids
 // are laid out for the upper bound "every walked frame decodes"; the kernel then overwrites n_granules (and ch1, which
 // follows the decoded length) with what it found, and the later stages skip the units past it.
 

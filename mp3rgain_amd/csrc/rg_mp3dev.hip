@@ -4,16 +4,15 @@
 //                          which frames decode, where each granule's bits are (the code of rg_mp3_frame.h, shared with
 //                          the host)
 //   rg_mp3_huffman_kernel  scalefactors + Huffman-coded spectrum, one thread per granule and channel
-//   rg_mp3_hybrid_kernel   six granules per block (both channels): requantisation, joint stereo (mid/side, intensity in
-//                          the MPEG-1 and the LSF form), short-block reordering, alias reduction, IMDCT + windowing,
-//                          overlap-add, frequency inversion -> subband samples
-//   rg_mp3_synth_kernel    six granules of one channel per block: the polyphase synthesis filterbank (matrixing into
-//                          64-vectors, 512-tap window over sixteen of them) -> 576 PCM samples per granule, planar f32,
-//                          straight into the analysis arena
+//   rg_mp3_backhalf_kernel everything after that, one block per run of 32 granules of a track (both channels), a pipeline
+//                          of four waves: requantisation + joint stereo (mid/side, intensity in the MPEG-1 and the LSF
+//                          form) + short-block reordering | alias reduction + IMDCT + windowing + overlap-add + frequency
+//                          inversion | matrixing of the polyphase filterbank | its 512-tap window -> 576 PCM samples per
+//                          granule and channel, planar f32, straight into the analysis arena
 //
-// Nothing here is recursive across granules: the overlap is the previous granule's second IMDCT half (a block computes
-// the granule before its own once more), the filterbank's FIFO the previous fifteen time slots' subband samples (read
-// again), so every granule of every track of a batch is independent work.
+// Nothing here is recursive across granules: the overlap is the previous granule's second IMDCT half, the filterbank's
+// FIFO the previous fifteen time slots' subband samples; a run that starts inside a track computes the two granules before
+// its own once more, so every run of every track of a batch is independent work.
 //
 // Bit-identical to the host decoder by construction: compiled with -ffp-contract=off, every sum in the host's order
 // (sequential, from 0.0f), every constant from the host's own tables (rg_mp3_fill_device_tables), the data-dependent
@@ -44,6 +43,15 @@ __device__ __forceinline__ uint32_t find_by_unit(const RgMp3DevTrack *__restrict
 }
 
 
+// The quantised spectra between the Huffman stage and the back half: 72 pieces of 16 bytes (8 lines) per unit.  With the
+// Huffman stage on the device, groups of G = 8 units are interleaved piece by piece -- the Huffman kernel's lanes are
+// consecutive units at the same piece, so eight lanes fill a 128-byte line with one store, where rows of their own made
+// every 16-byte store a partial line (read for ownership + a masked write: 3.5 KB of traffic per unit for 1.2 KB of
+// spectrum).  G = 1: plain rows (what the host's rg_mp3_parse_units writes).  Index in 16-byte pieces; G = 2^group_log2.
+__device__ __forceinline__ uint64_t rg_mp3_is_index(uint64_t unit, int chunk, uint32_t group_log2) {
+    return ((((unit >> group_log2) * 72 + (uint64_t)chunk) << group_log2) | (unit & ((1u << group_log2) - 1u)));
+}
+
 // Bit reader over the batch's main-data buffer; bits at or past `limit` (the end of the frame's own main data) read
 // as zero, which is what the host decoder's private copy of the frame's data does.
 struct DevBits {
@@ -69,76 +77,72 @@ struct DevBits {
 
 }  // namespace
 
-namespace {
-// finished subband samples: sub[unit][t][sb], t = time slot 0..17 of the granule
-__device__ __forceinline__ size_t sub_index(uint64_t unit, int t, int sb) {
-    return ((size_t)unit * 18 + (size_t)t) * 32 + (size_t)sb;
-}
-
-}  // namespace
-
-// One block = a run of up to RG_MP3_SYNTH_RUN consecutive granules of one track, both channels.  The block is a two-stage
-// pipeline over the run's granules with ONE barrier per granule in the common case:
-//   wave 1     requantises granule k (and applies plain mid/side stereo) into one half of a double-buffered spectrum,
-//   wave 0     thread (channel, subband) takes granule k-1 out of the other half: alias reduction folded into the load of
-//              its eighteen lines, the IMDCT (the fast 36-point one of rg_mp3_math.h -- the code the host runs -- or three
-//              12-point ones for a short block), window, overlap-add with the second half it kept from the granule before,
-//              frequency inversion, store.
-// What leaves the kernel are FINISHED subband samples, 2304 bytes per granule and channel; a run that starts inside the
-// track first takes the granule before it through the same stages for its overlap alone.  Granules that need more than
-// that between requantisation and IMDCT -- intensity stereo, short-block reordering -- get it from both waves in extra
-// barrier-separated steps, exactly as the one-granule-per-block kernel of round 2 did it.  Everything a granule's stages
-// look up lives in LDS (copied once per run); units and quantised spectra are fetched one granule ahead.  Two waves per
-// block, because the IMDCT wave is the long pole of a step and the register file has room for sixteen waves per CU: eight
-// blocks, eight IMDCT waves in flight.
-// (Round 2: a block was one granule, six barrier-separated stages, both IMDCT halves through memory to the synthesis
-// kernel, the prologue -- track look-up, tables into LDS -- once per granule: 0.68 ms per 256 K units, now 0.3.)
-#define RG_MP3_HYB_THREADS 128
-// 128 VGPRs: four waves per SIMD, eight blocks per CU (A/B on one board: 0.586 ms per 256 K units against 0.646 at the 144
-// registers the compiler takes when left alone, and 0.614 with the overlap prefetched into registers and 12 bytes spilled)
-#define RG_HYB_WAVES 4
-#define RG_HYB_OVPREF 0
-__global__ void __launch_bounds__(RG_MP3_HYB_THREADS) __attribute__((amdgpu_waves_per_eu(RG_HYB_WAVES)))
-rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks,
-                     const rg_mp3_unit *__restrict__ units, const int16_t *__restrict__ is, float *__restrict__ sub) {
-    constexpr int R = RG_MP3_SYNTH_RUN;
+// ---------------------------------------------------------------------------------------------------------------------
+// Stages B-E, one kernel.  One block = a run of RG_MP3_RUN consecutive granules of one track (both channels), four waves,
+// a four-stage pipeline over the run's granules with ONE barrier per granule; every hand-over goes through LDS:
+//   wave 1  granule k      units and quantised spectra in (fetched one granule ahead); requantisation -- a line's gain
+//                          2^((global_gain - 210)/4 - mult (sf + preflag pretab) [- 2 subblock_gain]) depends on its band
+//                          (and window) only, so the wave first writes the granule's 22 long-band and 39 (short band,
+//                          window) gains, from a table indexed by the exact integer exponent, and a line then costs one
+//                          look-up; what is the same for the whole granule sits in scalar registers --, mid/side,
+//                          intensity stereo, short-block reordering (wave-local steps, no block barrier inside)
+//   wave 0  granule k - 1  lane (channel, subband): alias butterflies folded into the load of its eighteen lines, the
+//                          fast 36-point IMDCT of rg_mp3_math.h (the code the host runs) or three 12-point ones, window,
+//                          overlap-add with the second half it kept from the granule before (an LDS column of its own),
+//                          frequency inversion -> 18 x 32 subband samples
+//   wave 2  granule k - 2  matrixing: lane (channel, time slot) runs the 32-point DCT of rg_mp3_math.h (one source
+//                          compiled into both decoders); the 32 DCT outputs are kept, the 64 matrixing values follow
+//                          from them by symmetry
+//   wave 3  granule k - 3  the 512-tap window: lane (channel, j) owns PCM sample j of the granule's eighteen time slots;
+//                          the two DCT columns it needs of the fifteen slots of history stay in its registers from one
+//                          granule to the next (2 LDS reads per output instead of 32), the symmetry's signs are folded
+//                          into its sixteen window coefficients; 576 PCM samples per granule straight into the arena
+// A run that starts inside the track takes the two granules before it through the first stages (the second one's subband
+// samples need the first one's overlap, and its DCT rows are the filterbank's history).  Each wave runs its own loop, so
+// the register file is sized for the largest stage, not for their sum: 112 VGPRs, 39 KB of LDS, four blocks per CU.
+// (Rounds 2 and 3 had two kernels with the subband samples in memory between them -- 4.6 KB of traffic per granule and
+// channel, the fifteen slots of history transformed again by every block, 0.60 ms per 256 K units against 0.49 now; a
+// first fused kernel in round 2, six waves stepping through barrier-separated phases together, had lost to them.)
+#define RG_MP3_BH_THREADS 256
+__global__ void __launch_bounds__(RG_MP3_BH_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
+rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks,
+                       const rg_mp3_unit *__restrict__ units, const int16_t *__restrict__ is, const uint32_t is_group_log2) {
+    constexpr int R = RG_MP3_RUN;
     __shared__ float xrb[2][2][576];   // [buffer][channel][line]
-    __shared__ __attribute__((aligned(16))) rg_mp3_unit Ub[3][2];  // units of the granules in the pipeline, slot = step % 3
+    __shared__ __attribute__((aligned(16))) rg_mp3_unit Ub[3][2];
     __shared__ int band_nz[64];
     __shared__ short band_mode[64];
     __shared__ float c12[12][6], wn[4][36], cs_l[8], ca_l[8];
     __shared__ uint8_t ptab[24];
-    // the overlap: the second half of the previous granule's 36 windowed samples, one column per IMDCT thread (read and
-    // written by that thread alone; in registers it cost the kernel half its occupancy)
     __shared__ float ovl[18][64];
     __shared__ float gain_l[RG_MP3_GAIN_Q_MAX - RG_MP3_GAIN_Q_MIN + 1];
-#ifndef RG_HYB_POW_LDS
-#define RG_HYB_POW_LDS 256
-#endif
-    constexpr int kPowLds = RG_HYB_POW_LDS;  // x^(4/3) for the values that occur; larger ones go to the table in memory
+    constexpr int kPowLds = 256;       // x^(4/3) for the values that occur; larger ones go to the table in memory
     __shared__ float pow_l[kPowLds];
     __shared__ uint16_t sfbl_l[24], sfbs_l[16];
-    __shared__ float gtab[2][64];      // the granule's gains per channel: 22 long bands, then 3 * band + window of the short ones
-    __shared__ __attribute__((aligned(4))) uint8_t sidx_l[576];  // short_idx_of_line of the stream's rate
-    constexpr int NT = RG_MP3_HYB_THREADS;
+    __shared__ float gtab[2][64];
+    __shared__ __attribute__((aligned(4))) uint8_t sidx_l[576];
+    __shared__ float Sin[2][2][18][33];  // [granule parity][channel][time slot][subband]: wave 0 -> wave 2
+    __shared__ float Ar[2][2][18][33];   // the DCT outputs of those slots (word 32 = 0.0f = V[16]): wave 2 -> wave 3
+    constexpr int NT = RG_MP3_BH_THREADS;
     const int tid = threadIdx.x;
     uint32_t ti = 0;
     {
         uint32_t lo = 0, hi = n_tracks - 1;
         while (lo < hi) {
             const uint32_t mid = (lo + hi + 1) >> 1;
-            if (tracks[mid].hrun_base <= blockIdx.x) lo = mid; else hi = mid - 1;
+            if (tracks[mid].run_base <= blockIdx.x) lo = mid; else hi = mid - 1;
         }
         ti = lo;
     }
     const RgMp3DevTrack tr = tracks[ti];
-    const uint32_t g0 = (blockIdx.x - tr.hrun_base) * R;
+    const uint32_t g0 = (blockIdx.x - tr.run_base) * R;
     if (g0 >= tr.n_granules) return;  // past what the device-side frame parser found decodable (block-uniform)
     const int ng = (int)(tr.n_granules - g0 < (uint32_t)R ? tr.n_granules - g0 : (uint32_t)R);
     const int nch = (int)tr.channels;
     const int rr = (int)tr.rate_row;
-    const int gi0 = g0 > 0 ? -1 : 0;   // first granule of the pipeline, relative to g0
-    const uint64_t ubase = tr.unit_base + (uint64_t)((long long)g0 + gi0) * nch;  // its first unit
+    const int gi0 = g0 > 0 ? -2 : 0;   // first granule of the pipeline, relative to g0 (g0 is a multiple of R >= 2)
+    const int pd0 = g0 > 0 ? 1 : 0;    // first pipeline granule whose subband samples are right (the one before has no overlap)
+    const uint64_t ubase = tr.unit_base + (uint64_t)((long long)g0 + gi0) * nch;
     const int nsteps = ng - gi0;       // granules through the pipeline
     for (int e = tid; e < 144; e += NT) (&wn[0][0])[e] = (&T->win[0][0])[e];
     if (tid < 72) (&c12[0][0])[tid] = (&T->imdct12[0][0])[tid];
@@ -149,67 +153,65 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
     if (tid >= 32 && tid < 56) sfbl_l[tid - 32] = T->sfb_long[rr][tid - 32];
     if (tid >= 64 && tid < 80) sfbs_l[tid - 64] = T->sfb_short[rr][tid - 64];
     for (int e = tid; e < 144; e += NT) reinterpret_cast<uint32_t *>(sidx_l)[e] = reinterpret_cast<const uint32_t *>(T->short_idx_of_line[rr])[e];
-    // ---- roles ----------------------------------------------------------------------------------------------------
-    const bool imdct_thread = tid < 32 * nch;          // wave 0 (half of it for a mono stream)
-    const int my_c = tid >> 5, my_sb = tid & 31;
-    if (imdct_thread) {
+    if (tid < 64) {
 #pragma unroll
         for (int i = 0; i < 18; ++i) ovl[i][tid] = 0.0f;  // a granule without a predecessor adds 0.0f, as the host does
     }
-    // wave 1: lane j requantises the four-line pieces j, j + 64, j + 128 (144 pieces) of every channel
-    const bool rq = tid >= 64;
-    const int rq_lane = tid - 64;
-    constexpr int kRounds = 3;
-    uint32_t rq_lb[kRounds] = {0u, 0u, 0u};            // long-block band numbers of a piece's four lines
-    if (rq) {
-#pragma unroll
-        for (int r = 0; r < kRounds; ++r)
-            if (rq_lane + 64 * r < 144) rq_lb[r] = *reinterpret_cast<const uint32_t *>(&T->long_band_of_line[rr][4 * (rq_lane + 64 * r)]);
-    }
     static_assert(sizeof(rg_mp3_unit) == 64, "the unit prefetch assumes 64-byte units");
-    const bool uq = tid >= 120 && tid < 120 + 4 * nch; // threads that carry the units: four 16-byte words each
-    const int uq_t = tid - 120;
-    // units: step 0's go to LDS now, step 1's wait in registers; spectra: step 0's wait in registers
-    uint4 u_reg = make_uint4(0u, 0u, 0u, 0u);
-    if (uq) {
-        reinterpret_cast<uint4 *>(&Ub[0][0])[uq_t] = reinterpret_cast<const uint4 *>(units + ubase)[uq_t];
-        if (nsteps > 1) u_reg = reinterpret_cast<const uint4 *>(units + ubase + nch)[uq_t];
-    }
-    uint2 rq_next[kRounds][2];
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) rq_next[r][0] = rq_next[r][1] = make_uint2(0u, 0u);
-    auto fetch_spectra = [&](const int step) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // a scalar: each wave takes one branch whole
+    const int lane = tid & 63;
+
+    if (wave == 1) {
+        // ================= wave 1: units and spectra in, requantised (and stereo-processed, reordered) spectrum out ===
+        constexpr int kRounds = 3;
+        uint32_t rq_lb[kRounds] = {0u, 0u, 0u};  // long-block band numbers of a piece's four lines
 #pragma unroll
         for (int r = 0; r < kRounds; ++r)
+            if (lane + 64 * r < 144) rq_lb[r] = *reinterpret_cast<const uint32_t *>(&T->long_band_of_line[rr][4 * (lane + 64 * r)]);
+        const bool uq = lane >= 56 && lane < 56 + 4 * nch;  // lanes that carry the units: four 16-byte words each
+        const int uq_t = lane - 56;
+        uint4 u_reg = make_uint4(0u, 0u, 0u, 0u);
+        if (uq) {
+            reinterpret_cast<uint4 *>(&Ub[0][0])[uq_t] = reinterpret_cast<const uint4 *>(units + ubase)[uq_t];
+            if (nsteps > 1) u_reg = reinterpret_cast<const uint4 *>(units + ubase + nch)[uq_t];
+        }
+        uint2 rq_next[kRounds][2];
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
-                if (c < nch && rq_lane + 64 * r < 144)
-                    rq_next[r][c] = *reinterpret_cast<const uint2 *>(is + (ubase + (uint64_t)step * nch + c) * 576 + 4 * (rq_lane + 64 * r));
-    };
-    if (rq) fetch_spectra(0);
-    __syncthreads();
-
-    for (int k = 0; k <= nsteps; ++k) {
-        // this step requantises granule k of the pipeline (if there is one) and transforms granule k - 1 (if there is one)
-        const int pb = k & 1;
-        float (*const XP)[576] = xrb[pb];
-        const rg_mp3_unit *const UP = Ub[k % 3];
-        bool special = false;
-        if (k < nsteps) {
-            // intensity stereo and short-block reordering need whole-block steps of their own behind the barrier
-            special = (nch == 2 && (UP[0].mode_ext & 1)) || UP[0].block_type == 2 || (nch == 2 && UP[1].block_type == 2);
-            // the units of step k + 1 become visible at this step's barrier; those of step k + 2 start travelling
-            if (uq) {
-                if (k + 1 < nsteps) reinterpret_cast<uint4 *>(&Ub[(k + 1) % 3][0])[uq_t] = u_reg;
-                if (k + 2 < nsteps) u_reg = reinterpret_cast<const uint4 *>(units + ubase + (uint64_t)(k + 2) * nch)[uq_t];
+        for (int r = 0; r < kRounds; ++r) rq_next[r][0] = rq_next[r][1] = make_uint2(0u, 0u);
+        // 16-byte piece `chunk` of unit U sits at ((U / G) 72 + chunk) G + U % G (rg_mp3_is_index): a lane's share of that
+        // is fixed, the unit's share is a scalar
+        uint32_t rq_off[kRounds];  // bytes from the unit's first piece to this lane's four lines
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) rq_off[r] = ((uint32_t)((lane + 64 * r) >> 1) << (is_group_log2 + 4)) + 8u * ((lane + 64 * r) & 1);
+        const uint8_t *const is_bytes = reinterpret_cast<const uint8_t *>(is);
+        auto fetch_spectra = [&](const int step) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (c >= nch) continue;
+                const uint64_t U = ubase + (uint64_t)step * nch + c;
+                const uint8_t *const row = is_bytes + rg_mp3_is_index(U, 0, is_group_log2) * 16;
+#pragma unroll
+                for (int r = 0; r < kRounds; ++r)
+                    if (lane + 64 * r < 144) rq_next[r][c] = *reinterpret_cast<const uint2 *>(row + rq_off[r]);
             }
-            if (rq) {
-                // ---- stage B: requantisation (rg_mp3dec.cpp: requantize).  The gain of a line is 2^(e),
-                // e = (global_gain - 210)/4 - mult (sf + preflag pretab) [- 2 subblock_gain], a multiple of 1/4 exactly:
-                // the table is indexed by 4e.  A line's gain depends on its band (and window) only, so the wave first
-                // writes the granule's 22 long-band and 39 (short band, window) gains per channel and a line then costs
-                // one look-up; what is the same for the whole granule sits in scalar registers (the branches on it are
-                // scalar branches: a long block runs straight through).
+        };
+        auto wave_sync = [] {  // LDS hand-over between lanes of this wave
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        fetch_spectra(0);
+        __syncthreads();
+        for (int k = 0; k <= nsteps + 2; ++k) {
+            if (k < nsteps) {
+                float (*const XP)[576] = xrb[k & 1];
+                const rg_mp3_unit *const UP = Ub[k % 3];
+                // the units of step k + 1 become visible at this step's barrier; those of step k + 2 start travelling
+                if (uq) {
+                    if (k + 1 < nsteps) reinterpret_cast<uint4 *>(&Ub[(k + 1) % 3][0])[uq_t] = u_reg;
+                    if (k + 2 < nsteps) u_reg = reinterpret_cast<const uint4 *>(units + ubase + (uint64_t)(k + 2) * nch)[uq_t];
+                }
+                // ---- stage B: requantisation (rg_mp3dec.cpp: requantize)
                 uint2 raw[kRounds][2];
 #pragma unroll
                 for (int r = 0; r < kRounds; ++r) { raw[r][0] = rq_next[r][0]; raw[r][1] = rq_next[r][1]; }
@@ -222,28 +224,27 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
                     const int m4 = u.scalefac_scale ? 4 : 2;  // 4 * mult
                     const int base4 = (int)u.global_gain - 210;
                     int q;
-                    if (rq_lane < 22) {
-                        q = base4 - m4 * ((int)u.sf[rq_lane] + (u.preflag ? (int)ptab[rq_lane] : 0));
+                    if (lane < 22) {
+                        q = base4 - m4 * ((int)u.sf[lane] + (u.preflag ? (int)ptab[lane] : 0));
                     } else {
-                        const int kk = rq_lane - 22;  // 3 * band + window
+                        const int kk = lane - 22;  // 3 * band + window
                         const int band = kk / 3, win = kk - 3 * band;
                         const int rel = kk - 3 * (int)u.short_start;
                         const int sv = (band < 12 && rel >= 0) ? (int)u.sf[(int)u.long_end + rel] : 0;
                         q = base4 - 8 * (int)u.subblock_gain[win] - m4 * sv;
                     }
-                    q = q < RG_MP3_GAIN_Q_MIN ? RG_MP3_GAIN_Q_MIN : (q > RG_MP3_GAIN_Q_MAX ? RG_MP3_GAIN_Q_MAX : q);  // entries no line of this granule uses
-                    gtab[c][rq_lane] = rq_lane < 61 ? gain_l[q - RG_MP3_GAIN_Q_MIN] : 0.0f;  // a short band past the twelfth: 0
+                    q = q < RG_MP3_GAIN_Q_MIN ? RG_MP3_GAIN_Q_MIN : (q > RG_MP3_GAIN_Q_MAX ? RG_MP3_GAIN_Q_MAX : q);
+                    gtab[c][lane] = lane < 61 ? gain_l[q - RG_MP3_GAIN_Q_MIN] : 0.0f;
                     bt_s[c] = __builtin_amdgcn_readfirstlane((int)u.block_type);
-                    ll_s[c] = __builtin_amdgcn_readfirstlane((int)sfbl_l[u.long_end]);  // lines coded as long bands when the block is short; 0 when long_end == 0
+                    ll_s[c] = __builtin_amdgcn_readfirstlane((int)sfbl_l[u.long_end]);
                     so_s[c] = __builtin_amdgcn_readfirstlane(3 * (int)sfbs_l[u.short_start < 13 ? u.short_start : 13]);
                 }
                 const int ms_n = __builtin_amdgcn_readfirstlane(
                     (nch == 2 && (UP[0].mode_ext & 3) == 2) ? (UP[0].nz > UP[1].nz ? (int)UP[0].nz : (int)UP[1].nz) : 0);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();  // the gains are read by other lanes of this wave only
+                wave_sync();
 #pragma unroll
                 for (int r = 0; r < kRounds; ++r) {
-                    const int piece = rq_lane + 64 * r;
+                    const int piece = lane + 64 * r;
                     if (piece >= 144) continue;
                     const int rq_l0 = 4 * piece;
                     float val[2][4];
@@ -272,19 +273,18 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
                             m[j] = pow_l[a[j] < kPowLds ? a[j] : 0];
                         }
                         const int amax = (a[0] > a[1] ? a[0] : a[1]) > (a[2] > a[3] ? a[2] : a[3]) ? (a[0] > a[1] ? a[0] : a[1]) : (a[2] > a[3] ? a[2] : a[3]);
-                        if (amax >= kPowLds) {  // rare: an escape value beyond the LDS part of the table
+                        if (amax >= kPowLds) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
                                 if (a[j] >= kPowLds) m[j] = T->pow43[a[j]];
                         }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float t = m[j] * gv[j];  // >= +0; a negative value takes its sign (-t, also of a product that underflowed)
+                            const float t = m[j] * gv[j];
                             val[c][j] = __uint_as_float((__float_as_uint(t) & 0x7FFFFFFFu) | ((uint32_t)v[j] & 0x80000000u));
                         }
                     }
-                    // ---- stage C, the plain case: mid/side on every line below the longer channel's end (rg_mp3dec.cpp: stereo)
-                    if (ms_n) {
+                    if (ms_n) {  // stage C, the plain case: mid/side below the longer channel's end
                         const float isq2 = 0.70710678118654752440f;
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
@@ -298,321 +298,285 @@ rg_mp3_hybrid_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *
                     for (int c = 0; c < 2; ++c)
                         if (c < nch) *reinterpret_cast<float4 *>(&XP[c][rq_l0]) = make_float4(val[c][0], val[c][1], val[c][2], val[c][3]);
                 }
-            }
-        }
-        if (k >= 1 && imdct_thread) {
-            // ---- stage D of granule k - 1: alias reduction + IMDCT + window + overlap-add (rg_mp3dec.cpp: antialias, hybrid)
-            const int q = k - 1;
-            const rg_mp3_unit &u = Ub[q % 3][my_c];
-            const float *const X = xrb[pb ^ 1][my_c];
-            const int bt = (u.block_type == 2 && u.mixed && my_sb < 2) ? 0 : (int)u.block_type;
-            // the butterflies between subbands sb - 1 | sb, sb = 1 .. nb; this thread evaluates its own half of the two it touches
-            const int nb = u.block_type == 2 ? (u.mixed ? 1 : 0) : 31;
-            float xs[18];
-            const float *Xr = X + my_sb * 18;
-#pragma unroll
-            for (int i = 0; i < 18; ++i) xs[i] = Xr[i];
-            if (my_sb >= 1 && my_sb <= nb) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float a = Xr[-1 - i], b = xs[i];
-                    xs[i] = b * cs_l[i] + a * ca_l[i];
-                }
-            }
-            if (my_sb < nb) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float a = xs[17 - i], b = Xr[18 + i];
-                    xs[17 - i] = a * cs_l[i] - b * ca_l[i];
-                }
-            }
-            float *__restrict__ dst = sub + sub_index(ubase + (uint64_t)q * nch + my_c, 0, my_sb);
-            const bool keep = q + gi0 >= 0;
-            const bool flip = (my_sb & 1) != 0;
-            // windowed sample i of this granule: the first eighteen are added to the overlap and leave (frequency inversion:
-            // odd samples of odd subbands change sign), the second eighteen are the next granule's overlap
-#if RG_HYB_OVPREF
-            float ov[18];  // all eighteen reads in flight together, ahead of the arithmetic
-#pragma unroll
-            for (int i = 0; i < 18; ++i) ov[i] = ovl[i][tid];
-#endif
-            auto emit = [&](const int i, const float val) {
-                if (i < 18) {
-#if RG_HYB_OVPREF
-                    float v = val + ov[i];
-#else
-                    float v = val + ovl[i][tid];
-#endif
-                    if (flip && (i & 1)) v = -v;
-                    if (keep) dst[(size_t)i * 32] = v;
-                } else {
-                    ovl[i - 18][tid] = val;
-                }
-            };
-            if (bt != 2) {
-                struct Sink {
-                    decltype(emit) &f;
-                    struct Ref {
-                        decltype(emit) &f;
-                        int i;
-                        __device__ __forceinline__ void operator=(float v) { f(i, v); }
-                    };
-                    __device__ __forceinline__ Ref operator[](int i) { return Ref{f, i}; }
-                } sink{emit};
-                rg_mp3_imdct36_windowed(xs, wn[bt], sink);  // raw[m], raw[17-m] (read the overlap) before raw[18+m], raw[35-m] (write it)
-            } else {
-                // sample i of the three overlapping 12-point IMDCTs: window w contributes its sample i - 6 - 6w, in the
-                // order w = 0, 1, 2 (the host's)
-#pragma unroll 1
-                for (int i = 0; i < 36; ++i) {
-                    float raw = 0.0f;
-#pragma unroll
-                    for (int w = 0; w < 3; ++w) {
-                        const int ii = i - 6 - 6 * w;
-                        if (ii >= 0 && ii < 12) {
-                            float s2 = 0.0f;
-#pragma unroll
-                            for (int kk = 0; kk < 6; ++kk) s2 = rg_mp3_mac(xs[3 * kk + w], c12[ii][kk], s2);
-                            raw = rg_mp3_mac(s2, wn[2][ii], raw);
-                        }
-                    }
-                    // (the loop is rolled: the overlap comes from LDS by index here, not from the registers above)
-                    if (i < 18) {
-                        float v = raw + ovl[i][tid];
-                        if (flip && (i & 1)) v = -v;
-                        if (keep) dst[(size_t)i * 32] = v;
-                    } else {
-                        ovl[i - 18][tid] = raw;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (!special) continue;
-
-        // ==== the rest of granule k's stage C / D preparation, all four waves (uniform: `special` comes from the units) ====
-        if (nch == 2 && (UP[0].mode_ext & 1)) {
-            // ---- intensity stereo, with mid/side on the bands it leaves (rg_mp3dec.cpp: stereo)
-            const rg_mp3_unit &u1 = UP[1];
-            const bool ms = (UP[0].mode_ext & 2) != 0;
-            const float isq2 = 0.70710678118654752440f;
-            if (tid < 64) { band_nz[tid] = 0; band_mode[tid] = 0; }
-            __syncthreads();
-            const int long_lines = (int)sfbl_l[u1.long_end];
-            const int short_off = 3 * (int)sfbs_l[u1.short_start < 13 ? u1.short_start : 13];
-            // stereo band of a line: short bands 0..38 = (band - short_start) * 3 + window, long bands 39 + band
-            auto band_of = [&](int line) -> int {
-                if (u1.block_type != 2 || line < long_lines) return 39 + (int)T->long_band_of_line[rr][line];
-                return (int)T->short_idx_of_line[rr][line - long_lines + short_off] - 3 * (int)u1.short_start;
-            };
-            for (int line = tid; line < 576; line += NT)
-                if (XP[1][line] != 0.0f) band_nz[band_of(line)] = 1;
-            __syncthreads();
-            if (tid == 0) {
-                // walk the bands from the top: a band is intensity coded while every band above it (of the same
-                // window, for short blocks) has an all-zero right channel and its own position is legal
-                const bool lsf = tr.lsf != 0;
-                bool found[3] = {false, false, false};
-                bool found_long = false;
-                if (u1.block_type == 2) {
-                    for (int b = 12; b >= (int)u1.short_start; --b) {
-                        const int sb = b == 12 ? 11 : b;
-                        for (int w = 2; w >= 0; --w) {
-                            const int kk = (b - (int)u1.short_start) * 3 + w;
-                            const int idx = (int)u1.long_end + 3 * (sb - (int)u1.short_start) + w;
-                            bool intensity = false;
-                            int mode = 0;
-                            if (!found[w]) {
-                                if (band_nz[kk]) {
-                                    found[w] = true;
-                                } else {
-                                    const int p = u1.sf[idx];
-                                    intensity = lsf ? !((u1.illegal >> idx) & 1ull) : p < 7;
-                                    if (intensity) mode = 2 + p;
+                const bool special = (nch == 2 && (UP[0].mode_ext & 1)) || UP[0].block_type == 2 || (nch == 2 && UP[1].block_type == 2);
+                if (special) {
+                    wave_sync();
+                    if (nch == 2 && (UP[0].mode_ext & 1)) {
+                        // ---- intensity stereo, with mid/side on the bands it leaves (rg_mp3dec.cpp: stereo)
+                        const rg_mp3_unit &u1 = UP[1];
+                        const bool ms = (UP[0].mode_ext & 2) != 0;
+                        const float isq2 = 0.70710678118654752440f;
+                        band_nz[lane] = 0;
+                        band_mode[lane] = 0;
+                        wave_sync();
+                        const int long_lines = (int)sfbl_l[u1.long_end];
+                        const int short_off = 3 * (int)sfbs_l[u1.short_start < 13 ? u1.short_start : 13];
+                        auto band_of = [&](int line) -> int {
+                            if (u1.block_type != 2 || line < long_lines) return 39 + (int)T->long_band_of_line[rr][line];
+                            return (int)sidx_l[line - long_lines + short_off] - 3 * (int)u1.short_start;
+                        };
+                        for (int line = lane; line < 576; line += 64)
+                            if (XP[1][line] != 0.0f) band_nz[band_of(line)] = 1;
+                        wave_sync();
+                        if (lane == 0) {
+                            const bool lsf = tr.lsf != 0;
+                            bool found[3] = {false, false, false};
+                            bool found_long = false;
+                            if (u1.block_type == 2) {
+                                for (int b = 12; b >= (int)u1.short_start; --b) {
+                                    const int sb = b == 12 ? 11 : b;
+                                    for (int w = 2; w >= 0; --w) {
+                                        const int kk = (b - (int)u1.short_start) * 3 + w;
+                                        const int idx = (int)u1.long_end + 3 * (sb - (int)u1.short_start) + w;
+                                        bool intensity = false;
+                                        int mode = 0;
+                                        if (!found[w]) {
+                                            if (band_nz[kk]) {
+                                                found[w] = true;
+                                            } else {
+                                                const int p = u1.sf[idx];
+                                                intensity = lsf ? !((u1.illegal >> idx) & 1ull) : p < 7;
+                                                if (intensity) mode = 2 + p;
+                                            }
+                                        }
+                                        if (!intensity && ms) mode = 1;
+                                        band_mode[kk] = (short)mode;
+                                    }
+                                }
+                                found_long = found[0] || found[1] || found[2];
+                            }
+                            if (!(u1.block_type == 2 && !u1.mixed)) {
+                                for (int b = (int)u1.long_end - 1; b >= 0; --b) {
+                                    const int sb = b == 21 ? 20 : b;
+                                    bool intensity = false;
+                                    int mode = 0;
+                                    if (!found_long) {
+                                        if (band_nz[39 + b]) {
+                                            found_long = true;
+                                        } else {
+                                            const int p = u1.sf[sb];
+                                            intensity = lsf ? !((u1.illegal >> sb) & 1ull) : p < 7;
+                                            if (intensity) mode = 2 + p;
+                                        }
+                                    }
+                                    if (!intensity && ms) mode = 1;
+                                    band_mode[39 + b] = (short)mode;
                                 }
                             }
-                            if (!intensity && ms) mode = 1;
-                            band_mode[kk] = (short)mode;
                         }
-                    }
-                    found_long = found[0] || found[1] || found[2];
-                }
-                if (!(u1.block_type == 2 && !u1.mixed)) {
-                    for (int b = (int)u1.long_end - 1; b >= 0; --b) {
-                        const int sb = b == 21 ? 20 : b;
-                        bool intensity = false;
-                        int mode = 0;
-                        if (!found_long) {
-                            if (band_nz[39 + b]) {
-                                found_long = true;
-                            } else {
-                                const int p = u1.sf[sb];
-                                intensity = lsf ? !((u1.illegal >> sb) & 1ull) : p < 7;
-                                if (intensity) mode = 2 + p;
+                        wave_sync();
+                        const int scale = u1.intensity_scale & 1;
+                        for (int line = lane; line < 576; line += 64) {
+                            const int mode = band_mode[band_of(line)];
+                            if (mode == 1) {
+                                const float a = XP[0][line], b = XP[1][line];
+                                XP[0][line] = (a + b) * isq2;
+                                XP[1][line] = (a - b) * isq2;
+                            } else if (mode >= 2) {
+                                const int pos = mode - 2;
+                                float kl, kr;
+                                if (!tr.lsf) {
+                                    kl = T->is_l[pos];
+                                    kr = T->is_r[pos];
+                                } else if (pos == 0) {
+                                    kl = kr = 1.0f;
+                                } else if (pos & 1) {
+                                    kl = T->lsf_is[scale][(pos + 1) >> 1];
+                                    kr = 1.0f;
+                                } else {
+                                    kl = 1.0f;
+                                    kr = T->lsf_is[scale][pos >> 1];
+                                }
+                                const float v = XP[0][line];
+                                XP[0][line] = v * kl;
+                                XP[1][line] = v * kr;
                             }
                         }
-                        if (!intensity && ms) mode = 1;
-                        band_mode[39 + b] = (short)mode;
+                        wave_sync();
+                    }
+                    // ---- short blocks: bitstream order [band][window][line] -> [line][window] (rg_mp3dec.cpp: reorder),
+                    // in place: a lane's nine lines wait in registers while the wave's reads finish
+                    for (int c = 0; c < nch; ++c) {
+                        const rg_mp3_unit &u = UP[c];
+                        if (u.block_type != 2) continue;
+                        float *X = XP[c];
+                        const int long_lines = u.mixed ? (int)sfbl_l[u.long_end] : 0;
+                        const int short_off = 3 * (int)sfbs_l[u.short_start];
+                        float keep9[9];
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) {
+                            const int line = lane + 64 * i;
+                            keep9[i] = line < long_lines ? X[line] : X[(int)T->short_reorder_src[rr][line - long_lines + short_off] - short_off + long_lines];
+                        }
+                        wave_sync();
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) X[lane + 64 * i] = keep9[i];
+                        wave_sync();
                     }
                 }
             }
             __syncthreads();
-            const int scale = u1.intensity_scale & 1;
-            for (int line = tid; line < 576; line += NT) {
-                const int mode = band_mode[band_of(line)];
-                if (mode == 1) {
-                    const float a = XP[0][line], b = XP[1][line];
-                    XP[0][line] = (a + b) * isq2;
-                    XP[1][line] = (a - b) * isq2;
-                } else if (mode >= 2) {
-                    const int pos = mode - 2;
-                    float kl, kr;
-                    if (!tr.lsf) {
-                        kl = T->is_l[pos];
-                        kr = T->is_r[pos];
-                    } else if (pos == 0) {
-                        kl = kr = 1.0f;
-                    } else if (pos & 1) {
-                        kl = T->lsf_is[scale][(pos + 1) >> 1];
-                        kr = 1.0f;
-                    } else {
-                        kl = 1.0f;
-                        kr = T->lsf_is[scale][pos >> 1];
-                    }
-                    const float v = XP[0][line];
-                    XP[0][line] = v * kl;
-                    XP[1][line] = v * kr;
-                }
-            }
-            __syncthreads();
         }
-        // ---- short blocks: the spectrum from bitstream order [band][window][line] to [line][window] (rg_mp3dec.cpp: reorder)
-        for (int c = 0; c < nch; ++c) {
-            const rg_mp3_unit &u = UP[c];
-            if (u.block_type != 2) continue;
-            float *X = XP[c];
-            float *const tmp = xrb[pb ^ 1][0];  // free: the transform of granule k - 1 is behind the barrier, granule k + 1 not yet here
-            const int long_lines = u.mixed ? (int)sfbl_l[u.long_end] : 0;
-            const int short_off = 3 * (int)sfbs_l[u.short_start];
-            for (int line = tid; line < 576; line += NT)
-                tmp[line] = line < long_lines ? X[line]
-                                              : X[(int)T->short_reorder_src[rr][line - long_lines + short_off] - short_off + long_lines];
-            __syncthreads();
-            for (int line = tid; line < 576; line += NT) X[line] = tmp[line];
-            __syncthreads();
-        }
+        return;
     }
-}
 
-// One block = up to RG_MP3_SYNTH_RUN consecutive granules of one channel of one track: the fifteen time slots of
-// filterbank history are recomputed once per run instead of once per granule, and every time slot's matrixing is one
-// thread running the 32-point DCT of rg_mp3_math.h (the host runs the same code).
-__global__ void __launch_bounds__(256)
-rg_mp3_synth_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks,
-                    const float *__restrict__ hyb) {
-    constexpr int R = RG_MP3_SYNTH_RUN, SLOTS = 15 + 18 * R;
-    // One array for both stages: row r first holds the subband samples of time slot r (-15 .. 18 R - 1 relative to the run's
-    // first granule), then -- overwritten by the one thread that read them -- the 32 outputs A of that slot's DCT, from
-    // which the 64 matrixing values V follow by symmetry (rg_mp3_math.h: rg_mp3_matrixing).  Rows are padded by one word
-    // (a thread per row walking rows 32 words apart would have every lane in the same LDS bank); the pad holds 0.0f = V[16].
-    __shared__ float S[SLOTS][33];
-    const int tid = threadIdx.x;
-    uint32_t lo = 0, hi = n_tracks - 1;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi + 1) >> 1;
-        if (tracks[mid].synth_base <= blockIdx.x) lo = mid; else hi = mid - 1;
-    }
-    const RgMp3DevTrack tr = tracks[lo];
-    const int nch = (int)tr.channels;
-    const uint32_t local = blockIdx.x - tr.synth_base;
-    const uint32_t runs = (tr.n_granules + R - 1) / R;
-    if (runs == 0 || local >= runs * (uint32_t)nch) return;  // fewer granules decoded than the grid was laid out for
-    const int c = (int)(local / runs);
-    const uint32_t g0 = (local % runs) * R;
-    const int ng = (int)(tr.n_granules - g0 < (uint32_t)R ? tr.n_granules - g0 : (uint32_t)R);
-    const int nslots = 15 + 18 * ng;
-    // the window's sixteen coefficients for this thread's sample index (e % 32 == tid % 32 for every e it takes), fetched
-    // with everything else the block reads from memory
-    const int wj = tid & 31;
-    float Dw[16];
+    if (wave == 0) {
+        // ================= wave 0: lane (channel, subband): spectrum -> subband samples of eighteen time slots =========
+        const bool active = lane < 32 * nch;
+        const int my_c = lane >> 5, my_sb = lane & 31;
+        __syncthreads();
+        for (int k = 0; k <= nsteps + 2; ++k) {
+            if (k >= 1 && k <= nsteps && active) {
+                // ---- stage D of granule k - 1 (rg_mp3dec.cpp: antialias, hybrid).  The butterflies between subbands
+                // sb - 1 | sb, sb = 1 .. nb: this lane evaluates its own half of the two it touches.  Windowed sample i:
+                // the first eighteen are added to the overlap and leave (frequency inversion: odd samples of odd subbands
+                // change sign), the second eighteen are the next granule's overlap.
+                const int q = k - 1;
+                const rg_mp3_unit &u = Ub[q % 3][my_c];
+                const float *const X = xrb[q & 1][my_c];
+                const int bt = (u.block_type == 2 && u.mixed && my_sb < 2) ? 0 : (int)u.block_type;
+                const int nb = u.block_type == 2 ? (u.mixed ? 1 : 0) : 31;
+                float xs[18];
+                const float *Xr = X + my_sb * 18;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { Dw[2 * i] = T->D[i * 64 + wj]; Dw[2 * i + 1] = T->D[i * 64 + 32 + wj]; }
-    // Finished subband samples (the hybrid kernel has added the overlap and applied the frequency inversion), sixteen
-    // bytes = four adjacent subbands of one time slot per load, all of a thread's loads in flight together.
-    constexpr int kLoads = (SLOTS * 8 + 255) / 256;
-    float4 first[kLoads];
+                for (int i = 0; i < 18; ++i) xs[i] = Xr[i];
+                if (my_sb >= 1 && my_sb <= nb) {
 #pragma unroll
-    for (int k = 0; k < kLoads; ++k) {
-        const int e = tid + 256 * k;
-        first[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (e < nslots * 8) {
-            const int r = e / 8, sb = (e % 8) * 4;
-            const int rel = r - 15;                        // time slot relative to granule g0
-            const long long gg = (long long)g0 + (rel >= 0 ? rel / 18 : -1);
-            const int t = rel >= 0 ? rel % 18 : 18 + rel;
-            // the slots before the track are silence
-            if (gg >= 0) first[k] = *reinterpret_cast<const float4 *>(&hyb[sub_index(tr.unit_base + (uint64_t)gg * nch + c, t, sb)]);
+                    for (int i = 0; i < 8; ++i) {
+                        const float a = Xr[-1 - i], b = xs[i];
+                        xs[i] = b * cs_l[i] + a * ca_l[i];
+                    }
+                }
+                if (my_sb < nb) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float a = xs[17 - i], b = Xr[18 + i];
+                        xs[17 - i] = a * cs_l[i] - b * ca_l[i];
+                    }
+                }
+                float *const dst = &Sin[q & 1][my_c][0][my_sb];
+                const bool flip = (my_sb & 1) != 0;
+                auto emit = [&](const int i, const float val) {
+                    if (i < 18) {
+                        float v = val + ovl[i][lane];
+                        if (flip && (i & 1)) v = -v;
+                        dst[i * 33] = v;
+                    } else {
+                        ovl[i - 18][lane] = val;
+                    }
+                };
+                if (bt != 2) {
+                    struct Sink {
+                        decltype(emit) &f;
+                        struct Ref {
+                            decltype(emit) &f;
+                            int i;
+                            __device__ __forceinline__ void operator=(float v) { f(i, v); }
+                        };
+                        __device__ __forceinline__ Ref operator[](int i) { return Ref{f, i}; }
+                    } sink{emit};
+                    rg_mp3_imdct36_windowed(xs, wn[bt], sink);
+                } else {
+#pragma unroll 1
+                    for (int i = 0; i < 36; ++i) {
+                        float raw = 0.0f;
+#pragma unroll
+                        for (int w = 0; w < 3; ++w) {
+                            const int ii = i - 6 - 6 * w;
+                            if (ii >= 0 && ii < 12) {
+                                float s2 = 0.0f;
+#pragma unroll
+                                for (int kk = 0; kk < 6; ++kk) s2 = rg_mp3_mac(xs[3 * kk + w], c12[ii][kk], s2);
+                                raw = rg_mp3_mac(s2, wn[2][ii], raw);
+                            }
+                        }
+                        if (i < 18) {
+                            float v = raw + ovl[i][lane];
+                            if (flip && (i & 1)) v = -v;
+                            dst[i * 33] = v;
+                        } else {
+                            ovl[i - 18][lane] = raw;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
         }
+        return;
     }
+
+    if (wave == 2) {
+        // ================= wave 2: matrixing, lane (channel, time slot): the 32-point DCT (rg_mp3dec.cpp: synth) =======
+        const int c = lane >> 5, t = lane & 31;
+        const bool active = t < 18 && c < nch;
+        __syncthreads();
+        for (int k = 0; k <= nsteps + 2; ++k) {
+            const int p = k - 2;
+            if (p >= pd0 && p < nsteps && active) {
+                float x[32], A[32];
+                const float *src = &Sin[p & 1][c][t][0];
 #pragma unroll
-    for (int k = 0; k < kLoads; ++k) {
-        const int e = tid + 256 * k;
-        if (e < nslots * 8) {
-            const int r = e / 8, sb = (e % 8) * 4;
-            S[r][sb] = first[k].x;
-            S[r][sb + 1] = first[k].y;
-            S[r][sb + 2] = first[k].z;
-            S[r][sb + 3] = first[k].w;
+                for (int i = 0; i < 32; ++i) x[i] = src[i];
+                RgMp3Dct<32>::run(x, A, T->sec);
+                float *dstA = &Ar[p & 1][c][t][0];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) dstA[i] = A[i];
+                dstA[32] = 0.0f;
+            }
+            __syncthreads();
         }
+        return;
     }
-    __syncthreads();
-    // ---- polyphase synthesis: matrixing, one time slot per thread (rg_mp3dec.cpp: synth) ---------------------------
-    if (tid < nslots) {
-        float x[32], A[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) x[k] = S[tid][k];
-        RgMp3Dct<32>::run(x, A, T->sec);
-#pragma unroll
-        for (int k = 0; k < 32; ++k) S[tid][k] = A[k];
-        S[tid][32] = 0.0f;
-    }
-    __syncthreads();
-    // ---- the 512-tap window.  PCM sample j of time slot r is  sum_{i<8} V[r-2i][j] D[64i+j] + V[r-2i-1][32+j] D[64i+32+j]
-    // in that order (the host's).  V[.][j] = A[.][16+j] (j < 16), 0 (j = 16), -A[.][48-j] (j > 16); V[.][32+j] = -A[.][16-j]
-    // (j < 16), -A[.][0] (j = 16), -A[.][j-16] (j > 16): per thread two fixed columns of A, the signs folded into its sixteen
-    // window coefficients (fma(-a, d, s) and fma(a, -d, s) are the same bits).  A thread owns sample j = tid % 32 of up to
-    // fourteen consecutive time slots and keeps the rows they share in registers: 2 LDS reads per output instead of 16.
+
     {
-        constexpr int PER = (18 * R + 7) / 8;  // time slots per group of 32 threads
-        const int col1 = wj < 16 ? 16 + wj : (wj == 16 ? 32 : 48 - wj);
-        const int col2 = wj < 16 ? 16 - wj : wj - 16;
+        // ================= wave 3: the 512-tap window, lane (channel, j) -> PCM sample j of every time slot ============
+        // PCM sample j of time slot r is  sum_{i<8} V[r-2i][j] D[64i+j] + V[r-2i-1][32+j] D[64i+32+j]  in that order (the
+        // host's); V[.][j] and V[.][32+j] are two fixed columns of the DCT rows with the signs folded into the window
+        // coefficients: V[.][j] = A[.][16+j] (j < 16), 0 (j = 16), -A[.][48-j] (j > 16); V[.][32+j] = -A[.][16-j] (j < 16),
+        // -A[.][0] (j = 16), -A[.][j-16] (j > 16) (fma(-a, d, s) and fma(a, -d, s) are the same bits).  cA / cB [q]: those
+        // columns of time slot q - 15 relative to the granule.
+        const int c = lane >> 5, wj = lane & 31;
+        const bool active = c < nch;
         float D1[8], D2[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            D1[i] = wj > 16 ? -Dw[2 * i] : Dw[2 * i];
-            D2[i] = -Dw[2 * i + 1];
+            const float da = T->D[i * 64 + wj], db = T->D[i * 64 + 32 + wj];
+            D1[i] = wj > 16 ? -da : da;
+            D2[i] = -db;
         }
-        const int s0 = (tid >> 5) * PER;              // first time slot of this thread, relative to granule g0
-        const int ns = ng * 18 - s0 < PER ? ng * 18 - s0 : PER;
-        if (ns > 0) {
-            float c1[PER + 15], c2[PER + 15];         // rows s0 .. s0 + PER + 14 of S (time slots s0 - 15 .. s0 + PER - 1)
+        const int col1 = wj < 16 ? 16 + wj : (wj == 16 ? 32 : 48 - wj);
+        const int col2 = wj < 16 ? 16 - wj : wj - 16;
+        float cA[33], cB[33];
 #pragma unroll
-            for (int q = 0; q < PER + 15; ++q) {
-                const bool live = q < ns + 15;
-                c1[q] = live ? S[s0 + q][col1] : 0.0f;
-                c2[q] = live ? S[s0 + q][col2] : 0.0f;
-            }
-            float *__restrict__ dst = (c == 0 ? tr.ch0 : tr.ch1) + (size_t)g0 * 576 + (size_t)s0 * 32 + wj;
+        for (int q = 0; q < 33; ++q) cA[q] = cB[q] = 0.0f;  // the slots before the track are silence
+        float *const plane = c == 0 ? tr.ch0 : tr.ch1;
+        __syncthreads();
+        for (int k = 0; k <= nsteps + 2; ++k) {
+            const int p = k - 3;
+            if (p >= pd0 && p < nsteps && active) {
+                const float *rows = &Ar[p & 1][c][0][0];
 #pragma unroll
-            for (int q = 0; q < PER; ++q) {
-                float s = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    s = rg_mp3_mac(c1[q + 15 - 2 * i], D1[i], s);
-                    s = rg_mp3_mac(c2[q + 15 - 2 * i - 1], D2[i], s);
+                for (int q = 0; q < 18; ++q) {
+                    cA[15 + q] = rows[q * 33 + col1];
+                    cB[15 + q] = rows[q * 33 + col2];
                 }
-                if (q < ns) dst[(size_t)q * 32] = s;
+                if (p + gi0 >= 0) {
+                    float *__restrict__ dst = plane + ((size_t)g0 + (size_t)(p + gi0)) * 576 + wj;
+#pragma unroll
+                    for (int q = 0; q < 18; ++q) {
+                        float s2 = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            s2 = rg_mp3_mac(cA[q + 15 - 2 * i], D1[i], s2);
+                            s2 = rg_mp3_mac(cB[q + 15 - 2 * i - 1], D2[i], s2);
+                        }
+                        dst[(size_t)q * 32] = s2;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 15; ++q) { cA[q] = cA[q + 18]; cB[q] = cB[q + 18]; }
             }
+            __syncthreads();
         }
     }
 }
@@ -762,22 +726,31 @@ __device__ __forceinline__ void huff_scalefactors(BitCache &b, const RgMp3HuffRe
     }
 }
 
-// the spectrum leaves four words (eight lines) at a time
+// the spectrum leaves four words (eight lines) at a time, into the interleaved layout of rg_mp3_is_index
 struct RowOut {
-    uint4 *__restrict__ row;  // the unit's 576 int16 = 72 x 16 bytes
+    uint4 *__restrict__ row;  // the unit's first piece; its 72 pieces are 2^RG_MP3_IS_GROUP_LOG2 pieces apart
     uint32_t a, b, c;
     __device__ __forceinline__ void put(int line, uint32_t word) {  // `line` even; words arrive in order
         switch ((line >> 1) & 3) {
             case 0: a = word; break;
             case 1: b = word; break;
             case 2: c = word; break;
-            default: row[line >> 3] = make_uint4(a, b, c, word); break;
+            default: row[(line >> 3) << RG_MP3_IS_GROUP_LOG2] = make_uint4(a, b, c, word); break;
         }
     }
-    // zeros from `line` (even) to the end of the row
+    // zeros from `line` (even) to the end of the row.  The lanes of a wave walk the pieces together, each joining in at
+    // its own first one, so that the eight lanes of a group write their 128-byte line with one store here too.
     __device__ __forceinline__ void finish(int line) {
         for (; (line & 7) != 0 && line < 576; line += 2) put(line, 0u);
-        for (; line < 576; line += 8) row[line >> 3] = make_uint4(0u, 0u, 0u, 0u);
+        const int first = line >> 3;  // <= 72
+        int lowest = first;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int other = __shfl_xor(lowest, d);
+            lowest = other < lowest ? other : lowest;
+        }
+        for (int piece = lowest; piece < 72; ++piece)
+            if (piece >= first) row[piece << RG_MP3_IS_GROUP_LOG2] = make_uint4(0u, 0u, 0u, 0u);
     }
 };
 
@@ -834,7 +807,7 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
         r1e = T->sfb_long[rr][i1 > 22 ? 22 : i1];
     }
     // ---- Huffman-coded spectrum ----
-    RowOut out{reinterpret_cast<uint4 *>(is + u * 576), 0u, 0u, 0u};
+    RowOut out{reinterpret_cast<uint4 *>(is) + rg_mp3_is_index(u, 0, RG_MP3_IS_GROUP_LOG2), 0u, 0u, 0u};
     int line = 0;
     // One loop over the big_values pairs of all three regions: which table a pair uses is a per-lane choice made with
     // selects, so the lanes of a wave -- which sit in different regions of different granules -- run the same instructions
@@ -1041,19 +1014,13 @@ extern "C" hipError_t rg_launch_mp3_huffman(const RgMp3DevTables *d_tab, const R
     return hipGetLastError();
 }
 
-// n_runs: blocks of the grid, one per run of RG_MP3_SYNTH_RUN granules (RgMp3DevTrack::hrun_base)
-extern "C" hipError_t rg_launch_mp3_hybrid(const RgMp3DevTables *d_tab, const RgMp3DevTrack *d_tracks, uint32_t n_tracks,
-                                           uint32_t n_runs, const rg_mp3_unit *d_units, const int16_t *d_is, float *d_hyb,
-                                           hipStream_t s) {
+// n_runs: blocks of the grid, one per run of RG_MP3_RUN granules (RgMp3DevTrack::run_base); is_group_log2: layout of d_is
+// (rg_mp3_is_index): RG_MP3_IS_GROUP_LOG2 behind the device Huffman stage, 0 for spectra parsed on the host
+extern "C" hipError_t rg_launch_mp3_backhalf(const RgMp3DevTables *d_tab, const RgMp3DevTrack *d_tracks, uint32_t n_tracks,
+                                             uint32_t n_runs, const rg_mp3_unit *d_units, const int16_t *d_is, uint32_t is_group_log2,
+                                             hipStream_t s) {
     if (n_runs == 0) return hipSuccess;
-    hipLaunchKernelGGL(rg_mp3_hybrid_kernel, dim3(n_runs), dim3(RG_MP3_HYB_THREADS), 0, s, d_tab, d_tracks, n_tracks, d_units, d_is, d_hyb);
-    return hipGetLastError();
-}
-
-extern "C" hipError_t rg_launch_mp3_synth(const RgMp3DevTables *d_tab, const RgMp3DevTrack *d_tracks, uint32_t n_tracks,
-                                          uint32_t n_blocks, const float *d_hyb, hipStream_t s) {
-    if (n_blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(rg_mp3_synth_kernel, dim3(n_blocks), dim3(256), 0, s, d_tab, d_tracks, n_tracks, d_hyb);
+    hipLaunchKernelGGL(rg_mp3_backhalf_kernel, dim3(n_runs), dim3(RG_MP3_BH_THREADS), 0, s, d_tab, d_tracks, n_tracks, d_units, d_is, is_group_log2);
     return hipGetLastError();
 }
 

@@ -41,7 +41,7 @@ struct RgMp3StreamItem {
 // bytes of the descriptor array the staging block must have room for behind the streams (8-byte aligned offset `tracks_off`)
 size_t rg_mp3dev_track_bytes(size_t n_items);
 // One chunk: H2D of staging[0, bytes) on the context's copy stream into device set `set` (0 / 1), then frame parser,
-// Huffman, hybrid and synthesis kernels on `s`.  `staged` is recorded on the copy stream behind the H2D: the staging block
+// Huffman and back-half kernels on `s`.  `staged` is recorded on the copy stream behind the H2D: the staging block
 // may be refilled once it has completed.  Nothing is synchronised.
 int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, size_t tracks_off, hipEvent_t staged,
                             const RgMp3StreamItem *items, size_t n, hipStream_t s);

@@ -12,9 +12,8 @@
 extern "C" {
 hipError_t rg_launch_mp3_huffman(const RgMp3DevTables *, const RgMp3DevHuff *, const RgMp3DevTrack *, uint32_t, const RgMp3HuffRec *,
                                  const uint8_t *, rg_mp3_unit *, int16_t *, uint64_t, hipStream_t);
-hipError_t rg_launch_mp3_hybrid(const RgMp3DevTables *, const RgMp3DevTrack *, uint32_t, uint32_t, const rg_mp3_unit *,
-                                const int16_t *, float *, hipStream_t);
-hipError_t rg_launch_mp3_synth(const RgMp3DevTables *, const RgMp3DevTrack *, uint32_t, uint32_t, const float *, hipStream_t);
+hipError_t rg_launch_mp3_backhalf(const RgMp3DevTables *, const RgMp3DevTrack *, uint32_t, uint32_t, const rg_mp3_unit *,
+                                  const int16_t *, uint32_t, hipStream_t);
 hipError_t rg_launch_mp3_frames(RgMp3DevTrack *, uint32_t, uint32_t, const uint8_t *, uint32_t *, RgMp3HuffRec *, uint32_t *, hipStream_t);
 }
 
@@ -71,7 +70,7 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
         while (last < n && (last == first || units + items[last].n_units <= kChunkUnits)) units += items[last++].n_units;
         std::vector<RgMp3DevTrack> tr(last - first);
         uint64_t ub = 0, mainb = 0;
-        uint32_t gb = 0, sb = 0, hb = 0;
+        uint32_t gb = 0, hb = 0;
         bool any_recs = false;
         for (size_t i = first; i < last; ++i) {
             const RgMp3SplitItem &it = items[i];
@@ -85,19 +84,16 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
             t.lsf = it.lsf;
             t.ch0 = it.d_ch0;
             t.ch1 = it.d_ch1;
-            t.synth_base = sb;
-            t.hrun_base = hb;
-            sb += ((t.n_granules + RG_MP3_SYNTH_RUN - 1) / RG_MP3_SYNTH_RUN) * t.channels;  // runs of granules x channels
-            hb += (t.n_granules + RG_MP3_SYNTH_RUN - 1) / RG_MP3_SYNTH_RUN;
+            t.run_base = hb;
+            hb += (t.n_granules + RG_MP3_RUN - 1) / RG_MP3_RUN;
             t.main_base = mainb;
             ub += it.n_units;
             gb += t.n_granules;
             if (it.recs) { any_recs = true; mainb += (it.main_len + 15) & ~(uint64_t)15; }
         }
         if (units) {
-            RG_HIP(c, c->d_mp3_is.reserve(units * 576));
+            RG_HIP(c, c->d_mp3_is.reserve(((units + RG_MP3_IS_GROUP - 1) / RG_MP3_IS_GROUP) * RG_MP3_IS_GROUP * 576));  // whole groups (rg_mp3_is_index)
             RG_HIP(c, c->d_mp3_units.reserve(units * sizeof(rg_mp3_unit)));
-            RG_HIP(c, c->d_mp3_hyb.reserve(units * 576));
             RG_HIP(c, c->d_mp3_tracks.reserve(tr.size() * sizeof(RgMp3DevTrack)));
             if (any_recs) {
                 RG_HIP(c, c->d_mp3_recs.reserve(units * sizeof(RgMp3HuffRec)));
@@ -125,9 +121,8 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
                 RG_HIP(c, rg_launch_mp3_huffman(d_tab, d_huff, d_tr, (uint32_t)tr.size(), reinterpret_cast<const RgMp3HuffRec *>(c->d_mp3_recs.p),
                                                 c->d_mp3_main.p, reinterpret_cast<rg_mp3_unit *>(c->d_mp3_units.p), c->d_mp3_is.p, ub, s));
             }
-            RG_HIP(c, rg_launch_mp3_hybrid(d_tab, d_tr, (uint32_t)tr.size(), hb, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p),
-                                           c->d_mp3_is.p, c->d_mp3_hyb.p, s));
-            RG_HIP(c, rg_launch_mp3_synth(d_tab, d_tr, (uint32_t)tr.size(), sb, c->d_mp3_hyb.p, s));
+            RG_HIP(c, rg_launch_mp3_backhalf(d_tab, d_tr, (uint32_t)tr.size(), hb, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p),
+                                             c->d_mp3_is.p, any_recs ? RG_MP3_IS_GROUP_LOG2 : 0u, s));
             // the chunk buffers (and `tr`) are reused by the next chunk
             RG_HIP(c, hipStreamSynchronize(s));
         }
@@ -169,7 +164,7 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
     // laid out for the upper bound "every walked frame decodes"
     RgMp3DevTrack *tr = reinterpret_cast<RgMp3DevTrack *>(staging + tracks_off);
     uint64_t ub = 0;
-    uint32_t gb = 0, sb = 0, tb = 0, hb = 0;
+    uint32_t gb = 0, tb = 0, hb = 0;
     for (size_t i = 0; i < n; ++i) {
         const RgMp3StreamItem &it = items[i];
         RgMp3DevTrack &t = tr[i];
@@ -187,22 +182,19 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
         t.ch0 = it.d_ch0;
         t.ch1 = it.channels == 2 ? it.d_ch0 + (size_t)granules * 576 : nullptr;
         t.main_base = it.main_off;
-        t.synth_base = sb;
-        t.hrun_base = hb;
+        t.run_base = hb;
         t.n_frames = it.n_frames;
         t.slots_base = it.slots_off;
         t.result_index = it.result_index;
         ub += (uint64_t)granules * it.channels;
         gb += granules;
-        sb += ((granules + RG_MP3_SYNTH_RUN - 1) / RG_MP3_SYNTH_RUN) * it.channels;
-        hb += (granules + RG_MP3_SYNTH_RUN - 1) / RG_MP3_SYNTH_RUN;
+        hb += (granules + RG_MP3_RUN - 1) / RG_MP3_RUN;
     }
     // grow-only buffers; growing one frees the old allocation, which waits for the kernels still using it
     RG_HIP(c, c->d_mp3_stage[set].reserve(bytes + 64));
     if (ub) {
-        RG_HIP(c, c->d_mp3_is.reserve(ub * 576));
+        RG_HIP(c, c->d_mp3_is.reserve(((ub + RG_MP3_IS_GROUP - 1) / RG_MP3_IS_GROUP) * RG_MP3_IS_GROUP * 576));  // whole groups (rg_mp3_is_index)
         RG_HIP(c, c->d_mp3_units.reserve(ub * sizeof(rg_mp3_unit)));
-        RG_HIP(c, c->d_mp3_hyb.reserve(ub * 576));
         RG_HIP(c, c->d_mp3_recs.reserve(ub * sizeof(RgMp3HuffRec)));
         RG_HIP(c, c->d_mp3_tiles.reserve((size_t)tb * 2));
     }
@@ -224,11 +216,9 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
         RG_HIP(c, rg_launch_mp3_huffman(d_tab, d_huff, d_tr, (uint32_t)n, d_recs, d_chunk, reinterpret_cast<rg_mp3_unit *>(c->d_mp3_units.p),
                                         c->d_mp3_is.p, ub, s));
         if (ev) RG_HIP(c, hipEventRecord(ev[2], s));
-        RG_HIP(c, rg_launch_mp3_hybrid(d_tab, d_tr, (uint32_t)n, hb, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p), c->d_mp3_is.p,
-                                       c->d_mp3_hyb.p, s));
+        RG_HIP(c, rg_launch_mp3_backhalf(d_tab, d_tr, (uint32_t)n, hb, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p), c->d_mp3_is.p,
+                                         RG_MP3_IS_GROUP_LOG2, s));
         if (ev) RG_HIP(c, hipEventRecord(ev[3], s));
-        RG_HIP(c, rg_launch_mp3_synth(d_tab, d_tr, (uint32_t)n, sb, c->d_mp3_hyb.p, s));
-        if (ev) RG_HIP(c, hipEventRecord(ev[4], s));
     }
     RG_HIP(c, hipEventRecord(c->mp3_set_free[set], s));
     c->mp3_set_used[set] = true;
