@@ -103,6 +103,15 @@ struct DevBits {
 // (Rounds 2 and 3 had two kernels with the subband samples in memory between them -- 4.6 KB of traffic per granule and
 // channel, the fifteen slots of history transformed again by every block, 0.60 ms per 256 K units against 0.49 now; a
 // first fused kernel in round 2, six waves stepping through barrier-separated phases together, had lost to them.)
+// The block's barrier between pipeline steps.  What the waves hand each other is in LDS, so only LDS traffic has to be
+// complete at the barrier: __syncthreads() would also wait for every global load and store in flight -- the next
+// granule's spectra and units, the PCM on its way out -- and make a step as long as a round trip to memory.
+__device__ __forceinline__ void rg_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 #define RG_MP3_BH_THREADS 256
 __global__ void __launch_bounds__(RG_MP3_BH_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks,
@@ -196,12 +205,12 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
             }
         };
         auto wave_sync = [] {  // LDS hand-over between lanes of this wave
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
         };
         fetch_spectra(0);
-        __syncthreads();
+        rg_lds_barrier();
         for (int k = 0; k <= nsteps + 2; ++k) {
             if (k < nsteps) {
                 float (*const XP)[576] = xrb[k & 1];
@@ -415,7 +424,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                     }
                 }
             }
-            __syncthreads();
+            rg_lds_barrier();
         }
         return;
     }
@@ -424,7 +433,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         // ================= wave 0: lane (channel, subband): spectrum -> subband samples of eighteen time slots =========
         const bool active = lane < 32 * nch;
         const int my_c = lane >> 5, my_sb = lane & 31;
-        __syncthreads();
+        rg_lds_barrier();
         for (int k = 0; k <= nsteps + 2; ++k) {
             if (k >= 1 && k <= nsteps && active) {
                 // ---- stage D of granule k - 1 (rg_mp3dec.cpp: antialias, hybrid).  The butterflies between subbands
@@ -500,7 +509,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                     }
                 }
             }
-            __syncthreads();
+            rg_lds_barrier();
         }
         return;
     }
@@ -509,7 +518,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         // ================= wave 2: matrixing, lane (channel, time slot): the 32-point DCT (rg_mp3dec.cpp: synth) =======
         const int c = lane >> 5, t = lane & 31;
         const bool active = t < 18 && c < nch;
-        __syncthreads();
+        rg_lds_barrier();
         for (int k = 0; k <= nsteps + 2; ++k) {
             const int p = k - 2;
             if (p >= pd0 && p < nsteps && active) {
@@ -523,7 +532,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                 for (int i = 0; i < 32; ++i) dstA[i] = A[i];
                 dstA[32] = 0.0f;
             }
-            __syncthreads();
+            rg_lds_barrier();
         }
         return;
     }
@@ -550,7 +559,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
 #pragma unroll
         for (int q = 0; q < 33; ++q) cA[q] = cB[q] = 0.0f;  // the slots before the track are silence
         float *const plane = c == 0 ? tr.ch0 : tr.ch1;
-        __syncthreads();
+        rg_lds_barrier();
         for (int k = 0; k <= nsteps + 2; ++k) {
             const int p = k - 3;
             if (p >= pd0 && p < nsteps && active) {
@@ -576,7 +585,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
 #pragma unroll
                 for (int q = 0; q < 15; ++q) { cA[q] = cA[q + 18]; cB[q] = cB[q + 18]; }
             }
-            __syncthreads();
+            rg_lds_barrier();
         }
     }
 }
