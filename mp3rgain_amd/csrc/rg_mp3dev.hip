@@ -48,6 +48,9 @@ __device__ __forceinline__ uint32_t find_by_unit(const RgMp3DevTrack *__restrict
 // consecutive units at the same piece, so eight lanes fill a 128-byte line with one store, where rows of their own made
 // every 16-byte store a partial line (read for ownership + a masked write: 3.5 KB of traffic per unit for 1.2 KB of
 // spectrum).  G = 1: plain rows (what the host's rg_mp3_parse_units writes).  Index in 16-byte pieces; G = 2^group_log2.
+typedef short rg_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short rg_u16x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ uint64_t rg_mp3_is_index(uint64_t unit, int chunk, uint32_t group_log2) {
     return ((((unit >> group_log2) * 72 + (uint64_t)chunk) << group_log2) | (unit & ((1u << group_log2) - 1u)));
 }
@@ -251,61 +254,95 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                 const int ms_n = __builtin_amdgcn_readfirstlane(
                     (nch == 2 && (UP[0].mode_ext & 3) == 2) ? (UP[0].nz > UP[1].nz ? (int)UP[0].nz : (int)UP[1].nz) : 0);
                 wave_sync();
+                // This wave is the pipeline's longest stage and it runs alone on its data, so its length is the sum of its
+                // LDS round trips: the look-ups of a round (8 gains, 8 powers per lane, both channels) are all asked for
+                // before the first one is used, the rare value beyond the LDS part of the power table is dealt with once per
+                // round, and the third round's idle lanes run along on clamped indices instead of branching.
 #pragma unroll
                 for (int r = 0; r < kRounds; ++r) {
                     const int piece = lane + 64 * r;
-                    if (piece >= 144) continue;
-                    const int rq_l0 = 4 * piece;
-                    float val[2][4];
+                    const int rq_l0 = 4 * (piece < 144 ? piece : 143);
+                    float gv[2][4], mg[2][4];
+                    rg_u16x2 amax2 = {0, 0};
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
                         if (c >= nch) continue;
-                        const uint32_t w[2] = {raw[r][c].x, raw[r][c].y};
-                        float gv[4];
                         if (bt_s[c] != 2) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) gv[j] = gtab[c][(rq_lb[r] >> (8 * j)) & 0xFFu];
+                            for (int j = 0; j < 4; ++j) gv[c][j] = gtab[c][(rq_lb[r] >> (8 * j)) & 0xFFu];
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const int line = rq_l0 + j;
                                 const int idx = line < ll_s[c] ? (int)((rq_lb[r] >> (8 * j)) & 0xFFu) : 22 + (int)sidx_l[line - ll_s[c] + so_s[c]];
-                                gv[j] = gtab[c][idx];
+                                gv[c][j] = gtab[c][idx];
                             }
                         }
-                        int v[4], a[4];
-                        float m[4];
+                        // two lines per 32-bit word: |v|, the largest of them and the index into the LDS part of the power
+                        // table as packed 16-bit operations
+                        const uint32_t w[2] = {raw[r][c].x, raw[r][c].y};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            v[j] = (int)(int16_t)(w[j >> 1] >> (16 * (j & 1)));
-                            a[j] = v[j] < 0 ? -v[j] : v[j];
-                            m[j] = pow_l[a[j] < kPowLds ? a[j] : 0];
-                        }
-                        const int amax = (a[0] > a[1] ? a[0] : a[1]) > (a[2] > a[3] ? a[2] : a[3]) ? (a[0] > a[1] ? a[0] : a[1]) : (a[2] > a[3] ? a[2] : a[3]);
-                        if (amax >= kPowLds) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (a[j] >= kPowLds) m[j] = T->pow43[a[j]];
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float t = m[j] * gv[j];
-                            val[c][j] = __uint_as_float((__float_as_uint(t) & 0x7FFFFFFFu) | ((uint32_t)v[j] & 0x80000000u));
+                        for (int h = 0; h < 2; ++h) {
+                            const rg_u16x2 ua = __builtin_bit_cast(rg_u16x2, __builtin_elementwise_abs(__builtin_bit_cast(rg_s16x2, w[h])));
+                            amax2 = __builtin_elementwise_max(amax2, ua);
+                            const rg_u16x2 top = {(unsigned short)(kPowLds - 1), (unsigned short)(kPowLds - 1)};
+                            const rg_u16x2 ci = __builtin_elementwise_min(ua, top);
+                            mg[c][2 * h] = pow_l[ci.x];
+                            mg[c][2 * h + 1] = pow_l[ci.y];
                         }
                     }
-                    if (ms_n) {  // stage C, the plain case: mid/side below the longer channel's end
-                        const float isq2 = 0.70710678118654752440f;
+                    if ((amax2.x > amax2.y ? amax2.x : amax2.y) >= kPowLds) {  // rare: a value beyond the LDS part of the table
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (rq_l0 + j < ms_n) {
+                        for (int c = 0; c < 2; ++c) {
+                            if (c >= nch) continue;
+                            const uint32_t w[2] = {raw[r][c].x, raw[r][c].y};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int v = (int)(int16_t)(w[j >> 1] >> (16 * (j & 1)));
+                                const int a = v < 0 ? -v : v;
+                                if (a >= kPowLds) mg[c][j] = T->pow43[a];
+                            }
+                        }
+                    }
+                    float val[2][4];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        if (c >= nch) continue;
+                        const uint32_t w[2] = {raw[r][c].x, raw[r][c].y};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            // the product is >= +0; a negative value takes its sign (-t, also of a product that underflowed):
+                            // bit 31 of the word, shifted up for the low half
+                            const float t = mg[c][j] * gv[c][j];
+                            val[c][j] = __builtin_copysignf(t, __uint_as_float((j & 1) ? w[j >> 1] : w[j >> 1] << 16));
+                        }
+                    }
+                    // ---- stage C, the plain case: mid/side on the lines below the longer channel's end; the end is the same
+                    // for all lanes, so at most one round has lanes on both sides of it
+                    if (ms_n > 256 * r) {
+                        const float isq2 = 0.70710678118654752440f;
+                        if (ms_n >= 256 * r + 256) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
                                 const float a = val[0][j], b = val[1][j];
                                 val[0][j] = (a + b) * isq2;
                                 val[1][j] = (a - b) * isq2;
                             }
-                    }
+                        } else {
 #pragma unroll
-                    for (int c = 0; c < 2; ++c)
-                        if (c < nch) *reinterpret_cast<float4 *>(&XP[c][rq_l0]) = make_float4(val[c][0], val[c][1], val[c][2], val[c][3]);
+                            for (int j = 0; j < 4; ++j)
+                                if (4 * piece + j < ms_n) {
+                                    const float a = val[0][j], b = val[1][j];
+                                    val[0][j] = (a + b) * isq2;
+                                    val[1][j] = (a - b) * isq2;
+                                }
+                        }
+                    }
+                    if (piece < 144) {
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+                            if (c < nch) *reinterpret_cast<float4 *>(&XP[c][4 * piece]) = make_float4(val[c][0], val[c][1], val[c][2], val[c][3]);
+                    }
                 }
                 const bool special = (nch == 2 && (UP[0].mode_ext & 1)) || UP[0].block_type == 2 || (nch == 2 && UP[1].block_type == 2);
                 if (special) {
