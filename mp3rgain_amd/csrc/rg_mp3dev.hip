@@ -48,6 +48,7 @@ __device__ __forceinline__ uint32_t find_by_unit(const RgMp3DevTrack *__restrict
 // consecutive units at the same piece, so eight lanes fill a 128-byte line with one store, where rows of their own made
 // every 16-byte store a partial line (read for ownership + a masked write: 3.5 KB of traffic per unit for 1.2 KB of
 // spectrum).  G = 1: plain rows (what the host's rg_mp3_parse_units writes).  Index in 16-byte pieces; G = 2^group_log2.
+typedef float rg_f32x2 __attribute__((ext_vector_type(2)));
 typedef short rg_s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short rg_u16x2 __attribute__((ext_vector_type(2)));
 
@@ -608,15 +609,18 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                 }
                 if (p + gi0 >= 0) {
                     float *__restrict__ dst = plane + ((size_t)g0 + (size_t)(p + gi0)) * 576 + wj;
+                    // two time slots per instruction: the same sixteen fused multiply-adds per output, in the same order, as
+                    // packed operations (v_pk_fma_f32: both halves are the IEEE fma the host's rg_mp3_mac is)
 #pragma unroll
-                    for (int q = 0; q < 18; ++q) {
-                        float s2 = 0.0f;
+                    for (int q = 0; q < 18; q += 2) {
+                        rg_f32x2 s2 = {0.0f, 0.0f};
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
-                            s2 = rg_mp3_mac(cA[q + 15 - 2 * i], D1[i], s2);
-                            s2 = rg_mp3_mac(cB[q + 15 - 2 * i - 1], D2[i], s2);
+                            s2 = __builtin_elementwise_fma(rg_f32x2{cA[q + 15 - 2 * i], cA[q + 16 - 2 * i]}, rg_f32x2{D1[i], D1[i]}, s2);
+                            s2 = __builtin_elementwise_fma(rg_f32x2{cB[q + 14 - 2 * i], cB[q + 15 - 2 * i]}, rg_f32x2{D2[i], D2[i]}, s2);
                         }
-                        dst[(size_t)q * 32] = s2;
+                        dst[(size_t)q * 32] = s2.x;
+                        dst[(size_t)(q + 1) * 32] = s2.y;
                     }
                 }
 #pragma unroll
