@@ -634,19 +634,17 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
 // =====================================================================================================================
 // Stage A's heavy part on the device: scalefactors + Huffman-coded spectrum (rg_mp3dec.cpp: read_scalefactors_v1 /
 // read_scalefactors_lsf / decode_spectrum), one thread per granule and channel.  Integer work throughout: the outputs
-// (576 int16 per unit + one rg_mp3_unit) are exactly what rg_mp3_parse_units writes on the host.
+// (576 int16 per unit + one rg_mp3_unit) are the values rg_mp3_parse_units writes on the host; the spectra are laid out for
+// this kernel's stores (rg_mp3_is_index).
 //
 // The decode is a chain of dependent look-ups per symbol, so everything a symbol touches is kept close: the code tables
 // of all 32 table numbers sit in LDS (31 KB, copied once per block of 512 units), the bit stream is read through three
 // registers of 32 bits with the next word always in flight, scalefactors are parsed into an LDS column per thread, and
-// the spectrum leaves in 16-byte stores.  Granule 1 of an MPEG-1 frame may reuse granule 0's scalefactors (scfsi): its
+// the spectrum leaves in 16-byte stores that the eight lanes of a group put side by side.  Granule 1 of an MPEG-1 frame may reuse granule 0's scalefactors (scfsi): its
 // thread then parses granule 0's scalefactors first, which is cheaper than chaining the two granules in one thread.
 namespace {
 
-#ifndef RG_HUFF_THREADS
-#define RG_HUFF_THREADS 512
-#endif
-constexpr int kHuffThreads = RG_HUFF_THREADS;
+constexpr int kHuffThreads = 512;  // 1024 (eight waves per SIMD instead of six) is slower: 0.44 against 0.38 ms on the dense stream
 
 // 96 bits of the track's main data around the read position, big-endian words; bits at or past `limit` (the end of the
 // frame's own main data) read as zero, which is what the host decoder's private copy of the frame's data does.  All
