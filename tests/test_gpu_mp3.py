@@ -460,3 +460,21 @@ def test_a_stream_without_a_whole_frame_decodes_to_nothing(_ctx):
         finally:
             _ctx.set_tuning(6, DEFAULT_ROUTE)
         assert gi.frames == 0 and got.shape[1] == 0
+
+
+def test_the_decode_bench_hook_counts_what_it_decodes(_ctx):
+    """rg_mp3_decode_bench (bench.py's mp3_end_to_end.roofline, tools/mp3_chain.py): units, PCM frames and compressed bytes are
+    those of `copies` copies of the stream, every stage has a duration and the chain is at least their sum's largest part.
+    The PCM it leaves in the arena is not read back here: test_device_half_reproduces_the_host_decoder holds the kernels."""
+    data = (GOLD / "dense_44k_joint_128.mp3").read_bytes()
+    si = mp3dec.scan(data)
+    copies = 6
+    r = _ctx.decode_mp3_bench(data, copies, reps=3)
+    assert r["units"] == si.audio_frames * 2 * si.channels * copies
+    assert r["frames"] == si.frames * copies
+    assert 0 < r["compressed_bytes"] <= len(data) * copies
+    ms = r["ms"]
+    assert set(ms) == {"frames", "huffman", "backhalf", "chain"}
+    assert all(v > 0.0 for v in ms.values())
+    assert ms["chain"] >= max(ms["frames"], ms["huffman"], ms["backhalf"])
+    assert ms["chain"] <= 1.5 * (ms["frames"] + ms["huffman"] + ms["backhalf"]) + 0.05
