@@ -472,7 +472,7 @@ def test_the_decode_bench_hook_counts_what_it_decodes(_ctx):
     r = _ctx.decode_mp3_bench(data, copies, reps=3)
     assert r["units"] == si.audio_frames * 2 * si.channels * copies
     assert r["frames"] == si.frames * copies
-    assert 0 < r["compressed_bytes"] <= len(data) * copies
+    assert 0.8 * len(data) * copies < r["compressed_bytes"] < 1.1 * len(data) * copies  # main data + a 40-byte slot per frame
     ms = r["ms"]
     assert set(ms) == {"frames", "huffman", "backhalf", "chain"}
     assert all(v > 0.0 for v in ms.values())
