@@ -220,6 +220,114 @@ def mp3_end_to_end(an, nfiles: int) -> dict:
     return leg
 
 
+def node_main(args) -> int:
+    """`--node` / `--gpus N` without torch.distributed.run: the album workload of configs[3] in ONE process.  A node
+    (mp3rgain_amd.Node: one context per GPU) with the library's in-process RCCL communicators (ncclCommInitAll), one host
+    thread per GPU: every thread fills its device's arena with its share of the album (tracks i, i + N, ...), and a step is
+    enqueue -> all-gather of the 48 KB album packs + fold on the batch's stream -> album percentile, exactly the calls a
+    torchrun rank makes.  Threads meet at a barrier before and after the timed steps; the time is the slowest thread's."""
+    import threading
+
+    import torch
+
+    import mp3rgain_amd as rg
+    from mp3rgain_amd import _capi
+
+    n_dev = args.gpus
+    if not torch.cuda.is_available() or torch.cuda.device_count() < n_dev:
+        raise SystemExit(f"bench.py --node --gpus {n_dev}: {torch.cuda.device_count()} device(s) visible; there is no CPU path")
+    frames = int(round(args.minutes * 60 * RATE))
+    node = rg.Node(list(range(n_dev)))
+    node.set_exchange(rg.Node.EXCHANGE_RCCL)  # one communicator per device, built in this process
+    total_tracks = args.tracks_per_rank * n_dev
+    gate = threading.Barrier(n_dev)
+    out = [None] * n_dev
+    errors = []
+
+    def device_thread(i: int):
+        try:
+            torch.cuda.set_device(i)
+            an = node.analyzer(i)
+            if args.kernel:
+                an.set_kernel(args.kernel)
+            mine = list(range(i, total_tracks, n_dev))
+            ntr = len(mine)
+            pcm = torch.empty(max(1, 2 * frames * ntr), dtype=torch.float32, device=f"cuda:{i}")
+            descs = (_capi.TrackDesc * max(1, ntr))()
+            for t, g in enumerate(mine):
+                off = 2 * frames * t
+                for c in range(2):
+                    an.synth_fill_device(pcm[off + c * frames:].data_ptr(), 0x5EED0000 + g, c, RATE, 0, frames)
+                descs[t].offset_bytes = off * 4
+                descs[t].frames = frames
+                descs[t].sample_rate = RATE
+                descs[t].channels = 2
+                descs[t].format = _capi.FMT_F32_PLANAR
+            torch.cuda.synchronize(i)
+
+            def step():
+                an.enqueue_device(descs, ntr, pcm.data_ptr(), pcm.numel() * 4, album=True)
+                an.album_exchange()
+                an.album_result_enqueue()
+
+            pre_steps = max(2, min(8192, int(args.pre_roll / (max(1, frames * ntr) / 3.5e11))))
+            for k in range(pre_steps + args.warmup):
+                step()
+                if k % 64 == 63:
+                    torch.cuda.synchronize(i)
+            torch.cuda.synchronize(i)
+            gate.wait()
+            an.timing_enable(True)
+            an.timing_read(reset=True)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize(i)
+            gate.wait()
+            dt = time.perf_counter() - t0
+            ks, kl, ksp = an.timing_read(reset=True)
+            an.timing_enable(False)
+            res = an.collect(ntr)
+            alb = an.album_finish()
+            out[i] = {"dt": dt, "frames": frames * ntr, "k": (ks, kl, ksp), "album": alb, "first": res[0] if res else None,
+                      "flagged": sum(1 for r in res if r.flags & 2)}
+        except Exception as ex:  # noqa: BLE001
+            errors.append(f"device {i}: {ex}")
+            gate.abort()
+
+    threads = [threading.Thread(target=device_thread, args=(i,)) for i in range(n_dev)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise SystemExit("; ".join(errors))
+    dt = max(o["dt"] for o in out)
+    total_frames = sum(o["frames"] for o in out) * args.steps
+    ks, kl, ksp = out[0]["k"]
+    tag = workload_tag(args.tracks_per_rank, frames, True)
+    roof = roofline_block(out[0]["frames"], ks, kl, ksp, tag)
+    alb0 = out[0]["album"]
+    line = {
+        "metric": "stereo PCM samples/s through IIR+RMS+histogram", "value": total_frames / dt, "unit": "stereo samples/s",
+        "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[3] shape: album mode, {args.tracks_per_rank} synthetic "
+                               f"{args.minutes:g}-min 44.1 kHz stereo tracks per GPU per step, resident in HBM",
+                   "launch": "ONE process: rg_node, one context + one host thread per GPU, album packs exchanged over the "
+                             "library's in-process RCCL communicators (ncclCommInitAll)",
+                   "tracks_per_gpu": args.tracks_per_rank, "album_tracks": total_tracks},
+        "roofline": roof,
+        "cpu_baseline": None,  # measured by the default run (N = 1, one rank)
+        "result": {"album_loudness_db": alb0.album_loudness_db if alb0 else None,
+                   "album_gain_db": alb0.album_gain_db if alb0 else None,
+                   "every_device_agrees": len({(o["album"].album_loudness_db, o["album"].album_peak) for o in out}) == 1,
+                   "tracks_flagged_imprecise": sum(o["flagged"] for o in out)},
+    }
+    print(json.dumps(line))
+    return 0
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,6 +354,10 @@ def main() -> int:
     ap.add_argument("--mp3-files", type=int, default=256, help="files of the MP3 end-to-end leg (3-minute 320 kb/s streams; the two host-bound routes run on the first 64)")
     ap.add_argument("--configs1-steps", type=int, default=300)
     ap.add_argument("--pre-roll", type=float, default=PRE_ROLL_SECONDS, help="untimed pre-roll before the warm-up steps, seconds of work")
+    ap.add_argument("--node", action="store_true",
+                    help="ONE process for all --gpus devices (include/mp3rgain_amd_node.h: one context and one host thread per GPU, "
+                         "the library's in-process RCCL communicators for the album exchange) instead of one rank per GPU; "
+                         "also what `--gpus N` does when it is not launched through torch.distributed.run")
     args = ap.parse_args()
 
     import numpy as np
@@ -258,9 +370,9 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.node or (world == 1 and args.gpus > 1):
+        return node_main(args)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")

@@ -175,7 +175,8 @@ class Analyzer:
     # -- lifecycle ---------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_ctx", None):
-            self._lib.rg_destroy(self._ctx)
+            if not getattr(self, "_borrowed", False):  # a Node's context (Node.analyzer) dies with the node
+                self._lib.rg_destroy(self._ctx)
             self._ctx = None
 
     def __enter__(self):
@@ -474,6 +475,19 @@ class Node:
 
     def set_exchange(self, mode: int):
         self._check(self._lib.rg_node_set_exchange(self._node, int(mode)))
+
+    def analyzer(self, i: int) -> "Analyzer":
+        """The i-th device's context as an Analyzer, for the PCM-level and asynchronous entry points (bench.py's one-process
+        mode drives one from a host thread per device).  Owned by the node: closing it releases nothing."""
+        ctx = self._lib.rg_node_ctx(self._node, int(i))
+        if not ctx:
+            raise ReplayGainError(-1, f"node has no context {i}")
+        a = Analyzer.__new__(Analyzer)
+        a._lib = self._lib
+        a._ctx = ctx
+        a._borrowed = True
+        a.device = int(i)
+        return a
 
     def set_tuning(self, key: int, value: int):
         """rg_set_tuning on every device's context."""

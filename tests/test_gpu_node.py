@@ -140,3 +140,26 @@ def test_node_tracks_are_the_single_context_tracks(_ctx, tmp_path):
             assert (a.loudness_db, a.gain_db, a.peak, a.sample_rate, a.windows) == (b.loudness_db, b.gain_db, b.peak, b.sample_rate, b.windows), f.name
     assert (single.loudness_db, single.peak) == (want[0].loudness_db, want[0].peak)
     assert pk.peak == _ctx.find_peak_amplitude_file(files[0]).peak
+
+
+def test_bench_one_process_mode_prints_the_contract_line():
+    """`bench.py --node`: the album workload through rg_node in one process (a host thread per device, the library's
+    in-process communicators).  One device is all a test box has; the line must carry the contract's fields and an album
+    result every device agrees on."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    p = subprocess.run([sys.executable, str(root / "bench.py"), "--node", "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--tracks-per-rank", "8", "--minutes", "0.25", "--pre-roll", "0.001"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 0
+    assert "workload" in line["config"] and "ONE process" in line["config"]["launch"]
+    assert line["result"]["every_device_agrees"] is True
