@@ -156,7 +156,7 @@ def test_bench_one_process_mode_prints_the_contract_line():
                         "--tracks-per-rank", "8", "--minutes", "0.25", "--pre-roll", "0.001"],
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    line = json.loads(p.stdout.strip().splitlines()[-1])
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])  # RCCL prints its banner on stdout too
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in line, key
