@@ -103,10 +103,11 @@ struct DevBits {
 //                          into its sixteen window coefficients; 576 PCM samples per granule straight into the arena
 // A run that starts inside the track takes the two granules before it through the first stages (the second one's subband
 // samples need the first one's overlap, and its DCT rows are the filterbank's history).  Each wave runs its own loop, so
-// the register file is sized for the largest stage, not for their sum: 112 VGPRs, 39 KB of LDS, four blocks per CU.
+// the register file is sized for the largest stage, not for their sum: 128 VGPRs, 39 KB of LDS, four blocks per CU.
 // (Rounds 2 and 3 had two kernels with the subband samples in memory between them -- 4.6 KB of traffic per granule and
-// channel, the fifteen slots of history transformed again by every block, 0.60 ms per 256 K units against 0.49 now; a
+// channel, the fifteen slots of history transformed again by every block, 0.60 ms per 256 K units against 0.46 now; a
 // first fused kernel in round 2, six waves stepping through barrier-separated phases together, had lost to them.)
+
 // The block's barrier between pipeline steps.  What the waves hand each other is in LDS, so only LDS traffic has to be
 // complete at the barrier: __syncthreads() would also wait for every global load and store in flight -- the next
 // granule's spectra and units, the PCM on its way out -- and make a step as long as a round trip to memory.
