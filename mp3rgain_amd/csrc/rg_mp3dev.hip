@@ -103,7 +103,7 @@ struct DevBits {
 //                          into its sixteen window coefficients; 576 PCM samples per granule straight into the arena
 // A run that starts inside the track takes the two granules before it through the first stages (the second one's subband
 // samples need the first one's overlap, and its DCT rows are the filterbank's history).  Each wave runs its own loop, so
-// the register file is sized for the largest stage, not for their sum: 128 VGPRs, 39 KB of LDS, four blocks per CU.
+// the register file is sized for the largest stage, not for their sum: 128 VGPRs, 40 KB of LDS, four blocks per CU.
 // (Rounds 2 and 3 had two kernels with the subband samples in memory between them -- 4.6 KB of traffic per granule and
 // channel, the fifteen slots of history transformed again by every block, 0.60 ms per 256 K units against 0.46 now; a
 // first fused kernel in round 2, six waves stepping through barrier-separated phases together, had lost to them.)
@@ -130,7 +130,8 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
     __shared__ uint8_t ptab[24];
     __shared__ float ovl[18][64];
     __shared__ float gain_l[RG_MP3_GAIN_Q_MAX - RG_MP3_GAIN_Q_MIN + 1];
-    constexpr int kPowLds = 256;       // x^(4/3) for the values that occur; larger ones go to the table in memory
+    constexpr int kPowLds = 704;       // x^(4/3) for the values that occur (what four blocks per CU leave room for); larger ones
+                                       // go to the table in memory: a wait the wave cannot hide, once per round that has one
     __shared__ float pow_l[kPowLds];
     __shared__ uint16_t sfbl_l[24], sfbs_l[16];
     __shared__ float gtab[2][64];
