@@ -83,7 +83,7 @@ struct RgMp3DevTrack {
     float *ch0;              // PCM outputs (planar); 576 frames per granule
     float *ch1;
     uint64_t main_base;      // device Huffman stage: byte offset of the track's main-data stream in the chunk buffer
-    uint32_t reserved_;
+    uint32_t all_frames_decode;  // written by the frame parser's scan pass: no frame of the track was dropped (its records are in place)
     uint32_t n_frames;       // tuning key 6 = 3: frames the host walked (slots); the device decides which decode
     uint64_t slots_base;     //   byte offset of the track's slots (rg_mp3_frame.h) in the chunk buffer
     uint32_t result_index;   //   where the frame parser reports the granules it found decodable

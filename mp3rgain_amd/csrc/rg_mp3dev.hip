@@ -961,8 +961,9 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
 //          number of decodable granule-channels goes to tile_units
 //   scan   one block per track: prefix sum over the track's tiles; the track's decoded length replaces the upper bound
 //          in its descriptor, the second channel's plane moves up behind the first, the host reads the count from `results`
-//   write  the count pass again, now writing the records compacted (a dropped frame leaves no gap in the PCM, exactly
-//          as on the host)
+//   write  only for tracks that lost a frame (the count pass writes every record where it belongs when none is dropped,
+//          the scan pass tells): the count pass again, now writing the records compacted (a dropped frame leaves no gap
+//          in the PCM, exactly as on the host)
 namespace {
 __device__ __forceinline__ uint32_t find_by_tile(const RgMp3DevTrack *__restrict__ tr, uint32_t n, uint32_t tile) {
     uint32_t lo = 0, hi = n - 1;
@@ -1002,6 +1003,7 @@ rg_mp3_frames_kernel(const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks
     __shared__ uint32_t wave_sum[4];
     const uint32_t ti = find_by_tile(tracks, n_tracks, blockIdx.x);
     const RgMp3DevTrack tr = tracks[ti];
+    if (WRITE && tr.all_frames_decode) return;  // the count pass has put the records in place (block-uniform)
     const uint32_t tile = blockIdx.x - tr.tile_base;
     const uint32_t f = tile * RG_MP3_FRAME_TILE + threadIdx.x;
     const bool live = f < tr.n_frames;
@@ -1026,6 +1028,11 @@ rg_mp3_frames_kernel(const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks
     const uint32_t unit_excl = block_scan256(n, &total, wave_sum);
     if (!WRITE) {
         if (threadIdx.x == 0) tile_units[blockIdx.x] = total;
+        // the records already go where they belong if no frame of the track is dropped (the usual case: the scan pass finds
+        // out and the write pass has nothing left to do for the track)
+        const uint32_t upf = (tr.lsf ? 1u : 2u) * tr.channels;
+        RgMp3HuffRec *__restrict__ dst = recs + tr.unit_base + (uint64_t)tile * RG_MP3_FRAME_TILE * upf + unit_excl;
+        for (uint32_t i = 0; i < n; ++i) dst[i] = r[i];
     } else {
         RgMp3HuffRec *__restrict__ dst = recs + tr.unit_base + tile_unit_base[blockIdx.x] + unit_excl;
         for (uint32_t i = 0; i < n; ++i) dst[i] = r[i];
@@ -1050,6 +1057,7 @@ rg_mp3_frames_scan_kernel(RgMp3DevTrack *__restrict__ tracks, const uint32_t *__
     if (threadIdx.x == 0) {
         const uint32_t granules = run / tr.channels;
         tracks[blockIdx.x].n_granules = granules;
+        tracks[blockIdx.x].all_frames_decode = run == tr.n_frames * (tr.lsf ? 1u : 2u) * tr.channels ? 1u : 0u;
         if (tr.channels == 2) tracks[blockIdx.x].ch1 = tr.ch0 + (size_t)granules * 576;
         results[tr.result_index] = granules;
     }
