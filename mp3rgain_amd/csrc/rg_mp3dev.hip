@@ -253,6 +253,12 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                     bt_s[c] = __builtin_amdgcn_readfirstlane((int)u.block_type);
                     ll_s[c] = __builtin_amdgcn_readfirstlane((int)sfbl_l[u.long_end]);
                     so_s[c] = __builtin_amdgcn_readfirstlane(3 * (int)sfbs_l[u.short_start < 13 ? u.short_start : 13]);
+                    // The lines from a unit's nz on are zero and the Huffman stage does not write them (it completes the
+                    // 16-byte piece the last value falls into): what was fetched from there is replaced by zeros.
+                    const int nz8 = __builtin_amdgcn_readfirstlane(((int)u.nz + 7) & ~7);
+#pragma unroll
+                    for (int r = 0; r < kRounds; ++r)
+                        if (4 * (lane + 64 * r) >= nz8) raw[r][c] = make_uint2(0u, 0u);
                 }
                 const int ms_n = __builtin_amdgcn_readfirstlane(
                     (nch == 2 && (UP[0].mode_ext & 3) == 2) ? (UP[0].nz > UP[1].nz ? (int)UP[0].nz : (int)UP[1].nz) : 0);
@@ -788,19 +794,10 @@ struct RowOut {
             default: row[(line >> 3) << RG_MP3_IS_GROUP_LOG2] = make_uint4(a, b, c, word); break;
         }
     }
-    // zeros from `line` (even) to the end of the row.  The lanes of a wave walk the pieces together, each joining in at
-    // its own first one, so that the eight lanes of a group write their 128-byte line with one store here too.
+    // zeros from `line` (even) to the end of its 16-byte piece; the pieces behind it stay unwritten: the back half does not
+    // read past the unit's nz (rounded up to a piece)
     __device__ __forceinline__ void finish(int line) {
         for (; (line & 7) != 0 && line < 576; line += 2) put(line, 0u);
-        const int first = line >> 3;  // <= 72
-        int lowest = first;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const int other = __shfl_xor(lowest, d);
-            lowest = other < lowest ? other : lowest;
-        }
-        for (int piece = lowest; piece < 72; ++piece)
-            if (piece >= first) row[piece << RG_MP3_IS_GROUP_LOG2] = make_uint4(0u, 0u, 0u, 0u);
     }
 };
 
