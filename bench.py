@@ -234,10 +234,14 @@ def node_main(args) -> int:
     from mp3rgain_amd import _capi
 
     n_dev = args.gpus
-    if not torch.cuda.is_available() or torch.cuda.device_count() < n_dev:
+    rehearsal = os.environ.get("RG_BENCH_REHEARSAL") == "1"  # see main(): contexts share devices, stand-in transport
+    if not torch.cuda.is_available() or (torch.cuda.device_count() < n_dev and not rehearsal):
         raise SystemExit(f"bench.py --node --gpus {n_dev}: {torch.cuda.device_count()} device(s) visible; there is no CPU path")
+    dev_of = [i % torch.cuda.device_count() for i in range(n_dev)] if rehearsal else list(range(n_dev))
+    if rehearsal:
+        _capi.load().rg_comm_library(os.fsencode(os.environ["MP3RGAIN_AMD_RCCL_LIBRARY"]))
     frames = int(round(args.minutes * 60 * RATE))
-    node = rg.Node(list(range(n_dev)))
+    node = rg.Node(dev_of)
     node.set_exchange(rg.Node.EXCHANGE_RCCL)  # one communicator per device, built in this process
     total_tracks = args.tracks_per_rank * n_dev
     gate = threading.Barrier(n_dev)
@@ -246,13 +250,13 @@ def node_main(args) -> int:
 
     def device_thread(i: int):
         try:
-            torch.cuda.set_device(i)
+            torch.cuda.set_device(dev_of[i])
             an = node.analyzer(i)
             if args.kernel:
                 an.set_kernel(args.kernel)
             mine = list(range(i, total_tracks, n_dev))
             ntr = len(mine)
-            pcm = torch.empty(max(1, 2 * frames * ntr), dtype=torch.float32, device=f"cuda:{i}")
+            pcm = torch.empty(max(1, 2 * frames * ntr), dtype=torch.float32, device=f"cuda:{dev_of[i]}")
             descs = (_capi.TrackDesc * max(1, ntr))()
             for t, g in enumerate(mine):
                 off = 2 * frames * t
@@ -263,7 +267,7 @@ def node_main(args) -> int:
                 descs[t].sample_rate = RATE
                 descs[t].channels = 2
                 descs[t].format = _capi.FMT_F32_PLANAR
-            torch.cuda.synchronize(i)
+            torch.cuda.synchronize(dev_of[i])
 
             def step():
                 an.enqueue_device(descs, ntr, pcm.data_ptr(), pcm.numel() * 4, album=True)
@@ -274,15 +278,15 @@ def node_main(args) -> int:
             for k in range(pre_steps + args.warmup):
                 step()
                 if k % 64 == 63:
-                    torch.cuda.synchronize(i)
-            torch.cuda.synchronize(i)
+                    torch.cuda.synchronize(dev_of[i])
+            torch.cuda.synchronize(dev_of[i])
             gate.wait()
             an.timing_enable(True)
             an.timing_read(reset=True)
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 step()
-            torch.cuda.synchronize(i)
+            torch.cuda.synchronize(dev_of[i])
             gate.wait()
             dt = time.perf_counter() - t0
             ks, kl, ksp = an.timing_read(reset=True)
@@ -324,6 +328,9 @@ def node_main(args) -> int:
                    "every_device_agrees": len({(o["album"].album_loudness_db, o["album"].album_peak) for o in out}) == 1,
                    "tracks_flagged_imprecise": sum(o["flagged"] for o in out)},
     }
+    if rehearsal:
+        line["rehearsal"] = ("NOT A MEASUREMENT: contexts share devices, the library communicators run over the tests' stand-in "
+                             "transport (RG_BENCH_REHEARSAL=1)")
     print(json.dumps(line))
     return 0
 
@@ -376,7 +383,13 @@ def main() -> int:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
-    torch.cuda.set_device(local_rank)
+    # Rehearsal (RG_BENCH_REHEARSAL=1; tests/test_gpu_multirank.py): the world > 1 code of this file on a box with fewer GPUs
+    # than ranks.  Ranks share devices (rank % device count), torch.distributed runs over gloo and the library's communicator
+    # over the tests' stand-in transport (MP3RGAIN_AMD_RCCL_LIBRARY) -- RCCL itself refuses two ranks on one device.  The line
+    # says so and is not a measurement.
+    rehearsal = os.environ.get("RG_BENCH_REHEARSAL") == "1"
+    device = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(device)
     frames = int(round(args.minutes * 60 * RATE))
     # which tracks of the album this rank owns (global indices; the seed of a track is 0x5EED0000 + its index)
     if args.scaling == "strong":
@@ -388,13 +401,16 @@ def main() -> int:
     ntr = len(mine)
     # The context first: its pipeline streams should each get a hardware queue of their own (the runtime has 4
     # per process and deals them out as streams are created; torch.distributed / RCCL create several more).
-    an = rg.Analyzer(local_rank)
+    an = rg.Analyzer(device)
     dist = None
     if world > 1 or (args.album and "RANK" in os.environ):
         import torch.distributed as dist  # noqa: PLC0415
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     if args.kernel:
         an.set_kernel(args.kernel)
@@ -673,8 +689,12 @@ def main() -> int:
             "result": {"loudness_db": res[0].loudness_db if ntr else None, "gain_db": res[0].gain_db if ntr else None,
                        "peak": res[0].peak if ntr else None,
                        "album_loudness_db": alb.album_loudness_db if alb else None,
+                       "album_peak": alb.album_peak if alb else None,
                        "tracks_flagged_imprecise": n_imprecise},
         }
+        if rehearsal:
+            out["rehearsal"] = ("NOT A MEASUREMENT: ranks share devices, torch.distributed over gloo, the library communicator over "
+                                "the tests' stand-in transport (RG_BENCH_REHEARSAL=1)")
         print(json.dumps(out), flush=True)
     an.close()
     if dist is not None:

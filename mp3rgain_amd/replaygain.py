@@ -365,16 +365,18 @@ class Analyzer:
     def comm_init(self, unique_id: bytes, world: int, rank: int):
         self._check(self._lib.rg_comm_init(self._ctx, unique_id, world, rank))
 
-    def comm_init_torch(self, group=None):
+    def comm_init_torch(self, group=None, library: Optional[str] = None):
         """Bootstrap through torch.distributed: rank 0's ncclUniqueId is broadcast over the (already
-        initialised) process group, then every rank joins.  torch's own librccl.so is the one used.
+        initialised) process group, then every rank joins.  torch's own librccl.so is the one used unless `library`
+        (or the environment's MP3RGAIN_AMD_RCCL_LIBRARY) names another -- the tests' stand-in transport, which lets
+        several ranks share one GPU (tests/standin_rccl).
         Every rank raises, or none does: failures are agreed on over the process group."""
         import torch
         import torch.distributed as dist
 
-        lib = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        lib = library or os.environ.get("MP3RGAIN_AMD_RCCL_LIBRARY") or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         if os.path.exists(lib):
-            self._lib.rg_comm_library(lib.encode())
+            self._check(self._lib.rg_comm_library(os.fsencode(lib)))
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         src = dist.get_global_rank(group, 0) if group is not None else 0
         uid = b""
