@@ -2,8 +2,8 @@
 return the bits of the single-context calls it wraps (host fold and RCCL exchange -- a one-rank communicator from
 ncclCommInitAll), and a node of TWO contexts on the same device runs the real multi-device path -- files dealt out, two
 host threads, two concurrent contexts, the fold of two packs -- against the same answers.  (A communicator of more than one
-rank cannot be built on a one-GPU lease: RCCL rejects two ranks on one device.  The multi-rank all-gather itself stays
-unexecuted here)"""
+rank cannot be built on a one-GPU lease: RCCL rejects two ranks on one device.  The multi-rank exchange runs over a stand-in
+transport in tests/test_gpu_multirank.py)"""
 import shutil
 import sys
 from pathlib import Path
