@@ -156,7 +156,7 @@ def _album_oracle(oracle, n_tracks, frames):
     return oracle.hist_loudness(hist), peak
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 8])
 def test_bench_rank_mode_rehearsal(standin, oracle, world):
     """The driver's own command line for N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`), rehearsed with all
     ranks on device 0: the world > 1 branch of bench.py -- sharding, library communicator, barrier + max-over-ranks timing,
