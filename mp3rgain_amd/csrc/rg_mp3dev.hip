@@ -19,6 +19,8 @@
 // powers of two from a table indexed by the exact integer exponent.  tests/test_gpu_mp3.py demands equality.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "rg_mp3dev.h"
 #include "rg_mp3_math.h"
 #include "rg_mp3_frame.h"
@@ -117,6 +119,19 @@ __device__ __forceinline__ void rg_lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+#ifdef RG_BH_TIMING
+// Instrument (tools/build_variant.sh NAME -DRG_BH_TIMING=<block>; tools/bh_timing.py): shader-clock stamps of one block's
+// waves around their work of every pipeline step, and inside the requantisation wave
+__device__ unsigned long long rg_bh_dbg[4][40][2];
+__device__ unsigned long long rg_bh_dbg2[40][4];
+extern "C" int rg_bh_dbg_read(void *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rg_bh_dbg), sizeof(unsigned long long) * 4 * 40 * 2); }
+extern "C" int rg_bh_dbg2_read(void *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rg_bh_dbg2), sizeof(unsigned long long) * 40 * 4); }
+#define RG_BH_STAMP(w, k, e) do { if (blockIdx.x == RG_BH_TIMING && (threadIdx.x & 63) == 0 && (k) < 40) rg_bh_dbg[w][k][e] = __builtin_amdgcn_s_memtime(); } while (0)
+#define RG_BH_STAMP2(k, e) do { if (blockIdx.x == RG_BH_TIMING && (threadIdx.x & 63) == 0 && (k) < 40) rg_bh_dbg2[k][e] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RG_BH_STAMP(w, k, e) do { } while (0)
+#define RG_BH_STAMP2(k, e) do { } while (0)
+#endif
 #define RG_MP3_BH_THREADS 256
 __global__ void __launch_bounds__(RG_MP3_BH_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks,
@@ -178,6 +193,11 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
 
     if (wave == 1) {
         // ================= wave 1: units and spectra in, requantised (and stereo-processed, reordered) spectrum out ===
+        // This wave is the pipeline's longest stage, and a wave issues at most one instruction in four cycles: its length is
+        // its instruction count.  The body is compiled once per channel count, so that nothing in it asks how many channels
+        // there are.
+        auto requant_wave = [&](auto nch_c) {
+        constexpr int nch = decltype(nch_c)::value;
         constexpr int kRounds = 3;
         uint32_t rq_lb[kRounds] = {0u, 0u, 0u};  // long-block band numbers of a piece's four lines
 #pragma unroll
@@ -185,11 +205,37 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
             if (lane + 64 * r < 144) rq_lb[r] = *reinterpret_cast<const uint32_t *>(&T->long_band_of_line[rr][4 * (lane + 64 * r)]);
         const bool uq = lane >= 56 && lane < 56 + 4 * nch;  // lanes that carry the units: four 16-byte words each
         const int uq_t = lane - 56;
-        uint4 u_reg = make_uint4(0u, 0u, 0u, 0u);
+        uint4 u_reg = make_uint4(0u, 0u, 0u, 0u), u_first = make_uint4(0u, 0u, 0u, 0u);
         if (uq) {
-            reinterpret_cast<uint4 *>(&Ub[0][0])[uq_t] = reinterpret_cast<const uint4 *>(units + ubase)[uq_t];
+            u_first = reinterpret_cast<const uint4 *>(units + ubase)[uq_t];
+            reinterpret_cast<uint4 *>(&Ub[0][0])[uq_t] = u_first;
             if (nsteps > 1) u_reg = reinterpret_cast<const uint4 *>(units + ubase + nch)[uq_t];
         }
+        // A unit's last sixteen bytes -- nz, global_gain, block_type | mixed, subblock_gain | scalefac_scale, preflag,
+        // long_end, short_start | mode_ext, ... -- are the same for the whole wave and sit in lane 59 + 4 c of the units' way
+        // in: they go to scalar registers from there (v_readlane), one step ahead, so that the gains of a granule cost one
+        // look-up of the scalefactor and one of the gain instead of a chain of byte reads from the unit in LDS.
+        static_assert(offsetof(rg_mp3_unit, nz) == 48 && offsetof(rg_mp3_unit, mixed) == 52 && offsetof(rg_mp3_unit, scalefac_scale) == 56 &&
+                      offsetof(rg_mp3_unit, long_end) == 58 && offsetof(rg_mp3_unit, mode_ext) == 60, "unit header layout");
+        uint32_t h_next[2][4];
+        auto header_of = [&](const uint4 &reg, uint32_t (&h)[2][4]) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                h[c][0] = (uint32_t)__builtin_amdgcn_readlane((int)reg.x, 59 + 4 * c);
+                h[c][1] = (uint32_t)__builtin_amdgcn_readlane((int)reg.y, 59 + 4 * c);
+                h[c][2] = (uint32_t)__builtin_amdgcn_readlane((int)reg.z, 59 + 4 * c);
+                h[c][3] = (uint32_t)__builtin_amdgcn_readlane((int)reg.w, 59 + 4 * c);
+            }
+        };
+        header_of(u_first, h_next);
+        // what a lane's gain depends on besides the unit: its pretab entry, its (band, window), its window's byte of the
+        // subblock gains; the band limits long_end / short_start can take (0, 6, 8, 22 / 0, 3, 13) as line numbers
+        const int gq_kk = lane - 22, gq_band = gq_kk / 3, gq_win = gq_kk - 3 * gq_band;
+        const int gq_pt = lane < 22 ? (int)T->pretab[lane] : 0;
+        const int gq_sh = 8 * (1 + (gq_win < 0 ? 0 : gq_win));
+        const int ll6 = __builtin_amdgcn_readfirstlane((int)T->sfb_long[rr][6]), ll8 = __builtin_amdgcn_readfirstlane((int)T->sfb_long[rr][8]);
+        const int ll22 = __builtin_amdgcn_readfirstlane((int)T->sfb_long[rr][22]);
+        const int so3 = __builtin_amdgcn_readfirstlane(3 * (int)T->sfb_short[rr][3]), so13 = __builtin_amdgcn_readfirstlane(3 * (int)T->sfb_short[rr][13]);
         uint2 rq_next[kRounds][2];
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) rq_next[r][0] = rq_next[r][1] = make_uint2(0u, 0u);
@@ -207,7 +253,11 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                 const uint8_t *const row = is_bytes + rg_mp3_is_index(U, 0, is_group_log2) * 16;
 #pragma unroll
                 for (int r = 0; r < kRounds; ++r)
+#ifdef RG_BH_EXP_LOADS  // timing experiment only (wrong results): every step reads the same few coalesced lines
+                    if (lane + 64 * r < 144) rq_next[r][c] = *reinterpret_cast<const uint2 *>(is_bytes + 8 * (lane + 64 * r) + 0 * (row - is_bytes));
+#else
                     if (lane + 64 * r < 144) rq_next[r][c] = *reinterpret_cast<const uint2 *>(row + rq_off[r]);
+#endif
             }
         };
         auto wave_sync = [] {  // LDS hand-over between lanes of this wave
@@ -218,51 +268,126 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         fetch_spectra(0);
         rg_lds_barrier();
         for (int k = 0; k <= nsteps + 2; ++k) {
+            RG_BH_STAMP(1, k, 0);
             if (k < nsteps) {
                 float (*const XP)[576] = xrb[k & 1];
                 const rg_mp3_unit *const UP = Ub[k % 3];
                 // the units of step k + 1 become visible at this step's barrier; those of step k + 2 start travelling
-                if (uq) {
-                    if (k + 1 < nsteps) reinterpret_cast<uint4 *>(&Ub[(k + 1) % 3][0])[uq_t] = u_reg;
-                    if (k + 2 < nsteps) u_reg = reinterpret_cast<const uint4 *>(units + ubase + (uint64_t)(k + 2) * nch)[uq_t];
+                uint32_t h[2][4];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) h[c][i] = h_next[c][i];
+                if (k + 1 < nsteps) {
+                    if (uq) reinterpret_cast<uint4 *>(&Ub[(k + 1) % 3][0])[uq_t] = u_reg;
+                    header_of(u_reg, h_next);
                 }
                 // ---- stage B: requantisation (rg_mp3dec.cpp: requantize)
                 uint2 raw[kRounds][2];
 #pragma unroll
                 for (int r = 0; r < kRounds; ++r) { raw[r][0] = rq_next[r][0]; raw[r][1] = rq_next[r][1]; }
-                if (k + 1 < nsteps) fetch_spectra(k + 1);
-                int bt_s[2] = {0, 0}, ll_s[2] = {0, 0}, so_s[2] = {0, 0};
+                // The lines from a unit's nz on are zero and the Huffman stage does not write them (it completes the
+                // 16-byte piece the last value falls into): what was fetched from there is replaced by zeros.
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    if (c >= nch) continue;
-                    const rg_mp3_unit &u = UP[c];
-                    const int m4 = u.scalefac_scale ? 4 : 2;  // 4 * mult
-                    const int base4 = (int)u.global_gain - 210;
-                    int q;
-                    if (lane < 22) {
-                        q = base4 - m4 * ((int)u.sf[lane] + (u.preflag ? (int)ptab[lane] : 0));
-                    } else {
-                        const int kk = lane - 22;  // 3 * band + window
-                        const int band = kk / 3, win = kk - 3 * band;
-                        const int rel = kk - 3 * (int)u.short_start;
-                        const int sv = (band < 12 && rel >= 0) ? (int)u.sf[(int)u.long_end + rel] : 0;
-                        q = base4 - 8 * (int)u.subblock_gain[win] - m4 * sv;
-                    }
-                    q = q < RG_MP3_GAIN_Q_MIN ? RG_MP3_GAIN_Q_MIN : (q > RG_MP3_GAIN_Q_MAX ? RG_MP3_GAIN_Q_MAX : q);
-                    gtab[c][lane] = lane < 61 ? gain_l[q - RG_MP3_GAIN_Q_MIN] : 0.0f;
-                    bt_s[c] = __builtin_amdgcn_readfirstlane((int)u.block_type);
-                    ll_s[c] = __builtin_amdgcn_readfirstlane((int)sfbl_l[u.long_end]);
-                    so_s[c] = __builtin_amdgcn_readfirstlane(3 * (int)sfbs_l[u.short_start < 13 ? u.short_start : 13]);
-                    // The lines from a unit's nz on are zero and the Huffman stage does not write them (it completes the
-                    // 16-byte piece the last value falls into): what was fetched from there is replaced by zeros.
-                    const int nz8 = __builtin_amdgcn_readfirstlane(((int)u.nz + 7) & ~7);
+                for (int c = 0; c < nch; ++c) {
+                    const int nz8 = ((int)(h[c][0] & 0xFFFFu) + 7) & ~7;
 #pragma unroll
                     for (int r = 0; r < kRounds; ++r)
                         if (4 * (lane + 64 * r) >= nz8) raw[r][c] = make_uint2(0u, 0u);
                 }
-                const int ms_n = __builtin_amdgcn_readfirstlane(
-                    (nch == 2 && (UP[0].mode_ext & 3) == 2) ? (UP[0].nz > UP[1].nz ? (int)UP[0].nz : (int)UP[1].nz) : 0);
+                RG_BH_STAMP2(k, 2);
+                // Order matters from here to the end of the step.  Everything this step needs from memory has arrived; the
+                // loads for the steps to come are issued below and nothing later in the step may wait for memory: the compiler
+                // cannot count loads across a branch and waits for ALL of them wherever a conditional load meets the code
+                // after it, i.e. it would sit out a round trip of the prefetch in every step.  The one conditional read of the
+                // step -- a quantised value beyond the LDS part of the x^(4/3) table takes its power from the full table in
+                // memory -- therefore happens HERE, before the prefetch, and the power waits in the line's own place in the
+                // output buffer (which nobody else touches before this step's barrier).
+                {
+                    rg_u16x2 amax_r[kRounds], amax2 = {0, 0};
+#pragma unroll
+                    for (int r = 0; r < kRounds; ++r) {
+                        amax_r[r] = rg_u16x2{0, 0};
+#pragma unroll
+                        for (int c = 0; c < nch; ++c) {
+                            amax_r[r] = __builtin_elementwise_max(amax_r[r], __builtin_bit_cast(rg_u16x2, __builtin_elementwise_abs(__builtin_bit_cast(rg_s16x2, raw[r][c].x))));
+                            amax_r[r] = __builtin_elementwise_max(amax_r[r], __builtin_bit_cast(rg_u16x2, __builtin_elementwise_abs(__builtin_bit_cast(rg_s16x2, raw[r][c].y))));
+                        }
+                        amax2 = __builtin_elementwise_max(amax2, amax_r[r]);
+                    }
+                    if (__builtin_amdgcn_ballot_w64((amax2.x > amax2.y ? amax2.x : amax2.y) >= kPowLds) != 0) {
+#pragma unroll
+                        for (int r = 0; r < kRounds; ++r) {
+                            // a round without such a value (the usual case even here) costs no trip to memory
+                            if (__builtin_amdgcn_ballot_w64((amax_r[r].x > amax_r[r].y ? amax_r[r].x : amax_r[r].y) >= kPowLds) == 0) continue;
+                            float big[2][4];
+#pragma unroll
+                            for (int c = 0; c < nch; ++c) {
+                                const uint32_t w[2] = {raw[r][c].x, raw[r][c].y};
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const int v = (int)(int16_t)(w[j >> 1] >> (16 * (j & 1)));
+                                    const int a = v < 0 ? -v : v;
+                                    big[c][j] = a >= kPowLds ? T->pow43[a] : 0.0f;
+                                }
+                            }
+                            // every lane consumes what it asked for, on every path: a load whose value is only looked at
+                            // under a condition stays "in flight" in the compiler's books on the other path, and the next
+                            // write to its register -- the prefetch's address arithmetic below -- then waits for everything
+#pragma unroll
+                            for (int c = 0; c < nch; ++c)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(big[c][j]));
+                            if (lane + 64 * r < 144) {
+#pragma unroll
+                                for (int c = 0; c < nch; ++c)
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j)
+                                        if (big[c][j] != 0.0f) XP[c][4 * (lane + 64 * r) + j] = big[c][j];
+                            }
+                        }
+                    }
+                }
+                RG_BH_STAMP2(k, 3);
+                if (uq && k + 2 < nsteps) u_reg = reinterpret_cast<const uint4 *>(units + ubase + (uint64_t)(k + 2) * nch)[uq_t];
+                if (k + 1 < nsteps) fetch_spectra(k + 1);
+                int bt_s[2] = {0, 0}, ll_s[2] = {0, 0}, so_s[2] = {0, 0};
+                int gq_idx[2] = {0, 0};
+                uint32_t gq_sf[2] = {0u, 0u};
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {  // the scalefactor each lane's gain needs: one byte read per channel, asked for together
+                    if (c >= nch) continue;
+                    const int long_end = (int)((h[c][2] >> 16) & 0xFFu), short_start = (int)(h[c][2] >> 24);
+                    const int rel = gq_kk - 3 * short_start;
+                    const bool short_sf = lane >= 22 && gq_band < 12 && rel >= 0;
+                    gq_idx[c] = lane < 22 ? lane : (short_sf ? long_end + rel : -1);
+                    gq_sf[c] = UP[c].sf[gq_idx[c] < 0 ? 0 : gq_idx[c]];
+                }
+                float gq_g[2] = {0.0f, 0.0f};
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (c >= nch) continue;
+                    const int scalefac_scale = (int)(h[c][2] & 0xFFu), preflag = (int)((h[c][2] >> 8) & 0xFFu);
+                    const int long_end = (int)((h[c][2] >> 16) & 0xFFu), short_start = (int)(h[c][2] >> 24);
+                    const int m4 = scalefac_scale ? 4 : 2;  // 4 * mult
+                    const int base4 = (int)((h[c][0] >> 16) & 0xFFu) - 210;
+                    const int sv = gq_idx[c] < 0 ? 0 : (int)gq_sf[c];
+                    int q;
+                    if (lane < 22) q = base4 - m4 * (sv + (preflag ? gq_pt : 0));
+                    else q = base4 - 8 * (int)((h[c][1] >> gq_sh) & 0xFFu) - m4 * sv;
+                    q = q < RG_MP3_GAIN_Q_MIN ? RG_MP3_GAIN_Q_MIN : (q > RG_MP3_GAIN_Q_MAX ? RG_MP3_GAIN_Q_MAX : q);
+                    gq_g[c] = gain_l[q - RG_MP3_GAIN_Q_MIN];
+                    bt_s[c] = (int)(h[c][0] >> 24);
+                    ll_s[c] = long_end == 22 ? ll22 : (long_end == 8 ? ll8 : (long_end == 6 ? ll6 : (long_end == 0 ? 0 : (int)sfbl_l[long_end])));
+                    so_s[c] = short_start >= 13 ? so13 : (short_start == 3 ? so3 : (short_start == 0 ? 0 : 3 * (int)sfbs_l[short_start]));
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    if (c < nch) gtab[c][lane] = lane < 61 ? gq_g[c] : 0.0f;
+                const int nz0 = (int)(h[0][0] & 0xFFFFu), nz1 = (int)(h[1][0] & 0xFFFFu);
+                const int ms_n = (nch == 2 && (h[0][3] & 3u) == 2u) ? (nz0 > nz1 ? nz0 : nz1) : 0;
                 wave_sync();
+                RG_BH_STAMP2(k, 0);
                 // This wave is the pipeline's longest stage and it runs alone on its data, so its length is the sum of its
                 // LDS round trips: the look-ups of a round (8 gains, 8 powers per lane, both channels) are all asked for
                 // before the first one is used, the rare value beyond the LDS part of the power table is dealt with once per
@@ -309,7 +434,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                             for (int j = 0; j < 4; ++j) {
                                 const int v = (int)(int16_t)(w[j >> 1] >> (16 * (j & 1)));
                                 const int a = v < 0 ? -v : v;
-                                if (a >= kPowLds) mg[c][j] = T->pow43[a];
+                                if (a >= kPowLds) mg[c][j] = XP[c][rq_l0 + j];  // put there at the top of the step
                             }
                         }
                     }
@@ -353,6 +478,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                             if (c < nch) *reinterpret_cast<float4 *>(&XP[c][4 * piece]) = make_float4(val[c][0], val[c][1], val[c][2], val[c][3]);
                     }
                 }
+                RG_BH_STAMP2(k, 1);
                 const bool special = (nch == 2 && (UP[0].mode_ext & 1)) || UP[0].block_type == 2 || (nch == 2 && UP[1].block_type == 2);
                 if (special) {
                     wave_sync();
@@ -470,8 +596,12 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                     }
                 }
             }
+            RG_BH_STAMP(1, k, 1);
             rg_lds_barrier();
         }
+        };
+        if (nch == 2) requant_wave(std::integral_constant<int, 2>{});
+        else requant_wave(std::integral_constant<int, 1>{});
         return;
     }
 
@@ -481,6 +611,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         const int my_c = lane >> 5, my_sb = lane & 31;
         rg_lds_barrier();
         for (int k = 0; k <= nsteps + 2; ++k) {
+            RG_BH_STAMP(0, k, 0);
             if (k >= 1 && k <= nsteps && active) {
                 // ---- stage D of granule k - 1 (rg_mp3dec.cpp: antialias, hybrid).  The butterflies between subbands
                 // sb - 1 | sb, sb = 1 .. nb: this lane evaluates its own half of the two it touches.  Windowed sample i:
@@ -555,6 +686,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                     }
                 }
             }
+            RG_BH_STAMP(0, k, 1);
             rg_lds_barrier();
         }
         return;
@@ -566,6 +698,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         const bool active = t < 18 && c < nch;
         rg_lds_barrier();
         for (int k = 0; k <= nsteps + 2; ++k) {
+            RG_BH_STAMP(2, k, 0);
             const int p = k - 2;
             if (p >= pd0 && p < nsteps && active) {
                 float x[32], A[32];
@@ -578,6 +711,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                 for (int i = 0; i < 32; ++i) dstA[i] = A[i];
                 dstA[32] = 0.0f;
             }
+            RG_BH_STAMP(2, k, 1);
             rg_lds_barrier();
         }
         return;
@@ -607,6 +741,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         float *const plane = c == 0 ? tr.ch0 : tr.ch1;
         rg_lds_barrier();
         for (int k = 0; k <= nsteps + 2; ++k) {
+            RG_BH_STAMP(3, k, 0);
             const int p = k - 3;
             if (p >= pd0 && p < nsteps && active) {
                 const float *rows = &Ar[p & 1][c][0][0];
@@ -634,6 +769,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
 #pragma unroll
                 for (int q = 0; q < 15; ++q) { cA[q] = cA[q + 18]; cB[q] = cB[q + 18]; }
             }
+            RG_BH_STAMP(3, k, 1);
             rg_lds_barrier();
         }
     }

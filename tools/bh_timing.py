@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Where a back-half block's step goes (GPU box; needs a library built with -DRG_BH_TIMING=<block>):
+
+    tools/build_variant.sh bht -DRG_BH_TIMING=2000
+    MP3RGAIN_AMD_LIB=build_ab/libbht.so python tools/bh_timing.py
+
+Per stream: each wave's busy time per pipeline step (stamp before its barrier minus stamp after the previous one) and the step
+period, in shader-clock cycles, for block RG_BH_TIMING of the last launch."""
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import torch  # noqa: E402,F401
+
+import mp3rgain_amd as rg  # noqa: E402
+from mp3rgain_amd import _capi, mp3dec  # noqa: E402
+
+lib = _capi.load()
+an = rg.Analyzer(0)
+names = {0: "imdct", 1: "requant", 2: "dct32", 3: "window"}
+for label, src in (("dense320_synthetic", ROOT / "tests/golden/mp3/v1_44k_stereo_long.mp3"),
+                   ("dense128_joint_music", ROOT / "tests/golden/mp3/dense_44k_joint_128.mp3"),
+                   ("vbr_fixture_sine", ROOT / "tests/golden/fixtures/test_vbr.mp3")):
+    data = src.read_bytes()
+    info = mp3dec.scan(data)
+    body = data[int(info.first_frame_offset):]
+    one = mp3dec.scan(body)
+    reps = max(1, int(180.0 / (one.frames / one.sample_rate)))
+    stream = body * reps
+    si = mp3dec.scan(stream)
+    units_per = si.audio_frames * (2 if si.mpeg_version == 1 else 1) * si.channels
+    copies = max(1, round((1 << 18) / units_per))
+    r = an.decode_mp3_bench(stream, copies, reps=3)
+    buf = np.zeros((4, 40, 2), dtype=np.uint64)
+    assert lib.rg_bh_dbg_read(C.c_void_p(buf.ctypes.data)) == 0
+    t = buf.astype(np.int64)
+    print(f"== {label}: backhalf {r['ms']['backhalf'] * (1 << 18) / r['units']:.3f} ms per 256K units")
+    steps = slice(4, 32)  # the pipeline's steady part
+    period = np.diff(t[1, :, 0])[steps]
+    print(f"   step period: mean {period.mean():.0f} cycles (min {period.min()}, max {period.max()})")
+    for w in (1, 0, 2, 3):
+        busy = (t[w, :, 1] - t[w, :, 0])[steps]
+        print(f"   wave {w} {names[w]:8s}: busy mean {busy.mean():7.0f}  min {busy.min():6d}  max {busy.max():6d}   = {busy.mean() / period.mean() * 100:4.0f} % of the step")
+    d2 = np.zeros((40, 4), dtype=np.uint64)
+    assert lib.rg_bh_dbg2_read(C.c_void_p(d2.ctypes.data)) == 0
+    d2 = d2.astype(np.int64)
+    a0 = (d2[:, 2] - t[1, :, 0])[steps]
+    a1 = (d2[:, 3] - d2[:, 2])[steps]
+    a2 = (d2[:, 0] - d2[:, 3])[steps]
+    print(f"   requant wave, top of the step: arrivals + copies {a0.mean():.0f}, big-value pre-pass {a1.mean():.0f}, prefetch issue + gains {a2.mean():.0f} cycles")
+    a = (d2[:, 0] - t[1, :, 0])[steps]
+    b = (d2[:, 1] - d2[:, 0])[steps]
+    c = (t[1, :, 1] - d2[:, 1])[steps]
+    print(f"   requant wave: units + gains {a.mean():.0f}, three rounds {b.mean():.0f}, special cases {c.mean():.0f} cycles")

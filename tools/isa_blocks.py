@@ -9,7 +9,7 @@ import sys
 def main():
     path, key = sys.argv[1], sys.argv[2]
     lines = open(path).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and key in l and ":" in l)
+    start = next(i for i, l in enumerate(lines) if (l.startswith("_Z") or l.startswith(key)) and key in l and ":" in l)
     end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
     blocks = []
     blk = None
