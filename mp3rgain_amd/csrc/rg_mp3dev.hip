@@ -196,6 +196,10 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         // This wave is the pipeline's longest stage, and a wave issues at most one instruction in four cycles: its length is
         // its instruction count.  The body is compiled once per channel count, so that nothing in it asks how many channels
         // there are.
+#ifndef RG_BH_NO_PRIO
+        // the block's step is as long as this wave's: where it shares a SIMD with the other blocks' lighter waves it goes first
+        __builtin_amdgcn_s_setprio(3);
+#endif
         auto requant_wave = [&](auto nch_c) {
         constexpr int nch = decltype(nch_c)::value;
         constexpr int kRounds = 3;
@@ -288,12 +292,14 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                 for (int r = 0; r < kRounds; ++r) { raw[r][0] = rq_next[r][0]; raw[r][1] = rq_next[r][1]; }
                 // The lines from a unit's nz on are zero and the Huffman stage does not write them (it completes the
                 // 16-byte piece the last value falls into): what was fetched from there is replaced by zeros.
+                int nz8_max = 0;  // lines from here on are zero in every channel
 #pragma unroll
                 for (int c = 0; c < nch; ++c) {
                     const int nz8 = ((int)(h[c][0] & 0xFFFFu) + 7) & ~7;
+                    nz8_max = nz8 > nz8_max ? nz8 : nz8_max;
 #pragma unroll
                     for (int r = 0; r < kRounds; ++r)
-                        if (4 * (lane + 64 * r) >= nz8) raw[r][c] = make_uint2(0u, 0u);
+                        if (nz8 < 256 * (r + 1) && 4 * (lane + 64 * r) >= nz8) raw[r][c] = make_uint2(0u, 0u);  // the first test is the wave's
                 }
                 RG_BH_STAMP2(k, 2);
                 // Order matters from here to the end of the step.  Everything this step needs from memory has arrived; the
@@ -303,23 +309,26 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                 // step -- a quantised value beyond the LDS part of the x^(4/3) table takes its power from the full table in
                 // memory -- therefore happens HERE, before the prefetch, and the power waits in the line's own place in the
                 // output buffer (which nobody else touches before this step's barrier).
+                bool big_r[kRounds];  // the wave's: some lane of round r holds such a value
                 {
-                    rg_u16x2 amax_r[kRounds], amax2 = {0, 0};
+                    bool any_big = false;
 #pragma unroll
                     for (int r = 0; r < kRounds; ++r) {
-                        amax_r[r] = rg_u16x2{0, 0};
+                        rg_u16x2 amax = {0, 0};
+                        if (nz8_max > 256 * r) {
 #pragma unroll
-                        for (int c = 0; c < nch; ++c) {
-                            amax_r[r] = __builtin_elementwise_max(amax_r[r], __builtin_bit_cast(rg_u16x2, __builtin_elementwise_abs(__builtin_bit_cast(rg_s16x2, raw[r][c].x))));
-                            amax_r[r] = __builtin_elementwise_max(amax_r[r], __builtin_bit_cast(rg_u16x2, __builtin_elementwise_abs(__builtin_bit_cast(rg_s16x2, raw[r][c].y))));
+                            for (int c = 0; c < nch; ++c) {
+                                amax = __builtin_elementwise_max(amax, __builtin_bit_cast(rg_u16x2, __builtin_elementwise_abs(__builtin_bit_cast(rg_s16x2, raw[r][c].x))));
+                                amax = __builtin_elementwise_max(amax, __builtin_bit_cast(rg_u16x2, __builtin_elementwise_abs(__builtin_bit_cast(rg_s16x2, raw[r][c].y))));
+                            }
                         }
-                        amax2 = __builtin_elementwise_max(amax2, amax_r[r]);
+                        big_r[r] = __builtin_amdgcn_ballot_w64((amax.x > amax.y ? amax.x : amax.y) >= kPowLds) != 0;
+                        any_big = any_big || big_r[r];
                     }
-                    if (__builtin_amdgcn_ballot_w64((amax2.x > amax2.y ? amax2.x : amax2.y) >= kPowLds) != 0) {
+                    if (any_big) {
 #pragma unroll
                         for (int r = 0; r < kRounds; ++r) {
-                            // a round without such a value (the usual case even here) costs no trip to memory
-                            if (__builtin_amdgcn_ballot_w64((amax_r[r].x > amax_r[r].y ? amax_r[r].x : amax_r[r].y) >= kPowLds) == 0) continue;
+                            if (!big_r[r]) continue;  // a round without such a value (the usual case even here) costs no trip to memory
                             float big[2][4];
 #pragma unroll
                             for (int c = 0; c < nch; ++c) {
@@ -396,8 +405,14 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                 for (int r = 0; r < kRounds; ++r) {
                     const int piece = lane + 64 * r;
                     const int rq_l0 = 4 * (piece < 144 ? piece : 143);
+                    if (nz8_max <= 256 * r) {  // the whole round lies behind the last value of every channel: zeros (mid/side of zeros included)
+                        if (piece < 144) {
+#pragma unroll
+                            for (int c = 0; c < nch; ++c) *reinterpret_cast<float4 *>(&XP[c][4 * piece]) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        }
+                        continue;
+                    }
                     float gv[2][4], mg[2][4];
-                    rg_u16x2 amax2 = {0, 0};
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
                         if (c >= nch) continue;
@@ -418,14 +433,13 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const rg_u16x2 ua = __builtin_bit_cast(rg_u16x2, __builtin_elementwise_abs(__builtin_bit_cast(rg_s16x2, w[h])));
-                            amax2 = __builtin_elementwise_max(amax2, ua);
                             const rg_u16x2 top = {(unsigned short)(kPowLds - 1), (unsigned short)(kPowLds - 1)};
                             const rg_u16x2 ci = __builtin_elementwise_min(ua, top);
                             mg[c][2 * h] = pow_l[ci.x];
                             mg[c][2 * h + 1] = pow_l[ci.y];
                         }
                     }
-                    if ((amax2.x > amax2.y ? amax2.x : amax2.y) >= kPowLds) {  // rare: a value beyond the LDS part of the table
+                    if (big_r[r]) {  // rare: a value beyond the LDS part of the table
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
                             if (c >= nch) continue;
@@ -479,7 +493,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                     }
                 }
                 RG_BH_STAMP2(k, 1);
-                const bool special = (nch == 2 && (UP[0].mode_ext & 1)) || UP[0].block_type == 2 || (nch == 2 && UP[1].block_type == 2);
+                const bool special = (nch == 2 && (h[0][3] & 1u)) || (h[0][0] >> 24) == 2u || (nch == 2 && (h[1][0] >> 24) == 2u);
                 if (special) {
                     wave_sync();
                     if (nch == 2 && (UP[0].mode_ext & 1)) {
@@ -609,6 +623,9 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         // ================= wave 0: lane (channel, subband): spectrum -> subband samples of eighteen time slots =========
         const bool active = lane < 32 * nch;
         const int my_c = lane >> 5, my_sb = lane & 31;
+#ifdef RG_BH_PRIO_IMDCT
+        __builtin_amdgcn_s_setprio(RG_BH_PRIO_IMDCT);
+#endif
         rg_lds_barrier();
         for (int k = 0; k <= nsteps + 2; ++k) {
             RG_BH_STAMP(0, k, 0);
@@ -696,6 +713,9 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         // ================= wave 2: matrixing, lane (channel, time slot): the 32-point DCT (rg_mp3dec.cpp: synth) =======
         const int c = lane >> 5, t = lane & 31;
         const bool active = t < 18 && c < nch;
+#ifdef RG_BH_PRIO_DCT
+        __builtin_amdgcn_s_setprio(RG_BH_PRIO_DCT);
+#endif
         rg_lds_barrier();
         for (int k = 0; k <= nsteps + 2; ++k) {
             RG_BH_STAMP(2, k, 0);
