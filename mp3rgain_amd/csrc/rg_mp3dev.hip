@@ -247,21 +247,21 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         // is fixed, the unit's share is a scalar
         uint32_t rq_off[kRounds];  // bytes from the unit's first piece to this lane's four lines
 #pragma unroll
-        for (int r = 0; r < kRounds; ++r) rq_off[r] = ((uint32_t)((lane + 64 * r) >> 1) << (is_group_log2 + 4)) + 8u * ((lane + 64 * r) & 1);
-        const uint8_t *const is_bytes = reinterpret_cast<const uint8_t *>(is);
-        auto fetch_spectra = [&](const int step) {
+        for (int r = 0; r < kRounds; ++r) {  // the third round's idle lanes read its last piece again: no branch around a load
+            const uint32_t piece = (uint32_t)(lane + 64 * r < 144 ? lane + 64 * r : 143);
+            rq_off[r] = ((piece >> 1) << (is_group_log2 + 4)) + 8u * (piece & 1u);
+        }
+        // the block's spectra start at the group its first unit lies in; from there 32-bit offsets do (a run is 68 units)
+        const uint32_t group_mask = (1u << is_group_log2) - 1u;
+        const uint32_t u_in_group0 = (uint32_t)(ubase & group_mask);
+        const uint8_t *const is_block = reinterpret_cast<const uint8_t *>(is) + (ubase >> is_group_log2) * ((uint64_t)(72 * 16) << is_group_log2);
+        auto fetch_spectra = [&](const int step) {  // every load of it is issued whatever the step: the compiler can count them
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                if (c >= nch) continue;
-                const uint64_t U = ubase + (uint64_t)step * nch + c;
-                const uint8_t *const row = is_bytes + rg_mp3_is_index(U, 0, is_group_log2) * 16;
+            for (int c = 0; c < nch; ++c) {
+                const uint32_t ul = u_in_group0 + (uint32_t)step * nch + c;
+                const uint8_t *const row = is_block + ((((ul >> is_group_log2) * 72u) << is_group_log2) + (ul & group_mask)) * 16u;
 #pragma unroll
-                for (int r = 0; r < kRounds; ++r)
-#ifdef RG_BH_EXP_LOADS  // timing experiment only (wrong results): every step reads the same few coalesced lines
-                    if (lane + 64 * r < 144) rq_next[r][c] = *reinterpret_cast<const uint2 *>(is_bytes + 8 * (lane + 64 * r) + 0 * (row - is_bytes));
-#else
-                    if (lane + 64 * r < 144) rq_next[r][c] = *reinterpret_cast<const uint2 *>(row + rq_off[r]);
-#endif
+                for (int r = 0; r < kRounds; ++r) rq_next[r][c] = *reinterpret_cast<const uint2 *>(row + rq_off[r]);
             }
         };
         auto wave_sync = [] {  // LDS hand-over between lanes of this wave
@@ -282,10 +282,9 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) h[c][i] = h_next[c][i];
-                if (k + 1 < nsteps) {
-                    if (uq) reinterpret_cast<uint4 *>(&Ub[(k + 1) % 3][0])[uq_t] = u_reg;
-                    header_of(u_reg, h_next);
-                }
+                // (past the run's last granule the same units and spectra are asked for again and never used)
+                if (uq) reinterpret_cast<uint4 *>(&Ub[(k + 1) % 3][0])[uq_t] = u_reg;
+                header_of(u_reg, h_next);
                 // ---- stage B: requantisation (rg_mp3dec.cpp: requantize)
                 uint2 raw[kRounds][2];
 #pragma unroll
@@ -358,8 +357,8 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                     }
                 }
                 RG_BH_STAMP2(k, 3);
-                if (uq && k + 2 < nsteps) u_reg = reinterpret_cast<const uint4 *>(units + ubase + (uint64_t)(k + 2) * nch)[uq_t];
-                if (k + 1 < nsteps) fetch_spectra(k + 1);
+                if (uq) u_reg = reinterpret_cast<const uint4 *>(units + ubase + (uint64_t)(k + 2 < nsteps ? k + 2 : nsteps - 1) * nch)[uq_t];
+                fetch_spectra(k + 1 < nsteps ? k + 1 : nsteps - 1);
                 int bt_s[2] = {0, 0}, ll_s[2] = {0, 0}, so_s[2] = {0, 0};
                 int gq_idx[2] = {0, 0};
                 uint32_t gq_sf[2] = {0u, 0u};
