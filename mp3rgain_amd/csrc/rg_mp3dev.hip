@@ -958,6 +958,14 @@ struct RowOut {
 
 }  // namespace
 
+#ifdef RG_HF_TIMING
+// Instrument (tools/bh_timing.py --huffman): shader-clock stamps of the eight waves of block RG_HF_TIMING at the kernel's phases
+__device__ unsigned long long rg_hf_dbg[8][8];
+extern "C" int rg_hf_dbg_read(void *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rg_hf_dbg), sizeof(unsigned long long) * 64); }
+#define RG_HF_STAMP(e) do { if (blockIdx.x == RG_HF_TIMING && (threadIdx.x & 63) == 0) rg_hf_dbg[threadIdx.x >> 6][e] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RG_HF_STAMP(e) do { } while (0)
+#endif
 __global__ void __launch_bounds__(kHuffThreads)
 rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *__restrict__ H,
                       const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks, const RgMp3HuffRec *__restrict__ recs,
@@ -967,11 +975,13 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
     __shared__ uint8_t t_pbits[32], t_linbits[32], quadA[64];
     __shared__ uint8_t sf_all[40 * kHuffThreads];
     const int tid = threadIdx.x;
+    RG_HF_STAMP(0);
     const uint32_t n_e = H->n_entries;  // <= RG_MP3_HUFF_LDS_ENTRIES: checked when the tables are uploaded
     for (uint32_t i = tid; i < n_e; i += kHuffThreads) E_all[i] = H->e[i];
     if (tid < 32) { t_base[tid] = H->base[tid]; t_pbits[tid] = H->primary_bits[tid]; t_linbits[tid] = H->linbits[tid]; }
     if (tid < 64) quadA[tid] = H->quadA[tid];
     __syncthreads();
+    RG_HF_STAMP(1);
     const uint64_t u = (uint64_t)blockIdx.x * kHuffThreads + (uint64_t)tid;
     if (u >= total_units) return;
     const uint32_t ti = find_by_unit(tracks, n_tracks, u);
@@ -992,6 +1002,7 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
     }
     b.open(main + tr.main_base, r.bit_off, r.part2_3_length, r.frame_end_bit);
     huff_scalefactors(b, r, tr.lsf != 0, reuse, sf, &illegal, &preflag);
+    RG_HF_STAMP(2);
     // ---- band layout and big_values regions (rg_mp3dec.cpp: parse_side_info, derived part) ----
     int long_end, short_start;
     if (r.block_type == 2) {
@@ -1058,6 +1069,7 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
             line += 2;
         }
     }
+    RG_HF_STAMP(3);
     while (line <= 572 && b.pos < b.end) {
         const uint32_t win = b.window();
         int v, used;
@@ -1084,6 +1096,7 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
         out.put(line + 2, ((uint32_t)q4[2] & 0xFFFFu) | ((uint32_t)q4[3] << 16));
         line += 4;
     }
+    RG_HF_STAMP(4);
     const int nz = line;
     out.finish(line);
     // ---- the unit ----
@@ -1104,6 +1117,7 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
     o.intensity_scale = r.intensity_scale;
     o.reserved[0] = o.reserved[1] = 0;
     units[u] = o;
+    RG_HF_STAMP(5);
 }
 
 // Tuning key 6 = 3: the frame parser.  The host's walk leaves one slot per frame (header + side information,

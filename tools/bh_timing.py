@@ -20,6 +20,7 @@ import mp3rgain_amd as rg  # noqa: E402
 from mp3rgain_amd import _capi, mp3dec  # noqa: E402
 
 lib = _capi.load()
+HUFFMAN = "--huffman" in sys.argv  # a library built with -DRG_HF_TIMING=<block>: the Huffman kernel's phases per wave
 an = rg.Analyzer(0)
 names = {0: "imdct", 1: "requant", 2: "dct32", 3: "window"}
 for label, src in (("dense320_synthetic", ROOT / "tests/golden/mp3/v1_44k_stereo_long.mp3"),
@@ -35,6 +36,17 @@ for label, src in (("dense320_synthetic", ROOT / "tests/golden/mp3/v1_44k_stereo
     units_per = si.audio_frames * (2 if si.mpeg_version == 1 else 1) * si.channels
     copies = max(1, round((1 << 18) / units_per))
     r = an.decode_mp3_bench(stream, copies, reps=3)
+    if HUFFMAN:
+        hb = np.zeros((8, 8), dtype=np.uint64)
+        assert lib.rg_hf_dbg_read(C.c_void_p(hb.ctypes.data)) == 0
+        hb = hb.astype(np.int64)
+        t0 = hb[:, 0].min()
+        print(f"== {label}: huffman {r['ms']['huffman'] * (1 << 18) / r['units']:.3f} ms per 256K units; cycles from the block's first stamp")
+        print("   wave: tables in LDS | scalefactors | big_values | count1 | finish + unit  (phase lengths)   end")
+        for w in range(8):
+            d = np.diff(hb[w, :6])
+            print(f"   {w}: " + " ".join(f"{int(x):7d}" for x in d) + f"   {int(hb[w, 5] - t0):8d}")
+        continue
     buf = np.zeros((4, 40, 2), dtype=np.uint64)
     assert lib.rg_bh_dbg_read(C.c_void_p(buf.ctypes.data)) == 0
     t = buf.astype(np.int64)
