@@ -107,7 +107,8 @@ struct DevBits {
 // samples need the first one's overlap, and its DCT rows are the filterbank's history).  Each wave runs its own loop, so
 // the register file is sized for the largest stage, not for their sum: 128 VGPRs, 40 KB of LDS, four blocks per CU.
 // (Rounds 2 and 3 had two kernels with the subband samples in memory between them -- 4.6 KB of traffic per granule and
-// channel, the fifteen slots of history transformed again by every block, 0.60 ms per 256 K units against 0.46 now; a
+// channel, the fifteen slots of history transformed again by every block, 0.60 ms per 256 K units against 0.46 for the first version of this kernel and 0.35 now (what the per-wave
+// clock stamps of RG_BH_TIMING showed); a
 // first fused kernel in round 2, six waves stepping through barrier-separated phases together, had lost to them.)
 
 // The block's barrier between pipeline steps.  What the waves hand each other is in LDS, so only LDS traffic has to be
