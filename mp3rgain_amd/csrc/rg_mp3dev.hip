@@ -942,6 +942,7 @@ __device__ __forceinline__ void huff_scalefactors(BitCache &b, const RgMp3HuffRe
 struct RowOut {
     uint4 *__restrict__ row;  // the unit's first piece; its 72 pieces are 2^RG_MP3_IS_GROUP_LOG2 pieces apart
     uint32_t a, b, c;
+#ifdef RG_HF_OLD_PUT
     __device__ __forceinline__ void put(int line, uint32_t word) {  // `line` even; words arrive in order
         switch ((line >> 1) & 3) {
             case 0: a = word; break;
@@ -950,6 +951,17 @@ struct RowOut {
             default: row[(line >> 3) << RG_MP3_IS_GROUP_LOG2] = make_uint4(a, b, c, word); break;
         }
     }
+#else
+    // `line` even; words arrive in order, one per pair of lines, from line 0 on.  The last three wait in a shift register: no
+    // choice of a slot per word (three branches per call in a loop whose lanes sit at different lines), the fourth word of a
+    // piece finds the other three in place.
+    __device__ __forceinline__ void put(int line, uint32_t word) {
+        if (((line >> 1) & 3) == 3) row[(line >> 3) << RG_MP3_IS_GROUP_LOG2] = make_uint4(a, b, c, word);
+        a = b;
+        b = c;
+        c = word;
+    }
+#endif
     // zeros from `line` (even) to the end of its 16-byte piece; the pieces behind it stay unwritten: the back half does not
     // read past the unit's nz (rounded up to a piece)
     __device__ __forceinline__ void finish(int line) {
@@ -1050,8 +1062,13 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
                 used += (int)(e & 0xFF);
                 int x = (int)((e >> 12) & 15), y = (int)((e >> 8) & 15);
                 if (linbits == 0 || (x != 15 && y != 15)) {
-                    if (x) { if ((win << used) >> 31) x = -x; ++used; }
-                    if (y) { if ((win << used) >> 31) y = -y; ++used; }
+                    // a sign bit follows each non-zero value: selects, no branches (a code is at most 19 bits long)
+                    const int nx = x != 0;
+                    x = (((win << used) >> 31) & (uint32_t)nx) ? -x : x;
+                    used += nx;
+                    const int ny = y != 0;
+                    y = (((win << used) >> 31) & (uint32_t)ny) ? -y : y;
+                    used += ny;
                     b.skip(used);
                 } else {
                     b.skip(used);
@@ -1084,12 +1101,10 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
         }
         int q4[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            q4[k] = (v >> (3 - k)) & 1;
-            if (q4[k]) {
-                if ((win << used) >> 31) q4[k] = -1;
-                ++used;
-            }
+        for (int k = 0; k < 4; ++k) {  // 0, or +-1 with the sign in the next bit of the stream: no branches
+            const int bit = (v >> (3 - k)) & 1;
+            q4[k] = bit - 2 * (bit & (int)((win << used) >> 31));
+            used += bit;
         }
         b.skip(used);
         if (b.pos > b.end) break;  // the quadruple ran past the granule's bits: stuffing, not data
