@@ -197,10 +197,9 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         // This wave is the pipeline's longest stage, and a wave issues at most one instruction in four cycles: its length is
         // its instruction count.  The body is compiled once per channel count, so that nothing in it asks how many channels
         // there are.
-#ifndef RG_BH_NO_PRIO
         // the block's step is as long as this wave's: where it shares a SIMD with the other blocks' lighter waves it goes first
+        // (priorities for the other stages as well were slower)
         __builtin_amdgcn_s_setprio(3);
-#endif
         auto requant_wave = [&](auto nch_c) {
         constexpr int nch = decltype(nch_c)::value;
         constexpr int kRounds = 3;
@@ -623,9 +622,6 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         // ================= wave 0: lane (channel, subband): spectrum -> subband samples of eighteen time slots =========
         const bool active = lane < 32 * nch;
         const int my_c = lane >> 5, my_sb = lane & 31;
-#ifdef RG_BH_PRIO_IMDCT
-        __builtin_amdgcn_s_setprio(RG_BH_PRIO_IMDCT);
-#endif
         rg_lds_barrier();
         for (int k = 0; k <= nsteps + 2; ++k) {
             RG_BH_STAMP(0, k, 0);
@@ -713,9 +709,6 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         // ================= wave 2: matrixing, lane (channel, time slot): the 32-point DCT (rg_mp3dec.cpp: synth) =======
         const int c = lane >> 5, t = lane & 31;
         const bool active = t < 18 && c < nch;
-#ifdef RG_BH_PRIO_DCT
-        __builtin_amdgcn_s_setprio(RG_BH_PRIO_DCT);
-#endif
         rg_lds_barrier();
         for (int k = 0; k <= nsteps + 2; ++k) {
             RG_BH_STAMP(2, k, 0);
@@ -942,16 +935,6 @@ __device__ __forceinline__ void huff_scalefactors(BitCache &b, const RgMp3HuffRe
 struct RowOut {
     uint4 *__restrict__ row;  // the unit's first piece; its 72 pieces are 2^RG_MP3_IS_GROUP_LOG2 pieces apart
     uint32_t a, b, c;
-#ifdef RG_HF_OLD_PUT
-    __device__ __forceinline__ void put(int line, uint32_t word) {  // `line` even; words arrive in order
-        switch ((line >> 1) & 3) {
-            case 0: a = word; break;
-            case 1: b = word; break;
-            case 2: c = word; break;
-            default: row[(line >> 3) << RG_MP3_IS_GROUP_LOG2] = make_uint4(a, b, c, word); break;
-        }
-    }
-#else
     // `line` even; words arrive in order, one per pair of lines, from line 0 on.  The last three wait in a shift register: no
     // choice of a slot per word (three branches per call in a loop whose lanes sit at different lines), the fourth word of a
     // piece finds the other three in place.
@@ -961,7 +944,6 @@ struct RowOut {
         b = c;
         c = word;
     }
-#endif
     // zeros from `line` (even) to the end of its 16-byte piece; the pieces behind it stay unwritten: the back half does not
     // read past the unit's nz (rounded up to a piece)
     __device__ __forceinline__ void finish(int line) {
