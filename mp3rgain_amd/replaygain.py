@@ -375,8 +375,8 @@ class Analyzer:
         import torch.distributed as dist
 
         lib = library or os.environ.get("MP3RGAIN_AMD_RCCL_LIBRARY") or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        if os.path.exists(lib):
-            self._check(self._lib.rg_comm_library(os.fsencode(lib)))
+        lib_rc = self._lib.rg_comm_library(os.fsencode(lib)) if os.path.exists(lib) else 0
+        explicit = bool(library or os.environ.get("MP3RGAIN_AMD_RCCL_LIBRARY"))
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         src = dist.get_global_rank(group, 0) if group is not None else 0
         uid = b""
@@ -389,10 +389,13 @@ class Analyzer:
         if not box[0]:
             raise ReplayGainError(-7, "ncclGetUniqueId failed on rank 0 (librccl.so not found?)")
         err = None
-        try:
-            self.comm_init(box[0], world, rank)
-        except ReplayGainError as ex:
-            err = ex
+        if explicit and lib_rc != 0:  # a library that was asked for by name and cannot be loaded: agreed on below, like any other failure
+            err = ReplayGainError(int(lib_rc), f"cannot load {lib}")
+        else:
+            try:
+                self.comm_init(box[0], world, rank)
+            except ReplayGainError as ex:
+                err = ex
         flags = [None] * world
         dist.all_gather_object(flags, err is None, group=group)
         if not all(flags):
