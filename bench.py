@@ -239,7 +239,9 @@ def node_main(args) -> int:
         raise SystemExit(f"bench.py --node --gpus {n_dev}: {torch.cuda.device_count()} device(s) visible; there is no CPU path")
     dev_of = [i % torch.cuda.device_count() for i in range(n_dev)] if rehearsal else list(range(n_dev))
     if rehearsal:
-        _capi.load().rg_comm_library(os.fsencode(os.environ["MP3RGAIN_AMD_RCCL_LIBRARY"]))
+        standin = os.environ.get("MP3RGAIN_AMD_RCCL_LIBRARY")
+        if not standin or _capi.load().rg_comm_library(os.fsencode(standin)) != 0:
+            raise SystemExit("RG_BENCH_REHEARSAL=1 needs MP3RGAIN_AMD_RCCL_LIBRARY=<tests/standin_rccl/librccl_standin.so>")
     frames = int(round(args.minutes * 60 * RATE))
     node = rg.Node(dev_of)
     node.set_exchange(rg.Node.EXCHANGE_RCCL)  # one communicator per device, built in this process
