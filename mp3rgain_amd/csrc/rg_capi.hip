@@ -266,6 +266,10 @@ extern "C" void rg_destroy(rg_ctx *c) {
     c->d_mp3_stage[1].release();
     c->d_mp3_results.release();
     c->d_mp3_tiles.release();
+    for (int k = 0; k < 2; ++k) {
+        c->d_mp3_recs_set[k].release();
+        c->d_mp3_tiles_set[k].release();
+    }
     c->h_mp3_results.release();
     if (c->mp3_copy_stream) (void)hipStreamDestroy(c->mp3_copy_stream);
     for (int k = 0; k < 2; ++k)

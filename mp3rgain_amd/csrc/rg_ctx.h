@@ -151,6 +151,10 @@ struct rg_ctx {
     bool mp3_set_used[2] = {false, false};
     DevBuf<uint32_t> d_mp3_results;
     DevBuf<uint32_t> d_mp3_tiles;            // frame parser: per tile, granule-channels found and their prefix
+    // The frame parser of chunk k + 1 runs on the copy stream, behind its staging block's H2D and beside the Huffman / back-half
+    // kernels of chunk k: what it writes (records, tile sums) is per staging set.
+    DevBuf<unsigned char> d_mp3_recs_set[2];
+    DevBuf<uint32_t> d_mp3_tiles_set[2];
     PinnedBuf<uint32_t> h_mp3_results;
     hipEvent_t *mp3_bench_ev = nullptr;      // rg_mp3_decode_bench: four events recorded around the three decode stages of a chunk
     void *mp3_pipe = nullptr;                // rg_files.hip: pinned staging blocks of the loader pipeline
