@@ -644,6 +644,12 @@ bool needs_exact_pass(rg_ctx *c, const rg_track_result *res, size_t n) {
     if (!any) c->force_exact.clear();
     return any;
 }
+struct OneShot {  // scope of a synchronous entry point's enqueue (rg_ctx.h: one_shot)
+    rg_ctx *c;
+    bool was;
+    explicit OneShot(rg_ctx *ctx) : c(ctx), was(ctx->one_shot) { c->one_shot = true; }
+    ~OneShot() { c->one_shot = was; }
+};
 struct ExactPass {  // scope of the repeat: the per-track routing mask is dropped afterwards
     rg_ctx *c;
     explicit ExactPass(rg_ctx *ctx) : c(ctx) {}
@@ -796,6 +802,7 @@ extern "C" int rg_analyze_pcm_batch(rg_ctx *c, const rg_track_desc *tracks, size
     const void *d_base = nullptr;
     int rc = stage_pcm(c, pcm_base, pcm_bytes, on_device, &d_base);
     if (rc != RG_OK) return rc;
+    OneShot one(c);
     rc = rg_enqueue_impl(c, tracks, n, d_base, pcm_bytes, 0);
     if (rc != RG_OK) return rc;
     rc = rg_collect(c, out, hist_out);
@@ -830,6 +837,7 @@ int rg_album_local_pcm(rg_ctx *c, const rg_track_desc *tracks, size_t n, const v
     const void *d_base = nullptr;
     int rc = stage_pcm(c, pcm_base, pcm_bytes, on_device, &d_base);
     if (rc != RG_OK) return rc;
+    OneShot one(c);
     rc = rg_enqueue_impl(c, tracks, n, d_base, pcm_bytes, 1);
     if (rc != RG_OK) return rc;
     std::vector<rg_track_result> probe;
@@ -858,6 +866,7 @@ int rg_album_part(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *
         if (rc != RG_OK) return rc;
         RG_HIP(c, c->d_album_packs.reserve(parts * (size_t)RG_ALBUM_PACK_WORDS));
     }
+    OneShot one(c);
     int rc = rg_enqueue_impl(c, tracks, n, d_base, bytes, 1);
     if (rc != RG_OK) return rc;
     rc = rg_collect(c, out, nullptr);

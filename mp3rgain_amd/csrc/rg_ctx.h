@@ -178,6 +178,7 @@ struct rg_ctx {
     DevBuf<unsigned char> d_wav;             // interleaved WAV samples awaiting de-interleave (rg_files.hip)
     std::string decoder_cmd;                 // rg_set_decoder_command
     std::vector<unsigned char> force_exact;  // per track of the next enqueue: 1 = use variant 1 (exact repeat of flagged tracks)
+    bool one_shot = false;  // the enqueue is a synchronous entry point's: ONE batch in flight, not one per pipeline stream (cost model)
     void *comm = nullptr;                    // ncclComm_t of rg_comm_init (owned)
     int comm_world = 1;
 

@@ -237,7 +237,10 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
         double lanes = 0;
         for (uint32_t id : g.ids) lanes += (double)((tracks[id].frames + stride - 1) / stride) * g.nch;
         double waves = ceil(lanes / block) * (block / 64);  // blocks run through track boundaries: no per-track padding
-        waves *= c->n_slots < RG_SLOT_STREAMS ? c->n_slots : RG_SLOT_STREAMS;  // batches in flight = streams
+        // batches in flight = streams when the caller pipelines (rg_enqueue_* / rg_collect); a synchronous entry point has one:
+        // its launch's last, ragged round of blocks is not filled by a neighbour, so the windows per lane are chosen to make
+        // the rounds come out even (256 three-minute tracks: m = 8 is 300 blocks = two rounds on 256 CUs, m = 10 is 240 = one)
+        if (!c->one_shot) waves *= c->n_slots < RG_SLOT_STREAMS ? c->n_slots : RG_SLOT_STREAMS;
         const double cost = (double)stride * 28.0 + (double)L * 2.0 + (double)std::min(L, H10) * 10.0 + 1500.0 + 1500.0 + 60.0 * (m - 1);
         // residency: the LDS image of the response tables + one 4 KiB tile per wave bound the blocks per CU
         const double lds = (double)rg_tm_lds_bytes(L, Hl, block);
@@ -245,9 +248,16 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
         // waves per SIMD that can be resident: three narrow blocks, or one wide block, per CU
         const double blocks_cu = block == RG_TM_BLOCK ? std::max(1.0, std::min(3.0, floor((double)RG_TM_LDS_BYTES / lds))) : (double)block / 256.0;
         const double cap = 1024.0 * blocks_cu;
-        const double rounds = waves <= cap ? ceil(waves / 1024.0) : waves / 1024.0 + 1.0;
+        double rounds = waves <= cap ? ceil(waves / 1024.0) : waves / 1024.0 + 1.0;
+        if (c->one_shot) {
+            // one batch in flight: nothing fills its last round, and a block is indivisible -- the busiest CU runs
+            // ceil(blocks / 256) of them, each block / 256 waves per SIMD deep (tools/oneshot_sweep.py: 256 three-minute tracks
+            // take 5.1 ms at m = 5 or 10, 7.9 ms at m = 8, in step with this count)
+            const double blocks = ceil(lanes / block);
+            rounds = ceil(blocks / 256.0) * ((double)block / 256.0);
+        }
         // FP64 issue efficiency by waves per SIMD (tools/ubench/frame.hip: 188 / 160 / 147 cycles per frame)
-        const double wps = std::min(blocks_cu, std::max(1.0, waves / 1024.0));
+        const double wps = std::min(blocks_cu, std::max(1.0, c->one_shot ? rounds : waves / 1024.0));
         const double eff = wps >= 3.0 ? 1.0 : (wps >= 2.0 ? 1.09 + (3.0 - wps) * 0.0 : 1.28 - (wps - 1.0) * 0.19);
         // tables that do not fit a CU's LDS (160 KiB) send the whole launch down the generic path
         // rounds * cost covers every lane of the batch whatever the segment stride is, so candidates compare on it directly
