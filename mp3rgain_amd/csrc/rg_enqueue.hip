@@ -270,7 +270,13 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
     std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return score[a] < score[b]; });
     (void)best_i;
     for (size_t i : order)
-        if (get_tm_tables(c, g.rate_idx, cand[i].L, out, cand[i].m) == RG_OK) return RG_OK;
+        if (get_tm_tables(c, g.rate_idx, cand[i].L, out, cand[i].m) == RG_OK) {
+            if (getenv("RG_TRACE_TM"))
+                fprintf(stderr, "[tm] %zu track(s) at %u Hz, %s: L = %u, m = %u (score %.3g; runner-up L = %u, m = %u: %.3g)\n", g.ids.size(),
+                        RG_RATE_TABLE[g.rate_idx].sample_rate, c->one_shot ? "one batch in flight" : "pipelined", cand[i].L, cand[i].m, score[i],
+                        cand[order.size() > 1 ? order[1] : i].L, cand[order.size() > 1 ? order[1] : i].m, score[order.size() > 1 ? order[1] : i]);
+            return RG_OK;
+        }
     return rg_set_err(c, RG_ERR_INVALID_ARG, "no admissible segment length for %u Hz",
                       RG_RATE_TABLE[g.rate_idx].sample_rate);
 }
