@@ -130,6 +130,8 @@ struct rg_ctx {
     DevBuf<RgCoefDev> d_coefs;
     std::map<uint32_t, RgTmDeviceTables *> tm_tables;  // key = rate_idx << 24 | m << 16 | L, shared by all slots (read only)
 
+    std::map<uint64_t, std::pair<uint32_t, uint32_t>> tm_choice;  // memo of choose_tm_tables: batch-shape signature -> (L, m)
+
     // host scratch for building one batch's descriptors
     std::vector<RgTrackDev> h_tracks, h_k1_tracks;
     std::vector<RgTmTrack> h_tm_tracks;

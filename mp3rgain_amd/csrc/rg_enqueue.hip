@@ -189,6 +189,17 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
         const uint32_t m = c->tune_tm_segment == W && c->tune_tm_windows > 1 ? c->tune_tm_windows : 1;
         if (get_tm_tables(c, g.rate_idx, c->tune_tm_segment, out, m) == RG_OK) return RG_OK;
     }
+    // The choice depends on the group's track lengths alone (and on the mode): remember it, so that a caller that enqueues
+    // the same batch shape again and again does not pay for the candidate sweep (about 270 candidates x tracks) every time.
+    uint64_t sig = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { sig = (sig ^ v) * 1099511628211ull; };
+    mix((uint64_t)g.rate_idx); mix((uint64_t)g.fmt); mix((uint64_t)g.nch); mix(c->one_shot ? 1 : 0); mix((uint64_t)c->n_slots);
+    mix(c->tune_tm_windows); mix(c->tune_tm_target_lanes);
+    for (uint32_t id : g.ids) mix(tracks[id].frames);
+    {
+        auto it = c->tm_choice.find(sig);
+        if (it != c->tm_choice.end() && get_tm_tables(c, g.rate_idx, it->second.first, out, it->second.second) == RG_OK) return RG_OK;
+    }
     // candidates: (L, 1) for every divisor L of the window, and (W, m) -- a lane runs m whole windows and pays for the
     // transient moments in the first one only (rg_tm.h)
     struct Cand { uint32_t L, m; };
@@ -197,8 +208,14 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
         if (W % d == 0 && (d >= kMinSegment || d == W)) cand.push_back(Cand{d, 1});
     if (c->tune_tm_windows != 1) {
         // every m is legal (a track's last segment simply holds fewer windows); which one wins is mostly a matter of how
-        // well ceil(windows / m) lanes fill whole blocks of the track
-        const uint32_t m_max = c->tune_tm_windows ? c->tune_tm_windows : 16;
+        // well ceil(windows / m) lanes fill whole blocks and whole rounds of the chip.  Up to round 3 m stopped at 16, and a
+        // 1000-track batch was 4.58 rounds of indivisible 768-lane blocks quantised to 5; with m free, 1000 three-minute
+        // tracks are ONE round (m = 37: 196 000 lanes = 255.2 blocks on 256 CUs).  No lane needs more windows than the
+        // longest track has.
+        uint64_t longest = 1;
+        for (uint32_t id : g.ids) longest = std::max<uint64_t>(longest, (tracks[id].frames + W - 1) / W);
+        const uint32_t m_cap = c->tune_tm_windows ? c->tune_tm_windows : 255;  // the table key holds eight bits of m
+        const uint32_t m_max = (uint32_t)std::min<uint64_t>(m_cap, longest);
         for (uint32_t m = 2; m <= m_max; ++m) cand.push_back(Cand{W, m});
     }
     auto lanes_of = [&](const Cand &q) {
@@ -248,7 +265,11 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
         // waves per SIMD that can be resident: three narrow blocks, or one wide block, per CU
         const double blocks_cu = block == RG_TM_BLOCK ? std::max(1.0, std::min(3.0, floor((double)RG_TM_LDS_BYTES / lds))) : (double)block / 256.0;
         const double cap = 1024.0 * blocks_cu;
-        double rounds = waves <= cap ? ceil(waves / 1024.0) : waves / 1024.0 + 1.0;
+        // pipelined: the ragged last round of a batch is filled by the batches behind it; what is left is the tail of the
+        // whole pipeline, one round shared by the batches in flight (charged in full to every batch until round 3, which
+        // made long lanes look a round of their own length worse than they are)
+        const double in_flight = c->n_slots < RG_SLOT_STREAMS ? c->n_slots : RG_SLOT_STREAMS;
+        double rounds = waves <= cap ? ceil(waves / 1024.0) : waves / 1024.0 + 1.0 / in_flight;
         if (c->one_shot) {
             // one batch in flight: nothing fills its last round, and a block is indivisible -- the busiest CU runs
             // ceil(blocks / 256) of them, each block / 256 waves per SIMD deep (tools/oneshot_sweep.py: 256 three-minute tracks
@@ -275,6 +296,8 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
                 fprintf(stderr, "[tm] %zu track(s) at %u Hz, %s: L = %u, m = %u (score %.3g; runner-up L = %u, m = %u: %.3g)\n", g.ids.size(),
                         RG_RATE_TABLE[g.rate_idx].sample_rate, c->one_shot ? "one batch in flight" : "pipelined", cand[i].L, cand[i].m, score[i],
                         cand[order.size() > 1 ? order[1] : i].L, cand[order.size() > 1 ? order[1] : i].m, score[order.size() > 1 ? order[1] : i]);
+            if (c->tm_choice.size() > 4096) c->tm_choice.clear();
+            c->tm_choice[sig] = std::make_pair(cand[i].L, cand[i].m);
             return RG_OK;
         }
     return rg_set_err(c, RG_ERR_INVALID_ARG, "no admissible segment length for %u Hz",

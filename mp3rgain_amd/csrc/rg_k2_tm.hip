@@ -510,11 +510,17 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
                     }
                     if (!__any(lenw != 0)) break;  // the track ended in an earlier window for every row of this wave
                     st.A[0] = 0.0;
-                    const bool plainw = lenw == L && wstart + ((L + 3u) & ~3u) <= tr.frames;
+                    // A row whose track ended in an earlier window of this lane must not send the whole wave down the masked
+                    // path (with 98 segments of 37 windows per three-minute track two waves in three hold such a row, for 26
+                    // of their 37 windows): it re-reads its track's FIRST window instead -- same track, same channel, so the
+                    // peak does not change; its energy is not stored and its state is never used again.
+                    const bool idle = lenw == 0 && tr.frames >= (uint64_t)((L + 3u) & ~3u);
+                    const bool plainw = idle || (lenw == L && wstart + ((L + 3u) & ~3u) <= tr.frames);
+                    gelem *const rowp = idle ? chp : chp + wstart;
                     if (__all(plainw))
-                        tm_fast_path<FMT, false, false>(st, pk, K, L, H, chp + wstart, lenw, T12, T2, wtile);
+                        tm_fast_path<FMT, false, false>(st, pk, K, L, H, rowp, lenw, T12, T2, wtile);
                     else
-                        tm_fast_path<FMT, true, false>(st, pk, K, L, H, chp + wstart, lenw, T12, T2, wtile);
+                        tm_fast_path<FMT, true, false>(st, pk, K, L, H, rowp, lenw, T12, T2, wtile);
                     note_nonfinite(st.A[0], seg * m + w, lenw != 0);
                     if (lenw != 0) win_energy[(size_t)chan * total_windows + tracks[t].win_base + (size_t)seg * m + w] = st.A[0];
                 }
@@ -628,11 +634,13 @@ rg_tm_plain_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restri
         }
         if (!__any(lenw != 0)) break;  // the track ended in an earlier window for every row of this wave
         st.A[0] = 0.0;
-        const bool plainw = lenw == L && wstart + ((L + 3u) & ~3u) <= tr.frames;
+        const bool idle = lenw == 0 && tr.frames >= (uint64_t)((L + 3u) & ~3u);  // see rg_tm_main_kernel
+        const bool plainw = idle || (lenw == L && wstart + ((L + 3u) & ~3u) <= tr.frames);
+        gelem *const rowp = idle ? chp : chp + wstart;
         if (__all(plainw))
-            tm_fast_path<FMT, false, false>(st, pk, K, L, G.H10, chp + wstart, lenw, nullptr, nullptr, wtile);
+            tm_fast_path<FMT, false, false>(st, pk, K, L, G.H10, rowp, lenw, nullptr, nullptr, wtile);
         else
-            tm_fast_path<FMT, true, false>(st, pk, K, L, G.H10, chp + wstart, lenw, nullptr, nullptr, wtile);
+            tm_fast_path<FMT, true, false>(st, pk, K, L, G.H10, rowp, lenw, nullptr, nullptr, wtile);
         note_nonfinite(st.A[0], seg * m + w, lenw != 0);
         if (lenw != 0) win_energy[(size_t)chan * total_windows + tracks[t].win_base + (size_t)seg * m + w] = st.A[0];
     }

@@ -339,6 +339,21 @@ class Analyzer:
         res = [_to_result(out[i], AudioFileType.Mp3) for i in range(n)]
         return AlbumGainResult(res, alb.album_loudness_db, alb.album_gain_db, alb.album_peak) if album else res
 
+    # -- synchronous, PCM already resident on the device (one blocking call = the reference's API shape) ----
+    def analyze_device(self, descs, n: int, d_pcm_base: int, pcm_bytes: int, want_hist: bool = False, out=None):
+        """rg_analyze_pcm_batch with pcm_on_device = 1: ONE batch in flight, results (exact repeat of flagged tracks
+        included) when the call returns.  With `out` (a ctypes TrackResult array) the raw records are left there and
+        nothing is converted (timing loops)."""
+        if out is not None:
+            self._check(self._lib.rg_analyze_pcm_batch(self._ctx, descs, n, d_pcm_base, pcm_bytes, 1, out, None))
+            return out
+        out = (_capi.TrackResult * max(1, n))()
+        hist = np.zeros((max(1, n), _capi.HISTOGRAM_SIZE), dtype=np.uint32) if want_hist else None
+        self._check(self._lib.rg_analyze_pcm_batch(self._ctx, descs, n, d_pcm_base, pcm_bytes, 1, out,
+                                                   hist.ctypes.data if hist is not None else None))
+        res = [_to_result(out[i], AudioFileType.Mp3) for i in range(n)]
+        return (res, hist[:n]) if want_hist else res
+
     # -- device-resident pipeline --------------------------------------------------------------
     def enqueue_device(self, descs, n: int, d_pcm_base: int, pcm_bytes: int, album: bool = False):
         self._check(self._lib.rg_enqueue_pcm_batch(self._ctx, descs, n, d_pcm_base, pcm_bytes, int(album)))

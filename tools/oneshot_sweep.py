@@ -49,7 +49,7 @@ for _ in range(12):  # every pipeline slot has been through its first use (alloc
     run()
 ref = None
 for label, seg, m in ([("library's choice", 0, 0)] + [(f"L = {L}", L, 1) for L in (245, 441, 735)]
-                     + [(f"W x {m}", 2205, m) for m in (1, 2, 3, 4, 5, 6, 8, 10, 12, 14, 16)]):
+                     + [(f"W x {m}", 2205, m) for m in (1, 2, 4, 5, 8, 10, 12, 14, 16, 20, 24, 30, 36, 37, 38, 40, 45)]):
     an.set_tuning(1, seg)
     an.set_tuning(4, m)
     run()
