@@ -73,10 +73,40 @@ namespace {
 
 typedef long double ld;
 
-// one step of the cascade in transposed direct form II, exactly the kernel's recursion
-// (rg_k2_tm.hip: tm_step), homogeneous part only when x = 0 and c = 0
-void tm_step_ld(const rg_rate_coeffs &rc, ld q[12], ld x, ld c, ld *z_out) {
+// servo constants exactly as the kernel holds them
+struct ServoK {
+    bool on;
+    ld g, alpha, beta;
+};
+ServoK servo_constants(const rg_rate_coeffs &rc) {
+    ServoK k;
+    k.on = rg_tm_servo_ok(rc);
+    k.g = (ld)rc.butter_b[0];
+    k.alpha = (ld)(double)(2.0L + (ld)rc.butter_a[1]);
+    k.beta = (ld)(double)(1.0L + (ld)rc.butter_a[1] + (ld)rc.butter_a[2]);
+    return k;
+}
+
+// one step of the cascade exactly as the kernel runs it (rg_k2_tm.hip: tm_step / tm_frame), homogeneous part only when
+// x = 0 and c = 0.
+//   classic: both stages in transposed direct form II, the reference's +c per stage injected at the deepest state of each
+//   servo:   Yule stage in DF2T with butter b0 folded into its feed-forward taps, Butterworth stage as output minus double
+//            integrator.  With c != 0 this is the EXACT affine system of the reference (used for its fixed point only; the
+//            kernel's lanes are linear): A_b Z = (1 - z^-1)^2 Y' + c U needs z = y' - v1 + c, v1 += v2 + alpha z - 2c,
+//            v2 += beta z - c, and the Yule stage's +c enters its output (times g).
+void tm_step_ld(const rg_rate_coeffs &rc, const ServoK &sv, ld q[12], ld x, ld c, ld *z_out) {
     ld n[12];
+    if (sv.on) {
+        const ld y = (ld)(double)(sv.g * (ld)rc.yule_b[0]) * x + q[0] + sv.g * c;
+        for (int i = 0; i < 9; ++i) n[i] = q[i + 1] + (ld)(double)(sv.g * (ld)rc.yule_b[i + 1]) * x - (ld)rc.yule_a[i + 1] * y;
+        n[9] = (ld)(double)(sv.g * (ld)rc.yule_b[10]) * x - (ld)rc.yule_a[10] * y;
+        const ld z = y - q[10] + c;
+        n[10] = q[10] + q[11] + sv.alpha * z - 2.0L * c;
+        n[11] = q[11] + sv.beta * z - c;
+        memcpy(q, n, sizeof n);
+        *z_out = z;
+        return;
+    }
     const ld y = (ld)rc.yule_b[0] * x + q[0];
     for (int i = 0; i < 9; ++i) n[i] = q[i + 1] + (ld)rc.yule_b[i + 1] * x - (ld)rc.yule_a[i + 1] * y;
     n[9] = (ld)rc.yule_b[10] * x - (ld)rc.yule_a[10] * y + c;
@@ -156,6 +186,10 @@ ld maxabs(const ld *A, int n) {
 
 }  // namespace
 
+bool rg_tm_servo_ok(const rg_rate_coeffs &rc) {
+    return rc.butter_b[1] == -2.0 * rc.butter_b[0] && rc.butter_b[2] == rc.butter_b[0];
+}
+
 void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out, uint32_t m) {
     *out = RgTmDesign();
     const uint32_t W = (uint32_t)(((uint64_t)rc.sample_rate * 50u) / 1000u);
@@ -166,6 +200,11 @@ void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out, uint32_
     if (!rd.stable) return;
     out->L = L;
     out->W = W;
+    const ServoK sv = servo_constants(rc);
+    out->servo = sv.on;
+    out->alpha = (double)sv.alpha;
+    out->beta = (double)sv.beta;
+    out->g = sv.on ? (double)sv.g : 1.0;
 
     // state matrix F (column j = one homogeneous step from unit state j) and output row h
     ld F[12][12], h[12];
@@ -173,7 +212,7 @@ void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out, uint32_
         ld q[12] = {0};
         q[j] = 1.0L;
         ld z;
-        tm_step_ld(rc, q, 0.0L, 0.0L, &z);
+        tm_step_ld(rc, sv, q, 0.0L, 0.0L, &z);
         for (int i = 0; i < 12; ++i) F[i][j] = q[i];
         h[j] = z;
     }
@@ -290,7 +329,9 @@ void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out, uint32_
     // the rounded values too)
     out->T.resize((size_t)L * 12);
     out->Gp.resize((size_t)L * RG_TM_GRAM);
+    if (sv.on) out->ST.resize((size_t)L * 12);
     std::vector<ld> gram(RG_TM_GRAM, 0.0L);
+    ld tsum[12] = {0};
     ld tmax = 0;
     for (uint32_t n = 0; n < L; ++n) {
         for (int j = 0; j < 12; ++j) {
@@ -302,6 +343,11 @@ void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out, uint32_
             for (int k = j; k < 12; ++k, ++p)
                 gram[p] += (ld)out->T[(size_t)n * 12 + j] * (ld)out->T[(size_t)n * 12 + k];
         for (int q = 0; q < RG_TM_GRAM; ++q) out->Gp[(size_t)n * RG_TM_GRAM + q] = (double)gram[q];
+        if (sv.on)
+            for (int j = 0; j < 12; ++j) {
+                tsum[j] += (ld)out->T[(size_t)n * 12 + j];
+                out->ST[(size_t)n * 12 + j] = (double)tsum[j];
+            }
     }
     // H10: first multiple of 4 after which every fast response stays below 1e-13 of its maximum
     uint32_t H10 = 0;
@@ -345,14 +391,48 @@ void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out, uint32_
     out->PhiY.resize((size_t)rounds * 100);
     out->PhiB.resize((size_t)rounds * 4);
 
-    // track-start state: every DF2T state holds the +1e-10 offset once (see rg_tm.h), then t' = t + X s, then the carried
-    // coordinates (the identity below 64 kHz)
+    // track-start state in the kernel's own coordinates
     const ld c = 1e-10L;
+    ld q0[12];
+    if (!sv.on) {
+        // classic: every DF2T state holds the +1e-10 offset once (see rg_tm.h)
+        for (int j = 0; j < 12; ++j) q0[j] = c;
+    } else {
+        // servo: the lanes are linear.  The reference's affine system (tm_step_ld with c) has the fixed point
+        // q_inf = (I - F)^-1 c_vec and settles at the constant output d_inf; in coordinates q - q_inf it IS the linear
+        // system, so a track starts at -q_inf and every output carries + d_inf (added per window by the kernels).
+        ld cvec[12] = {0}, zc;
+        tm_step_ld(rc, sv, cvec, 0.0L, c, &zc);  // Phi(0)
+        std::vector<ld> A(144), b(12);
+        for (int i = 0; i < 12; ++i) {
+            for (int j = 0; j < 12; ++j) A[i * 12 + j] = (i == j ? 1.0L : 0.0L) - F[i][j];
+            b[i] = cvec[i];
+        }
+        std::vector<ld> A0 = A, x = b;
+        if (!solve_ld(12, A, x)) { out->ok = false; return; }
+        for (int it = 0; it < 2; ++it) {  // iterative refinement
+            std::vector<ld> res(12);
+            for (int i = 0; i < 12; ++i) {
+                ld sres = b[i];
+                for (int j = 0; j < 12; ++j) sres -= A0[i * 12 + j] * x[j];
+                res[i] = sres;
+            }
+            std::vector<ld> A1 = A0;
+            if (solve_ld(12, A1, res))
+                for (int j = 0; j < 12; ++j) x[j] += res[j];
+        }
+        ld qinf[12], zinf;
+        for (int j = 0; j < 12; ++j) qinf[j] = x[j];
+        tm_step_ld(rc, sv, qinf, 0.0L, c, &zinf);  // one more step from the fixed point: its output is d_inf
+        out->dinf = (double)zinf;
+        for (int j = 0; j < 12; ++j) q0[j] = -x[j];
+    }
+    // ... then t' = t + X s, then the carried coordinates (the identity below 64 kHz)
     ld s0[12];
-    for (int j = 0; j < 10; ++j) s0[j] = c;
+    for (int j = 0; j < 10; ++j) s0[j] = q0[j];
     for (int i = 0; i < 2; ++i) {
-        ld s = c;
-        for (int j = 0; j < 10; ++j) s += X[i][j] * c;
+        ld s = q0[10 + i];
+        for (int j = 0; j < 10; ++j) s += X[i][j] * q0[j];
         s0[10 + i] = s;
     }
     for (int i = 0; i < 10; ++i) {

@@ -33,6 +33,11 @@ struct RgTmDesign {
     double Wf[100];              // [10][10] upper triangular: fast block of a DF2T end state -> carried coordinates (identity if !whiten)
     double Xs[2][12];            // slow pair of a DF2T end state (s, t) -> carried coordinates: Rs (t + X s) = Xs [s; t]
     double sigma0[12];           // track-start state in block-diagonal coordinates
+    bool servo = false;          // Butterworth stage in servo form, linear lanes, analytic affine term (rg_tm.h: RgTmCoef)
+    double alpha = 0, beta = 0;  // servo constants as the kernel holds them (rounded once, from long double)
+    double g = 1;                // servo: butter b0, folded into the Yule stage's feed-forward taps
+    double dinf = 0;             // servo: constant output offset of the reference's "+1e-10" terms (= 1e-10 / beta)
+    std::vector<double> ST;      // servo: [L][12] prefix sums of T (affine cross term 2 d_inf sigma . ST)
     double resid;                // Sylvester residual (diagnostic)
     bool ok = false;
 };
@@ -41,3 +46,5 @@ struct RgTmDesign {
 // which is what the state transition Phi spans.  Returns ok=false for an unstable row or when no truncation
 // with <= RG_TM_MAX_ROUNDS doubling rounds reaches 1e-18.
 void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out, uint32_t m = 1);
+// true when the row's Butterworth numerator is exactly g (1, -2, 1): the servo form then realises the same filter
+bool rg_tm_servo_ok(const rg_rate_coeffs &rc);

@@ -127,7 +127,8 @@ int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out, u
     if (!D.ok) return RG_ERR_INVALID_ARG;
     const size_t nT = D.T.size(), nG = D.Gp.size(), nY = D.PhiY.size(), nB = D.PhiB.size();
     const size_t nL = (size_t)D.H10 * 12 + (size_t)(D.L - D.H10) * 2;
-    const size_t total = nT + nG + nY + nB + 24 + 12 + 100 + 8 + nL + 2;
+    const size_t nST = D.ST.size();  // servo: [L][12] prefix sums of T
+    const size_t total = nT + nG + nY + nB + 24 + 12 + 100 + 12 + 8 + nL + 2 + nST;
     std::vector<double> blob(total, 0.0);
     size_t o = 0;
     const size_t oT = o; memcpy(&blob[o], D.T.data(), nT * 8); o += nT;
@@ -136,12 +137,18 @@ int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out, u
     const size_t oB = o; if (nB) memcpy(&blob[o], D.PhiB.data(), nB * 8); o += nB;
     const size_t oX = o; memcpy(&blob[o], &D.Xs[0][0], 24 * 8); o += 24;
     const size_t oS = o; memcpy(&blob[o], D.sigma0, 12 * 8); o += 12;
-    memcpy(&blob[o], D.Wf, 100 * 8); o += 100;  // [last Gram | PhiY | PhiB | Xs | sigma0 | Wf] is one image for the fix-up kernel
+    memcpy(&blob[o], D.Wf, 100 * 8); o += 100;  // [last Gram | PhiY | PhiB | Xs | sigma0 | Wf | ST of a full segment] is one image for the fix-up kernel
+    if (nST) memcpy(&blob[o], &D.ST[(size_t)(D.L - 1) * 12], 12 * 8);
+    o += 12;
     o = (o + 1) & ~(size_t)1;  // 16-byte alignment of the LDS image
     const size_t oL = o;
     for (uint32_t n = 0; n < D.H10; ++n)
         for (int j = 0; j < 12; ++j) blob[o++] = D.T[(size_t)n * 12 + j];
     for (uint32_t n = D.H10; n < D.L; ++n) { blob[o++] = D.T[(size_t)n * 12 + 10]; blob[o++] = D.T[(size_t)n * 12 + 11]; }
+    o = (o + 1) & ~(size_t)1;
+    const size_t oST = o;
+    if (nST) memcpy(&blob[o], D.ST.data(), nST * 8);
+    o += nST;
     RG_HIP(c, hipMalloc((void **)&tb->d_blob, total * 8));
     RG_HIP(c, hipMemcpy(tb->d_blob, blob.data(), total * 8, hipMemcpyHostToDevice));
     RgTmGeom &g = tb->geom;
@@ -156,6 +163,11 @@ int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out, u
     g.block = rg_tm_choose_block(D.L, D.H10, m);
     g.m = m;
     g.whiten = D.whiten ? 1u : 0u;
+    g.servo = D.servo ? 1u : 0u;
+    // servo: the affine term of a window of n frames is aff_lin * (v2_end - v2_start) + aff_n * n (rg_tm.h)
+    g.aff_lin = D.servo ? 2.0 * D.dinf / D.beta : 0.0;
+    g.aff_n = D.servo ? D.dinf * D.dinf : 0.0;
+    g.aff_sig = D.servo ? 2.0 * D.dinf : 0.0;
     if (m > 1 && rg_tm_lds_bytes(D.L, D.H10, g.block) > RG_TM_LDS_BYTES) {  // multi-window segments run on the LDS path only
         tb->design.ok = false;
         return RG_ERR_INVALID_ARG;
@@ -167,6 +179,7 @@ int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out, u
     tb->fix.PhiB = tb->d_blob + oB;
     tb->fix.X = tb->d_blob + oX;
     tb->fix.sigma0 = tb->d_blob + oS;
+    tb->fix.ST = nST ? tb->d_blob + oST : nullptr;
     if (g.fix_windows == 0) {
         tb->design.ok = false;
         return RG_ERR_INVALID_ARG;
@@ -438,9 +451,18 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
         // the power-of-two input scale of the sample format is folded into the feed-forward taps
         // (exact): F32 x 32768 (src/replaygain.rs:969), S16 x 1 (:990), S32 x 32768/2^31 (:1005)
         const double scale = g.fmt == RG_FMT_F32_PLANAR ? 32768.0 : (g.fmt == RG_FMT_S16_PLANAR ? 1.0 : 32768.0 / 2147483648.0);
-        for (int i = 0; i < 11; ++i) { gl.K.b[i] = rcf.yule_b[i] * scale; gl.K.a[i] = rcf.yule_a[i]; }
+        const RgTmDesign &des = gl.tb->design;
+        // servo form (rg_tm.h): butter b0 is folded into the Yule taps (one rounding per tap, then the exact scale)
+        for (int i = 0; i < 11; ++i) {
+            gl.K.b[i] = (des.servo ? (double)((long double)des.g * (long double)rcf.yule_b[i]) : rcf.yule_b[i]) * scale;
+            gl.K.a[i] = rcf.yule_a[i];
+        }
         for (int i = 0; i < 3; ++i) { gl.K.bb[i] = rcf.butter_b[i]; gl.K.ba[i] = rcf.butter_a[i]; }
         gl.K.c0 = 1e-10;
+        gl.K.alpha = des.alpha;
+        gl.K.beta = des.beta;
+        gl.K.aff_lin = geo.aff_lin;
+        gl.K.aff_n = geo.aff_n;
         gl.fmt = g.fmt;
         gl.nch = g.nch;
         gl.list_off = tm_off;

@@ -38,6 +38,19 @@ __device__ __forceinline__ double tm_step(double (&s)[10], double (&t)[2], const
     return z;
 }
 
+// the same step with the Butterworth stage in servo form (rg_tm.h: RgTmCoef): t = (v1, v2), linear (no offsets)
+__device__ __forceinline__ double tm_step_servo(double (&s)[10], double (&t)[2], const double x, const RgTmCoef &K) {
+    const double y = fma(K.b[0], x, s[0]);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s[i] = fma(-K.a[i + 1], y, fma(K.b[i + 1], x, s[i + 1]));
+    s[9] = fma(-K.a[10], y, K.b[10] * x);
+    const double z = y - t[0];
+    const double p = t[0] + t[1];
+    t[1] = fma(K.beta, z, t[1]);
+    t[0] = fma(K.alpha, z, p);
+    return z;
+}
+
 template <int NCH>
 struct TmLane {
     double s[NCH][10];
@@ -170,7 +183,7 @@ typedef short __attribute__((ext_vector_type(4), aligned(2))) rg_s16x4u;     // 
 //   G2  z,  w_1 = bb_1 y + t_1,  w_2 = bb_2 y + c          (need y, issued 10 slots earlier)
 //   G3  s_i = u_i - a_{i+1} y                              (10, need y and u_i)
 //   G4  t_0, t_1, A, B_j                                   (need z, issued 10 slots earlier)
-template <int FMT, int NX, bool MASK, bool PEAK = true>
+template <int FMT, int NX, bool MASK, bool PEAK = true, bool SERVO = false>
 __device__ __forceinline__ void tm_frame(TmLane<1> &st, const uint32_t wbits, typename Fmt<FMT>::peak_t &pk,
                                          const double *__restrict__ tr /* NX values; unused when NX == 0 */, const RgTmCoef &K,
                                          const uint32_t n, const uint32_t len) {
@@ -178,6 +191,33 @@ __device__ __forceinline__ void tm_frame(TmLane<1> &st, const uint32_t wbits, ty
     double (&t)[2] = st.t[0];
     // frames past the end were staged as zeros; the peak is tracked here or, for whole pieces, by the caller (peak4)
     const double x = PEAK ? Fmt<FMT>::cvt_word(wbits, pk) : Fmt<FMT>::word_value(wbits);
+    if constexpr (SERVO) {
+        // 26 operations: the Butterworth stage is the Yule output (butter b0 folded into K.b) minus a double integrator,
+        // t = (v1, v2).  Three groups of independent instructions:
+        //   G1  y, u_i = b_{i+1} x + s_{i+1}, p = v1 + v2      (12; p last: v1, v2 are the previous frame's last writes)
+        //   G2  z = y - v1,  s_i = u_i - a_{i+1} y               (11)
+        //   G3  v2, v1, A, B_j                                    (3 + NX, need z, issued 10 slots earlier)
+        const double y = fma(K.b[0], x, s[0]);
+        double u[10];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) u[i] = fma(K.b[i + 1], x, s[i + 1]);
+        u[9] = K.b[10] * x;
+        const double p = t[0] + t[1];
+        __builtin_amdgcn_sched_barrier(0);
+        double z = y - t[0];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) s[i] = fma(-K.a[i + 1], y, u[i]);
+        __builtin_amdgcn_sched_barrier(0);
+        // a masked frame (past the end of the track) leaves v2 where it is: v2 / beta is the sum of the outputs so far
+        if (MASK) z = n < len ? z : 0.0;
+        t[1] = fma(K.beta, z, t[1]);
+        t[0] = fma(K.alpha, z, p);
+        st.A[0] = fma(z, z, st.A[0]);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) st.B[0][RG_TM_DIM - NX + j] = fma(z, tr[j], st.B[0][RG_TM_DIM - NX + j]);
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+    }
     const double y = fma(K.b[0], x, s[0]);
     double u[10];
 #pragma unroll
@@ -222,7 +262,7 @@ __device__ __forceinline__ void tm_load_row(double (&dst)[NX], const double *__r
 // cascade and the energy alone (windows 2..m of a multi-window segment: no table reads at all).
 // A row is up to L frames: lane r of the wave owns row r, which starts at `rowp` (this lane's) and has `len` valid
 // frames.  The rows of a wave need not belong to one track or channel: the loader lanes fetch the bases by shuffle.
-template <int FMT, bool TAIL, bool MOM>
+template <int FMT, bool TAIL, bool MOM, bool SERVO>
 __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::peak_t &pk, const RgTmCoef &K, const uint32_t L,
                                              const uint32_t H,
                                              const __attribute__((address_space(1))) typename Fmt<FMT>::elem *rowp,
@@ -309,13 +349,13 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
             F::peak4(f, pk);
             if (MODE == 3 || MODE == 4) {  // cascade and energy only
 #pragma unroll
-                for (int u = 0; u < 4; ++u) tm_frame<FMT, 0, TAIL, false>(st, f[u], pk, nullptr, K, n + u, len);
+                for (int u = 0; u < 4; ++u) tm_frame<FMT, 0, TAIL, false, SERVO>(st, f[u], pk, nullptr, K, n + u, len);
             } else if (MODE == 1 || (MODE == 0 && n < H)) {  // all 12 transient moments live (H is a multiple of 4, or the whole segment)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     double row[12];
                     tm_load_row<12>(row, T12 + (size_t)(n + u) * 12);
-                    tm_frame<FMT, 12, TAIL, false>(st, f[u], pk, row, K, n + u, len);
+                    tm_frame<FMT, 12, TAIL, false, SERVO>(st, f[u], pk, row, K, n + u, len);
                 }
             } else {  // only the slow (Butterworth) pair
                 double rows[8];
@@ -324,7 +364,7 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const double tr[2] = {rows[2 * u], rows[2 * u + 1]};
-                    tm_frame<FMT, 2, TAIL, false>(st, f[u], pk, tr, K, n + u, len);
+                    tm_frame<FMT, 2, TAIL, false, SERVO>(st, f[u], pk, tr, K, n + u, len);
                 }
             }
         };
@@ -353,14 +393,14 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
                 const uint32_t o = n - n0;
                 const uint32_t f = *reinterpret_cast<const uint32_t *>(rrow + 16 * ((int)(o >> 2) ^ rswz) + 4 * (o & 3));
                 if (MODE == 4) {
-                    tm_frame<FMT, 0, TAIL>(st, f, pk, nullptr, K, n, len);
+                    tm_frame<FMT, 0, TAIL, true, SERVO>(st, f, pk, nullptr, K, n, len);
                 } else if (n < H) {
                     double row[12];
                     tm_load_row<12>(row, T12 + (size_t)n * 12);
-                    tm_frame<FMT, 12, TAIL>(st, f, pk, row, K, n, len);
+                    tm_frame<FMT, 12, TAIL, true, SERVO>(st, f, pk, row, K, n, len);
                 } else {
                     const double tr[2] = {T2[(size_t)(n - H) * 2], T2[(size_t)(n - H) * 2 + 1]};
-                    tm_frame<FMT, 2, TAIL>(st, f, pk, tr, K, n, len);
+                    tm_frame<FMT, 2, TAIL, true, SERVO>(st, f, pk, tr, K, n, len);
                 }
             }
         }
@@ -388,7 +428,7 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
 
 // MULTI = multi-window segments (G.m > 1); a separate instantiation, so that the one-window kernel's register
 // allocation is not disturbed by the window loop
-template <int FMT, bool MULTI>
+template <int FMT, bool MULTI, bool SERVO>
 __global__ void __launch_bounds__(MULTI ? RG_TM_BLOCK_WIDE_MULTI : RG_TM_BLOCK_WIDE)
 rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restrict__ tracks, uint32_t n_tracks,
                   double *__restrict__ rec, uint32_t total_recs, double *__restrict__ win_energy /* [channels][total_windows], m > 1 */,
@@ -457,6 +497,14 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
         if (__any(bad) && bad) atomicMax(&nonfinite[tracks[t].track_index], 0xFFFFFFFFu - unit);
     };
 
+    // servo: the lanes are linear and every true output is the linear one + d_inf (rg_tm.h).  The part of that which does not
+    // depend on the segment's start state goes into the stored energy right here, while v2 still is the sum of beta z over
+    // the window the moments cover: 2 d_inf v2 / beta + len d_inf^2.  (The fix-up kernel adds the start state's share.)
+    auto first_energy = [&]() -> double {
+        // (an energy that is not finite keeps its class: an Inf sample in the last frame leaves +Inf here and -Inf in v2)
+        if constexpr (SERVO) return fabs(st.A[0]) <= 1.7976931348623157e308 ? st.A[0] + fma(K.aff_lin, st.t[0][1], K.aff_n * (double)len) : st.A[0];
+        return st.A[0];
+    };
     bool done = false;
     {
         if (lds_tables) {
@@ -486,9 +534,9 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
             // of the channel go through the element-wise staging of the TAIL variant too
             const bool plain = len == L && start + ((L + 3u) & ~3u) <= tr.frames;
             if (__all(plain))
-                tm_fast_path<FMT, false, true>(st, pk, K, L, H, chp + start, len, T12, T2, wtile);
+                tm_fast_path<FMT, false, true, SERVO>(st, pk, K, L, H, chp + start, len, T12, T2, wtile);
             else if (__any(len != 0))
-                tm_fast_path<FMT, true, true>(st, pk, K, L, H, chp + start, len, T12, T2, wtile);
+                tm_fast_path<FMT, true, true, SERVO>(st, pk, K, L, H, chp + start, len, T12, T2, wtile);
             if constexpr (MULTI) {
                 // ---- windows 2..m of the segment: the start state's transient is gone (|Phi| < 1e-15 per window,
                 // rg_design.cpp), what is left is the running cascade and one energy per window.  The moments of the
@@ -496,7 +544,7 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
                 note_nonfinite(st.A[0], seg * m, active);
                 if (active) {
                     double *__restrict__ const r = rec_ptr();
-                    r[0] = st.A[0];
+                    r[0] = first_energy();
 #pragma unroll
                     for (int j = 0; j < RG_TM_DIM; ++j) r[(size_t)(1 + j) * total_recs] = st.B[0][j];
                 }
@@ -510,6 +558,7 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
                     }
                     if (!__any(lenw != 0)) break;  // the track ended in an earlier window for every row of this wave
                     st.A[0] = 0.0;
+                    const double v2_start = st.t[0][1];
                     // A row whose track ended in an earlier window of this lane must not send the whole wave down the masked
                     // path (with 98 segments of 37 windows per three-minute track two waves in three hold such a row, for 26
                     // of their 37 windows): it re-reads its track's FIRST window instead -- same track, same channel, so the
@@ -518,11 +567,15 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
                     const bool plainw = idle || (lenw == L && wstart + ((L + 3u) & ~3u) <= tr.frames);
                     gelem *const rowp = idle ? chp : chp + wstart;
                     if (__all(plainw))
-                        tm_fast_path<FMT, false, false>(st, pk, K, L, H, rowp, lenw, T12, T2, wtile);
+                        tm_fast_path<FMT, false, false, SERVO>(st, pk, K, L, H, rowp, lenw, T12, T2, wtile);
                     else
-                        tm_fast_path<FMT, true, false>(st, pk, K, L, H, rowp, lenw, T12, T2, wtile);
+                        tm_fast_path<FMT, true, false, SERVO>(st, pk, K, L, H, rowp, lenw, T12, T2, wtile);
                     note_nonfinite(st.A[0], seg * m + w, lenw != 0);
-                    if (lenw != 0) win_energy[(size_t)chan * total_windows + tracks[t].win_base + (size_t)seg * m + w] = st.A[0];
+                    // servo: the lanes are linear; the reference's constant offsets add d_inf to every output, and
+                    // sum (z + d_inf)^2 = sum z^2 + 2 d_inf (v2_end - v2_start) / beta + n d_inf^2 (rg_tm.h)
+                    double energy = st.A[0];
+                    if constexpr (SERVO) energy = fabs(energy) <= 1.7976931348623157e308 ? energy + fma(K.aff_lin, st.t[0][1] - v2_start, K.aff_n * (double)lenw) : energy;
+                    if (lenw != 0) win_energy[(size_t)chan * total_windows + tracks[t].win_base + (size_t)seg * m + w] = energy;
                 }
             }
         }
@@ -537,7 +590,15 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
             double x = 0.0;
             if (valid) x = F::cvt(p0[n], pk);
             rg_cdouble *__restrict__ Trow = T + (size_t)n * RG_TM_DIM;
-            double z = tm_step(st.s[0], st.t[0], x, K);
+            double z;
+            if constexpr (SERVO) {
+                // a frame past the end must leave v2 alone (v2 / beta = sum of the outputs): the state after the end is never used
+                const double v2 = st.t[0][1];
+                z = tm_step_servo(st.s[0], st.t[0], x, K);
+                if (!valid) st.t[0][1] = v2;
+            } else {
+                z = tm_step(st.s[0], st.t[0], x, K);
+            }
             z = valid ? z : 0.0;
             st.A[0] = fma(z, z, st.A[0]);
 #pragma unroll
@@ -560,7 +621,7 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
         note_nonfinite(st.A[0], seg, active);
         if (active) {
             double *__restrict__ const r = rec_ptr();
-            r[0] = st.A[0];
+            r[0] = first_energy();
 #pragma unroll
             for (int j = 0; j < RG_TM_DIM; ++j) r[(size_t)(1 + j) * total_recs] = st.B[0][j];
         }
@@ -582,7 +643,7 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
 // rg_tm_main_kernel (windows_here = 1) left it -- the twelve state words and the peak it stored in the segment's record --
 // runs the remaining windows exactly as the main kernel's own loop would (same tm_fast_path instantiations, same order),
 // and puts the final state back.
-template <int FMT>
+template <int FMT, bool SERVO>
 __global__ void __launch_bounds__(RG_TM_BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
 rg_tm_plain_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restrict__ tracks, uint32_t n_tracks,
                    double *__restrict__ rec, uint32_t total_recs, double *__restrict__ win_energy, uint32_t total_windows,
@@ -634,15 +695,18 @@ rg_tm_plain_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restri
         }
         if (!__any(lenw != 0)) break;  // the track ended in an earlier window for every row of this wave
         st.A[0] = 0.0;
+        const double v2_start = st.t[0][1];
         const bool idle = lenw == 0 && tr.frames >= (uint64_t)((L + 3u) & ~3u);  // see rg_tm_main_kernel
         const bool plainw = idle || (lenw == L && wstart + ((L + 3u) & ~3u) <= tr.frames);
         gelem *const rowp = idle ? chp : chp + wstart;
         if (__all(plainw))
-            tm_fast_path<FMT, false, false>(st, pk, K, L, G.H10, rowp, lenw, nullptr, nullptr, wtile);
+            tm_fast_path<FMT, false, false, SERVO>(st, pk, K, L, G.H10, rowp, lenw, nullptr, nullptr, wtile);
         else
-            tm_fast_path<FMT, true, false>(st, pk, K, L, G.H10, rowp, lenw, nullptr, nullptr, wtile);
+            tm_fast_path<FMT, true, false, SERVO>(st, pk, K, L, G.H10, rowp, lenw, nullptr, nullptr, wtile);
         note_nonfinite(st.A[0], seg * m + w, lenw != 0);
-        if (lenw != 0) win_energy[(size_t)chan * total_windows + tracks[t].win_base + (size_t)seg * m + w] = st.A[0];
+        double energy = st.A[0];
+        if constexpr (SERVO) energy = fabs(energy) <= 1.7976931348623157e308 ? energy + fma(K.aff_lin, st.t[0][1] - v2_start, K.aff_n * (double)lenw) : energy;
+        if (lenw != 0) win_energy[(size_t)chan * total_windows + tracks[t].win_base + (size_t)seg * m + w] = energy;
     }
     if (active) {
         double *__restrict__ const r = rec_ptr();
@@ -739,10 +803,10 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     // ---- the wave-uniform tables, one contiguous image in the design blob (rg_enqueue.hip: the last prefix
     // Gram matrix is followed by PhiY, PhiB, X, sigma0), copied to LDS under the record loads: as scalar
     // loads they missed the constant cache in every wave and sat on the critical path of each scan round
-    __shared__ double ftab[RG_TM_GRAM + RG_TM_MAX_ROUNDS * 104 + 36 + 100];
+    __shared__ double ftab[RG_TM_GRAM + RG_TM_MAX_ROUNDS * 104 + 36 + 100 + 12];
     {
         const double *__restrict__ src = FT.Gp + (size_t)(G.L - 1) * RG_TM_GRAM;
-        const int n = RG_TM_GRAM + (int)G.rounds * 104 + 36 + (G.whiten ? 100 : 0);
+        const int n = RG_TM_GRAM + (int)G.rounds * 104 + 36 + (G.servo ? 112 : (G.whiten ? 100 : 0));
         for (int q = i; q < n; q += RG_TM_BLOCK) ftab[q] = src[q];
     }
     const double *const Gfull = ftab;
@@ -751,6 +815,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     const double *const X = PhiB + G.rounds * 4;
     const double *const S0 = X + 24;
     const double *const Wf = S0 + 12;
+    const double *const STf = Wf + 100;  // servo: sum over a full segment of the responses (affine cross term)
 
     // ---- zero-state end states of this segment, all channels (the moments are fetched where they are used:
     // the kernel is latency bound and lives on occupancy, so the live register set is kept small) ----------
@@ -903,6 +968,20 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
             S += 2.0 * (lin[c] + quad[c]);
             Mseg += 2.0 * quad[c];
         }
+        // servo: every true output is the linear one + d_inf (rg_tm.h).  The main kernel has put 2 d_inf sum zs + len d_inf^2
+        // into A; the start state's share 2 d_inf sigma . ST (ST = sum of the responses over the segment) is added here (a
+        // segment the track ends in gets it with its own prefix sum from wave 0 below)
+        if (G.servo && full) {
+            double aff = 0.0;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                double sx = 0.0;
+#pragma unroll
+                for (int j = 0; j < RG_TM_DIM; ++j) sx = fma(STf[j], sgm[c][j], sx);
+                aff = fma(G.aff_sig, sx, aff);
+            }
+            S += aff;
+        }
     }
     // windows after the first non-finite unit of the track are NaN windows (see the main kernel).  The unit itself has
     // the class of its zero-state energy (the true output differs from the zero-state one by finite terms): NaN, or
@@ -930,7 +1009,12 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     if (wave == 0 && part_len != 0) {
         // term p of the packed upper triangle is G[p] s_j s_q (halved on the diagonal); two terms per lane
         const double *__restrict__ Gm = FT.Gp + (size_t)(part_len - 1) * RG_TM_GRAM;
-        double quad = 0.0;
+        double quad = 0.0, affp = 0.0;
+        if (G.servo && lane < RG_TM_DIM) {  // the affine cross term with the prefix sum of this length
+            const double sj = FT.ST[(size_t)(part_len - 1) * RG_TM_DIM + lane];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) affp = fma(G.aff_sig * sj, part_sg[c][lane], affp);
+        }
         for (int p = lane; p < RG_TM_GRAM; p += 64) {
             int j = 0, base = 0;
             while (p >= base + RG_TM_DIM - j) { base += RG_TM_DIM - j; ++j; }
@@ -940,9 +1024,12 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
             for (int c = 0; c < NCH; ++c) quad = fma(g * part_sg[c][j], part_sg[c][q], quad);
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) quad += __shfl_xor(quad, off, 64);
+        for (int off = 32; off > 0; off >>= 1) {
+            quad += __shfl_xor(quad, off, 64);
+            affp += __shfl_xor(affp, off, 64);
+        }
         if (lane == 0) {
-            pieces[part_lane] += 2.0 * quad;
+            pieces[part_lane] += 2.0 * quad + affp;
             pieces_m[part_lane] += 2.0 * quad;
         }
     }
@@ -1073,7 +1160,7 @@ extern "C" void rg_tm_set_debug_buffer(unsigned long long *d_buf) { g_tm_debug =
 static unsigned long long *g_tm_fix_debug = nullptr;
 extern "C" void rg_tm_set_fix_debug_buffer(unsigned long long *d_buf) { g_tm_fix_debug = d_buf; }
 
-template <int FMT>
+template <int FMT, bool SERVO>
 static hipError_t launch_main_fmt(int nch, const RgTmCoef &K, const RgTmGeom &G, const RgTmTrack *d_tracks,
                                   uint32_t n_tracks, uint32_t grid, double *d_rec, uint32_t total_recs, double *d_win,
                                   uint32_t total_windows, uint32_t *d_nonfinite, uint32_t *d_zero, uint64_t zero_count,
@@ -1089,22 +1176,22 @@ static hipError_t launch_main_fmt(int nch, const RgTmCoef &K, const RgTmGeom &G,
     (void)hipGetDevice(&dev);
     const unsigned long long dev_bit = 1ull << (dev & 63);
     if (lds > 48 * 1024 && !(attr_set.load(std::memory_order_acquire) & dev_bit)) {
-        (void)hipFuncSetAttribute((const void *)rg_tm_main_kernel<FMT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_TM_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)rg_tm_main_kernel<FMT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_TM_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)rg_tm_main_kernel<FMT, false, SERVO>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_TM_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)rg_tm_main_kernel<FMT, true, SERVO>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_TM_LDS_BYTES);
         attr_set.fetch_or(dev_bit, std::memory_order_release);
     }
     if (G.m > 1) {
         if (!lds_tables) return hipErrorInvalidValue;  // multi-window segments exist on the LDS path only
-        hipLaunchKernelGGL((rg_tm_main_kernel<FMT, true>), dim3(grid), dim3(G.block), lds, s, K, G, d_tracks, n_tracks,
+        hipLaunchKernelGGL((rg_tm_main_kernel<FMT, true, SERVO>), dim3(grid), dim3(G.block), lds, s, K, G, d_tracks, n_tracks,
                            d_rec, total_recs, d_win, total_windows, d_nonfinite, lds_tables, split ? 1u : G.m, d_zero, zero_count, g_tm_debug);
         if (split) {  // windows 2..m at four waves per SIMD; the same lanes, in blocks of 256
             const uint64_t lanes = (uint64_t)grid * G.block;
             const uint32_t pgrid = (uint32_t)((lanes + RG_TM_BLOCK - 1) / RG_TM_BLOCK);
-            hipLaunchKernelGGL((rg_tm_plain_kernel<FMT>), dim3(pgrid), dim3(RG_TM_BLOCK), (RG_TM_BLOCK / 64) * RG_TM_WAVE_TILE_BYTES, s, K, G,
+            hipLaunchKernelGGL((rg_tm_plain_kernel<FMT, SERVO>), dim3(pgrid), dim3(RG_TM_BLOCK), (RG_TM_BLOCK / 64) * RG_TM_WAVE_TILE_BYTES, s, K, G,
                                d_tracks, n_tracks, d_rec, total_recs, d_win, total_windows, d_nonfinite);
         }
     } else {
-        hipLaunchKernelGGL((rg_tm_main_kernel<FMT, false>), dim3(grid), dim3(G.block), lds, s, K, G, d_tracks, n_tracks,
+        hipLaunchKernelGGL((rg_tm_main_kernel<FMT, false, SERVO>), dim3(grid), dim3(G.block), lds, s, K, G, d_tracks, n_tracks,
                            d_rec, total_recs, d_win, total_windows, d_nonfinite, lds_tables, 1u, d_zero, zero_count, g_tm_debug);
     }
     return hipGetLastError();
@@ -1115,11 +1202,20 @@ extern "C" hipError_t rg_launch_tm_main(int fmt, int nch, const RgTmCoef *K, con
                                         uint32_t total_recs, double *d_win, uint32_t total_windows, uint32_t *d_nonfinite,
                                         uint32_t *d_zero, uint64_t zero_count, int split, hipStream_t s) {
     if (grid == 0) return hipSuccess;
-    switch (fmt) {
-        case RG_FMT_F32_PLANAR: return launch_main_fmt<RG_FMT_F32_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_win, total_windows, d_nonfinite, d_zero, zero_count, split, s);
-        case RG_FMT_S16_PLANAR: return launch_main_fmt<RG_FMT_S16_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_win, total_windows, d_nonfinite, d_zero, zero_count, split, s);
-        default: return launch_main_fmt<RG_FMT_S32_PLANAR>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_win, total_windows, d_nonfinite, d_zero, zero_count, split, s);
+#define RG_TM_LAUNCH(F, SV) launch_main_fmt<F, SV>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_win, total_windows, d_nonfinite, d_zero, zero_count, split, s)
+    if (G->servo) {
+        switch (fmt) {
+            case RG_FMT_F32_PLANAR: return RG_TM_LAUNCH(RG_FMT_F32_PLANAR, true);
+            case RG_FMT_S16_PLANAR: return RG_TM_LAUNCH(RG_FMT_S16_PLANAR, true);
+            default: return RG_TM_LAUNCH(RG_FMT_S32_PLANAR, true);
+        }
     }
+    switch (fmt) {
+        case RG_FMT_F32_PLANAR: return RG_TM_LAUNCH(RG_FMT_F32_PLANAR, false);
+        case RG_FMT_S16_PLANAR: return RG_TM_LAUNCH(RG_FMT_S16_PLANAR, false);
+        default: return RG_TM_LAUNCH(RG_FMT_S32_PLANAR, false);
+    }
+#undef RG_TM_LAUNCH
 }
 
 extern "C" hipError_t rg_launch_tm_fix(int nch, const RgTmGeom *G, const RgTmFixTables *FT, const RgTmTrack *d_tracks,

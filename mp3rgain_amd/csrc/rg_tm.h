@@ -49,12 +49,32 @@
 #define RG_TM_EDGE 16         // lanes of a wave whose scan values are visible to the next wave (>= 2^(MAX_ROUNDS-1), and 1 for the final shift)
 
 // filter constants of one launch group, passed by value (wave-uniform -> SGPRs)
+//
+// Two realisations of the Butterworth high-pass stage (src/replaygain.rs:604-615):
+//   classic  transposed direct form II, 5 multiply-adds per sample, the reference's "+1e-10" per stage injected at the
+//            deepest state of each stage (rounds 1-3; still used for the rates whose numerator is not exactly g (1, -2, 1))
+//   servo    (round 4) for numerators that ARE exactly g (1 - z^-1)^2 -- 96, 48, 44.1, 32, 16, 12 and 8 kHz: g is folded
+//            into the Yule stage's feed-forward taps and the stage is the output minus a double integrator,
+//                z = y - v1;   v1 += v2 + alpha z;   v2 += beta z;      alpha = 2 + a1,  beta = 1 + a1 + a2 = A(1)
+//            which has the reference's denominator to 1e-19 (alpha, beta are small numbers computed in long double),
+//            costs 4 operations instead of 5 (26 per sample with the energy instead of 27) and is better conditioned
+//            than either direct form: v1, v2 follow the low-frequency content instead of holding differences of large
+//            numbers (30 Hz full-scale sine, window energies against a long double run of the reference's recursion:
+//            reference order 1.1e-12, classic 8.7e-13, servo 8e-15).  The lanes are LINEAR in this mode; the "+1e-10"
+//            offsets are an affine term that does not depend on the signal and is added analytically: the true
+//            system is the linear one started at -q_inf plus a constant output offset d_inf = 1e-10 / beta, and
+//            sum over a window of (z + d_inf)^2 = sum z^2 + 2 d_inf (v2_end - v2_start) / beta + n d_inf^2 because
+//            v2 IS the running sum of beta z.
 struct RgTmCoef {
-    double b[11];   // yule b, pre-multiplied by the (power of two) input scale of the sample format
+    double b[11];   // yule b, pre-multiplied by the (power of two) input scale of the sample format (servo: and by butter b0)
     double a[11];   // yule a (a[0] unused)
-    double bb[3];   // butter b
-    double ba[3];   // butter a (ba[0] unused)
-    double c0;      // the reference's per-stage +1e-10 (src/replaygain.rs:530), injected at the deepest state
+    double bb[3];   // butter b (classic)
+    double ba[3];   // butter a (ba[0] unused; classic)
+    double c0;      // classic: the reference's per-stage +1e-10 (src/replaygain.rs:530), injected at the deepest state
+    double alpha;   // servo: 2 + butter a1
+    double beta;    // servo: 1 + butter a1 + butter a2
+    double aff_lin; // servo: 2 d_inf / beta   -- window energy += aff_lin * (v2_end - v2_start) + aff_n * frames
+    double aff_n;   // servo: d_inf^2
 };
 
 struct RgTmTrack {
@@ -89,6 +109,9 @@ struct RgTmGeom {
                            // start state has decayed below 1e-30 of itself -- and hands windows 2..m over as plain
                            // energies, which rg_tm_direct_kernel bins)
     uint32_t whiten;       // 64 / 96 kHz: the fix-up kernel takes a DF2T end state's fast block through Wf (rg_design.cpp)
+    uint32_t servo;        // the Butterworth stage runs in servo form and the lanes are linear (RgTmCoef)
+    double aff_lin, aff_n; // servo: the affine term of a window, see RgTmCoef (0 otherwise)
+    double aff_sig;        // servo: 2 d_inf -- times (start state . sum of the responses) for the window the moments cover
     const double *T;       // [L][12] homogeneous responses, block-diagonal coordinates
     const double *Tlds;    // the same packed for LDS: [H10][12] then [L - H10][2] (only the slow pair)
 };
@@ -100,6 +123,7 @@ struct RgTmFixTables {
     const double *PhiY;    // [rounds][10][10]  (F_y^L)^(2^r)
     const double *PhiB;    // [rounds][2][2]    (F_b^L)^(2^r)
     const double *Gp;      // [L][78]  prefix Gram matrices: Gp[len-1] = sum_{n<len} T T'
+    const double *ST;      // [L][12]  servo: prefix sums of the responses, ST[len-1] = sum_{n<len} T[n] (the affine cross term)
 };
 
 // LDS bytes of a main-kernel block of `block` threads, and the block size for an (L, H10) design
