@@ -521,10 +521,10 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
         const size_t o_k1 = (o_all + n * sizeof(RgTrackDev) + 15) & ~(size_t)15;
         const size_t o_tm = (o_k1 + n_k1 * sizeof(RgTrackDev) + 15) & ~(size_t)15;
         const size_t blob_bytes = o_tm + tm_off * sizeof(RgTmTrack);
-        const unsigned char *old_dev = S.d_desc.p;
+        const size_t old_desc_cap = S.d_desc.cap;  // (a reallocation may hand the freed address out again: compare capacities)
         RG_HIP(c, S.d_desc.reserve(blob_bytes));
         RG_HIP(c, S.h_desc.reserve(blob_bytes));
-        if (S.d_desc.p != old_dev) S.desc_shadow.clear();
+        if (S.d_desc.cap != old_desc_cap) S.desc_shadow.clear();
         std::vector<unsigned char> blob(blob_bytes, 0);
         memcpy(&blob[o_all], c->h_tracks.data(), n * sizeof(RgTrackDev));
         if (n_k1) memcpy(&blob[o_k1], c->h_k1_tracks.data(), n_k1 * sizeof(RgTrackDev));

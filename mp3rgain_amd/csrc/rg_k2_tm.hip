@@ -1119,7 +1119,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
                     const double lo = total - e;
                     any_flag = any_flag || rg_window_bin(lo < 0.0 ? 0.0 : lo, 0.0, n) != rg_window_bin(total + e, 0.0, n);
                 }
-                if (wb >= 0) tm_performed(atomicAdd(&hist[(size_t)tr.track_index * RG_HISTOGRAM_SIZE + wb], 1u));
+                if (wb >= 0) (void)atomicAdd(&hist[(size_t)tr.track_index * RG_HISTOGRAM_SIZE + wb], 1u);  // no return value: waited for once, below
             }
         }
         if (__any(any_flag) && lane == 0) tm_performed(atomicOr(&imprecise[tr.track_index], 1u));
@@ -1131,7 +1131,10 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     // device-scope atomics whose results have come back (tm_performed) before the barrier, so the arrival
     // counter moves after them without a release fence: an agent-scope release on this multi-XCD part writes
     // the whole L2 back, and one per wave made that the most expensive thing in the kernel.  The finisher
-    // drops its XCD's possibly stale histogram lines before reading.
+    // drops its XCD's possibly stale histogram lines before reading.  (The per-window counts of multi-window segments
+    // are atomics without a return value -- up to m - 1 per lane, not worth a round trip each: every wave waits here
+    // until the memory side has acknowledged its own.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (i == 0) is_last = atomicAdd(&done_count[tr.track_index], 1u) + 1u == tr.fix_blocks ? 1 : 0;
     __syncthreads();
