@@ -228,7 +228,8 @@ int rg_album_allreduce(rg_ctx *ctx, void *nccl_comm);
  * per step, which is what makes it the fast form (a torch.distributed collective hops into torch's RCCL stream
  * and back).  Bootstrap: rank 0 calls rg_comm_unique_id, the 128 bytes travel by whatever the host has
  * (torch.distributed broadcast in bench.py), every rank calls rg_comm_init (ncclCommInitRank).
- * rg_comm_library names the librccl.so to resolve from first (e.g. the one PyTorch already loaded).
+ * rg_comm_library names the librccl.so to resolve from first (e.g. the one PyTorch already loaded); a file that is not
+ * called librccl.so[.N] is refused unless MP3RGAIN_AMD_TEST_SEAMS=1 (the tests' stand-in transport: unsupported in production).
  * Without a communicator rg_album_exchange is a no-op (single GPU). */
 #define RG_COMM_ID_BYTES 128
 int rg_comm_library(const char *librccl_path);

@@ -81,6 +81,7 @@ typedef struct rg_node_backend {
     const char *(*last_error)(void *engine, void *user);
     void *user;
 } rg_node_backend;
+/* TEST SEAM, unsupported in production: refused (NULL, see rg_node_create_error) unless MP3RGAIN_AMD_TEST_SEAMS=1. */
 rg_node *rg_node_create_backend(const rg_node_backend *backend, const int *devices, size_t n);
 
 #ifdef __cplusplus

@@ -294,7 +294,14 @@ class Cli:
     def analyzer(self) -> rgmod.Node:
         if self._an is None:
             devs = os.environ.get("MP3RGAIN_AMD_DEVICES")
-            self._an = rgmod.Node([int(d) for d in devs.split(",")] if devs else None)
+            if devs:
+                devices = [int(d) for d in devs.split(",")]
+            elif len(self.o.files) <= 1:
+                devices = [0]  # one file runs on one GPU: no contexts (streams, tables, pinned buffers) on the others, and a
+                               # GPU that cannot be opened elsewhere on the machine does not fail a single-file command
+            else:
+                devices = None  # every visible GPU
+            self._an = rgmod.Node(devices)
             dec = self.o.decoder or os.environ.get("MP3RGAIN_AMD_DECODER")
             if dec:
                 self._an.set_decoder_command(dec)

@@ -509,6 +509,15 @@ const char *nccl_error(int r) {
 // cross-stream event per step (what a torch.distributed collective costs twice: into its RCCL stream and back)
 extern "C" int rg_comm_library(const char *path) {
     if (!path) return RG_ERR_INVALID_ARG;
+    // Only a library called librccl.so[.N] is taken in normal operation (PyTorch's copy, or the system's).  Anything else
+    // is a test seam -- tests/standin_rccl lets several ranks share one GPU -- and needs MP3RGAIN_AMD_TEST_SEAMS=1.
+    {
+        const char *base = strrchr(path, '/');
+        base = base ? base + 1 : path;
+        const bool rccl = strncmp(base, "librccl.so", 10) == 0 && (base[10] == 0 || base[10] == '.');
+        const char *seams = getenv("MP3RGAIN_AMD_TEST_SEAMS");
+        if (!rccl && !(seams && seams[0] == '1')) return RG_ERR_INVALID_ARG;
+    }
     void *h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
     if (!h) return RG_ERR_COLLECTIVE;
     g_rccl = h;

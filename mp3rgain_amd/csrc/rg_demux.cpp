@@ -257,6 +257,7 @@ extern "C" int rg_mp4_access_units(const void *data, size_t len, size_t audio_in
     if (cb + 8 + runs * 12 > t.stsc.end()) return fail(RG_DEMUX_ERR_FORMAT, "stsc entries run past the box");
     if (ob + 8 + chunks * (t.co64 ? 8u : 4u) > t.stco.end()) return fail(RG_DEMUX_ERR_FORMAT, "chunk offsets run past the box");
     uint64_t sample = 0, run = 0;
+    uint64_t total_bytes = 0;  // the samples of one track do not overlap: together they cannot exceed the file
     for (uint64_t c = 1; c <= chunks && sample < count; ++c) {
         while (run + 1 < runs && be32(d + cb + 8 + (run + 1) * 12) <= c) ++run;
         if (runs == 0 || be32(d + cb + 8 + run * 12) > c) continue;  // a chunk before the first run: no samples
@@ -266,6 +267,10 @@ extern "C" int rg_mp4_access_units(const void *data, size_t len, size_t audio_in
             uint32_t sz = 0;
             if (!size_of(sample, &sz)) return fail(RG_DEMUX_ERR_FORMAT, "sample sizes run past the box");
             if (off > len || sz > len - off) return RG_DEMUX_OK;  // truncated file: the reader's UnexpectedEof ends the track
+            total_bytes += sz;
+            // (a crafted table -- fixed size 1, count 2^32 - 1, every chunk at offset 0 -- would otherwise list four billion
+            // samples of a 400 KB file and have the caller allocate for them)
+            if (total_bytes > len) return fail(RG_DEMUX_ERR_FORMAT, "sample table describes more bytes than the file holds");
             if (*n < cap) {
                 if (offsets) offsets[*n] = off;
                 if (sizes) sizes[*n] = sz;

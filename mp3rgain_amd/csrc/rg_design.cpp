@@ -299,7 +299,13 @@ void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out, uint32_
                 for (int j = 0; j < 2; ++j) Gs[i * 2 + j] += r[10 + i] * r[10 + j];
         }
         ld Rf2[100], Rs2[4];
-        if (cholesky_ld(10, Gf, Rf2) && cholesky_ld(2, Gs, Rs2)) {
+        if (!(cholesky_ld(10, Gf, Rf2) && cholesky_ld(2, Gs, Rs2))) {
+            // without the whitening these rates bring back the cancellation it was added to remove (rg_enqueue.hip sends
+            // every stable rate to variant 2): the candidate is refused, choose_tm_tables tries the next one
+            out->ok = false;
+            return;
+        }
+        {
             memcpy(Rf, Rf2, sizeof Rf);
             memcpy(Rs, Rs2, sizeof Rs);
             out->whiten = true;

@@ -23,6 +23,8 @@
 #include <string>
 #include <vector>
 
+#include <new>
+#include <stdexcept>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -461,7 +463,21 @@ std::string shell_quote(const char *s) {
 
 // Load one file (no device work; safe to call from several threads at once as long as `err` is per call).
 // RIFF/WAVE: the bytes; MPEG Layer III: decoded planar f32; anything else: the decoder command's stdout.
+int load_audio_for_impl(const std::string &decoder_cmd, int gpu_decode, const char *path, LoadedAudio *out, std::string *err, int32_t track_index);
+// The loaders run on host threads of the library's own: an allocation failure there must come back as a status, not end
+// the process in std::terminate.
 int load_audio_for(const std::string &decoder_cmd, int gpu_decode, const char *path, LoadedAudio *out, std::string *err, int32_t track_index) {
+    try {
+        return load_audio_for_impl(decoder_cmd, gpu_decode, path, out, err, track_index);
+    } catch (const std::bad_alloc &) {
+        *err = std::string("Out of memory while loading: ") + (path ? path : "");
+        return RG_ERR_NOMEM;
+    } catch (const std::exception &ex) {
+        *err = std::string("Failed to load: ") + (path ? path : "") + " (" + ex.what() + ")";
+        return RG_ERR_FORMAT;
+    }
+}
+int load_audio_for_impl(const std::string &decoder_cmd, int gpu_decode, const char *path, LoadedAudio *out, std::string *err, int32_t track_index) {
     char msg[1024];
     auto fail = [&](int code, const char *fmt, const char *a, int b = 0) {
         snprintf(msg, sizeof msg, fmt, a, b);
@@ -1165,7 +1181,7 @@ extern "C" int rg_analyze_album_begin(rg_ctx *c, const char *const *paths, size_
         c->file_track_index = track_index;
         rc = load_many(c, paths + first, cnt, &in, &rcs, &errs);
         c->file_track_index = -1;
-        if (rc != RG_OK) return fail_at(first, rc);
+        if (rc != RG_OK) return rc;  // not a file's failure: *failed_index stays (size_t)-1, so that a node prefers real file errors of other shares
         for (size_t i = 0; i < cnt; ++i) {
             std::string msg;
             const int frc = file_outcome(in[i], rcs[i], errs[i], paths[first + i], track_index, &msg);
@@ -1181,11 +1197,11 @@ extern "C" int rg_analyze_album_begin(rg_ctx *c, const char *const *paths, size_
             if (sscanf(c->err.c_str(), "input %zu", &i) == 1 && i < cnt)
                 return fail_at(first + i, rg_set_err(c, RG_ERR_FORMAT, "Failed to probe format: %s", paths[first + i]));
         }
-        if (rc != RG_OK) return fail_at(first, rc);
+        if (rc != RG_OK) return rc;  // not a file's failure: *failed_index stays (size_t)-1, so that a node prefers real file errors of other shares
         const double t2 = now();
         if (groups.size() <= 1) rc = rg_album_local_pcm(c, descs.data(), cnt, c->d_arena.p, arena_bytes, 1, tracks_out);
         else rc = rg_album_part(c, descs.data(), cnt, c->d_arena.p, arena_bytes, g, groups.size(), tracks_out + first);
-        if (rc != RG_OK) return fail_at(first, rc);
+        if (rc != RG_OK) return rc;  // not a file's failure: *failed_index stays (size_t)-1, so that a node prefers real file errors of other shares
         for (size_t i = 0; i < cnt; ++i) tracks_out[first + i].file_type = in[i].is_mp4 ? RG_FILE_AAC : RG_FILE_MP3;
         if (trace) fprintf(stderr, "[rg_analyze_album] analysis %.1f ms\n", (now() - t2) * 1e3);
     }

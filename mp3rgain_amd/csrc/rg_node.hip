@@ -112,6 +112,13 @@ extern "C" rg_node *rg_node_create_backend(const rg_node_backend *backend, const
         g_node_create_error = "rg_node_create_backend: incomplete backend or empty device list";
         return nullptr;
     }
+    if (backend != &kCtxBackend) {  // engines other than the library's own contexts: a test seam (tests/test_node_cpu.py)
+        const char *seams = getenv("MP3RGAIN_AMD_TEST_SEAMS");
+        if (!(seams && seams[0] == '1')) {
+            g_node_create_error = "rg_node_create_backend: foreign engines are a test seam (MP3RGAIN_AMD_TEST_SEAMS=1)";
+            return nullptr;
+        }
+    }
     rg_node *nd = new rg_node;
     nd->be = *backend;
     nd->builtin = backend == &kCtxBackend;

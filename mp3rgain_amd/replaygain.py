@@ -390,8 +390,13 @@ class Analyzer:
         import torch.distributed as dist
 
         lib = library or os.environ.get("MP3RGAIN_AMD_RCCL_LIBRARY") or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        lib_rc = self._lib.rg_comm_library(os.fsencode(lib)) if os.path.exists(lib) else 0
         explicit = bool(library or os.environ.get("MP3RGAIN_AMD_RCCL_LIBRARY"))
+        # a library named explicitly must exist and load: silently going on with whatever librccl.so resolves instead (real
+        # RCCL where the stand-in was meant refuses two ranks on one device) would fail on some ranks only
+        if os.path.exists(lib):
+            lib_rc = self._lib.rg_comm_library(os.fsencode(lib))
+        else:
+            lib_rc = -1 if explicit else 0
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         src = dist.get_global_rank(group, 0) if group is not None else 0
         uid = b""

@@ -1,7 +1,13 @@
 import sys
 from pathlib import Path
 
+import os
+
 import pytest
+
+# the tests drive two seams of the shipped ABI that production refuses: a stand-in for librccl.so (rg_comm_library) and
+# foreign node engines (rg_node_create_backend); subprocesses inherit the switch
+os.environ.setdefault("MP3RGAIN_AMD_TEST_SEAMS", "1")
 
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:

@@ -171,3 +171,24 @@ def test_damaged_containers_never_crash():
                 assert o + s <= len(d)
         except demux.DemuxError:
             pass
+
+
+def test_sample_table_that_describes_more_bytes_than_the_file_is_refused():
+    """A crafted table (fixed sample size 1, count 2^32 - 1, every chunk at the same offset) must come back as a format
+    error at once -- not as four billion access units for the caller to allocate (rg_files.hip walked such a table twice)."""
+    rng = random.Random(7)
+    data = bytearray(M.build_mp4([M.Track("mp3", _samples(rng, 20, fixed=96), fixed_size=True, per_chunk=(1,) * 20)]))
+    z = data.index(b"stsz")
+    struct.pack_into(">II", data, z + 8, 1, 0xFFFFFFFF)          # sample_size = 1, sample_count = 2^32 - 1
+    c = data.index(b"stsc")
+    (runs,) = struct.unpack_from(">I", data, c + 8)
+    for r in range(runs):
+        struct.pack_into(">I", data, c + 12 + 12 * r + 4, 1000)  # samples_per_chunk of every run: a chunk stays inside the file
+    o = data.index(b"stco")
+    (chunks,) = struct.unpack_from(">I", data, o + 8)
+    (first,) = struct.unpack_from(">I", data, o + 12)
+    for k in range(chunks):
+        struct.pack_into(">I", data, o + 12 + 4 * k, first)      # every chunk at the same place: the walk never runs off the file
+    assert chunks == 20
+    with pytest.raises(demux.DemuxError):
+        demux.mp4_access_units(bytes(data), 0)
