@@ -16,8 +16,10 @@ in HBM (generated there by the library's rg_synth kernel; include/rg_synth.h):
            kernels the [12 000-bin album histogram | album peak] packs of all ranks are all-gathered
            over RCCL (one collective, on the stream of the batch) and folded on the device (sum / max),
            then every rank runs the album percentile.  `--scaling strong --total-tracks T` keeps the
-           album fixed instead and shards it by cumulative frames.  One rank per GPU, launched by
-           torch.distributed.run.
+           album fixed instead and shards it by cumulative frames (configs[3]'s 8000-track album on N GPUs:
+           `--scaling strong --total-tracks 8000`); both curves can come out of one 8-GPU lease.  One rank per GPU,
+           launched by torch.distributed.run.  Every N > 1 line carries `exchange` (ranks of the library's communicator,
+           transport, ncclGetVersion), `parity` (rank 0's first tracks against the oracle, bin for bin) and `cpu_baseline`.
 
 Timing: an untimed pre-roll (0.25 s worth of steps, so that clock and power have settled), W warm-up
 steps, then exactly K steps between barrier + torch.cuda.synchronize() pairs; the time is the MAX
@@ -219,7 +221,45 @@ def mp3_end_to_end(an, nfiles: int) -> dict:
     return leg
 
 
+def cpu_baseline_leg(po, l0, r0, rate0: int, fr0: int, label: str, cpu_seconds: float) -> dict:
+    """The CPU oracle (oracle/rg_oracle.c, a C restatement of replaygain.rs -- not the Rust binary) on a bounded sample of the
+    workload: one of its tracks, repeated for `cpu_seconds` on one thread (the reference is single-threaded), then
+    the same code on every usable host core with tracks as the parallel unit."""
+    c0 = time.perf_counter()
+    reps = 0
+    while True:
+        po.analyze_pcm(l0, r0, rate0)
+        reps += 1
+        if time.perf_counter() - c0 >= cpu_seconds:
+            break
+    cdt = time.perf_counter() - c0
+    from concurrent.futures import ThreadPoolExecutor
+
+    nthr = _usable_cores()
+    per_thread = max(1, int(reps * min(1.0, 4.0 / max(cdt, 1e-9))))  # about 4 s per thread
+    m0 = time.perf_counter()
+    with ThreadPoolExecutor(nthr) as pool:  # ctypes releases the GIL inside the C call
+        list(pool.map(lambda _: [po.analyze_pcm(l0, r0, rate0) for _ in range(per_thread)], range(nthr)))
+    mdt = time.perf_counter() - m0
+    return {"value": fr0 * reps / cdt, "unit": "stereo samples/s", "cores": 1, "kind": "port",
+            "sample": f"{label} ({fr0} stereo frames @{rate0 / 1000:g} kHz) x{reps} = {cdt:.1f} s, "
+                      f"oracle/rg_oracle.c (C restatement of replaygain.rs, not the Rust binary), 1 thread, "
+                      f"host has {os.cpu_count()} cores, {_usable_cores()} usable by this process",
+            "all_cores": {"value": fr0 * per_thread * nthr / mdt, "cores": nthr,
+                          "sample": f"the same track x{per_thread} on each of {nthr} threads (tracks as the parallel unit)"}}
+
+
+def exchange_block(an, transport: str) -> dict:
+    """What the album exchange of a multi-GPU line ran over: ranks the library's communicator spans, the transport, the
+    collective library's version (ncclGetVersion; 0 = the library has no such entry point, e.g. the tests' stand-in)."""
+    info = an.comm_info()
+    return {"ranks": info["ranks"], "transport": transport, "nccl_version": info["nccl_version"],
+            "collective": "one all-gather of 12 002-word [histogram | peak] packs + device fold, on the batch's stream"}
+
+
 def node_main(args) -> int:
+    import numpy as np
+
     """`--node` / `--gpus N` without torch.distributed.run: the album workload of configs[3] in ONE process.  A node
     (mp3rgain_amd.Node: one context per GPU) with the library's in-process RCCL communicators (ncclCommInitAll), one host
     thread per GPU: every thread fills its device's arena with its share of the album (tracks i, i + N, ...), and a step is
@@ -292,10 +332,13 @@ def node_main(args) -> int:
             dt = time.perf_counter() - t0
             ks, kl, ksp = an.timing_read(reset=True)
             an.timing_enable(False)
-            res = an.collect(ntr)
+            res, hists = an.collect(ntr, want_hist=True) if i == 0 else (an.collect(ntr), None)
             alb = an.album_finish()
+            npar = min(args.parity_tracks, ntr)
             out[i] = {"dt": dt, "frames": frames * ntr, "k": (ks, kl, ksp), "album": alb, "first": res[0] if res else None,
-                      "flagged": sum(1 for r in res if r.flags & 2)}
+                      "flagged": sum(1 for r in res if r.flags & 2), "seeds": [0x5EED0000 + g for g in mine[:npar]],
+                      "res": res[:npar], "hists": hists[:npar].copy() if hists is not None else None,
+                      "exchange": exchange_block(an, "rccl (library communicators of this process, ncclCommInitAll)")}
         except Exception as ex:  # noqa: BLE001
             errors.append(f"device {i}: {ex}")
             gate.abort()
@@ -313,6 +356,23 @@ def node_main(args) -> int:
     tag = workload_tag(args.tracks_per_rank, frames, True)
     roof = roofline_block(out[0]["frames"], ks, kl, ksp, tag)
     alb0 = out[0]["album"]
+    parity = cpu = None
+    if args.cpu_seconds > 0 and out[0]["seeds"]:
+        # device 0's first tracks of the album (global indices 0, n_dev, 2 n_dev, ...) against the oracle, bin for bin
+        from oracle import pyoracle as po
+
+        diff_bins, max_db, peaks_equal = 0, 0.0, True
+        for seed_t, r_t, h_t in zip(out[0]["seeds"], out[0]["res"], out[0]["hists"]):
+            l, r = po.synth_f32(seed_t, 0, RATE, frames), po.synth_f32(seed_t, 1, RATE, frames)
+            want, want_hist = po.analyze_pcm(l, r, RATE)
+            diff_bins += int(np.count_nonzero(h_t != want_hist))
+            max_db = max(max_db, abs(r_t.loudness_db - want["loudness_db"]))
+            peaks_equal = peaks_equal and r_t.peak == want["peak"]
+        parity = {"tracks_compared": len(out[0]["seeds"]), "which": "device 0's first tracks of the album", "differing_histogram_bins": diff_bins,
+                  "max_abs_db_delta": max_db, "peaks_equal": peaks_equal,
+                  "every_device_agrees_on_the_album": len({(o["album"].album_loudness_db, o["album"].album_peak) for o in out}) == 1,
+                  "tracks_flagged_imprecise": sum(o["flagged"] for o in out)}
+        cpu = cpu_baseline_leg(po, l, r, RATE, frames, "one track of the album", args.cpu_seconds)
     line = {
         "metric": "stereo PCM samples/s through IIR+RMS+histogram", "value": total_frames / dt, "unit": "stereo samples/s",
         "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -323,7 +383,9 @@ def node_main(args) -> int:
                              "library's in-process RCCL communicators (ncclCommInitAll)",
                    "tracks_per_gpu": args.tracks_per_rank, "album_tracks": total_tracks},
         "roofline": roof,
-        "cpu_baseline": None,  # measured by the default run (N = 1, one rank)
+        "exchange": out[0]["exchange"],
+        "cpu_baseline": cpu,
+        "parity": parity,
         "result": {"album_loudness_db": alb0.album_loudness_db if alb0 else None,
                    "album_gain_db": alb0.album_gain_db if alb0 else None,
                    "every_device_agrees": len({(o["album"].album_loudness_db, o["album"].album_peak) for o in out}) == 1,
@@ -528,7 +590,10 @@ def main() -> int:
         an.timing_enable(False)
         return dt_, ks, kl, ksp
 
-    dt, k1_ms_sum, k1_launches, k1_span_ms = timed(step, args.steps, args.warmup, max(1, batch_frames))
+    # (the pre-roll's step count must be the same on every rank -- each step is a collective -- so it is sized from the
+    # album's frames per rank, not from this rank's share, which differs under --scaling strong)
+    dt, k1_ms_sum, k1_launches, k1_span_ms = timed(step, args.steps, args.warmup,
+                                                   max(1, batch_frames if world == 1 else (total_tracks * frames) // world))
 
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -658,30 +723,7 @@ def main() -> int:
                       "note": "async enqueue/collect path: a flagged track may have windows off by <= 3 bins (0.03 dB); "
                               "the synchronous entry points re-run flagged tracks on the order-faithful kernel"}
             # ---- CPU baseline: a bounded sample of the same workload (one of its tracks, repeated) ----
-            c0 = time.perf_counter()
-            reps = 0
-            while True:
-                po.analyze_pcm(l0, r0, rate0)
-                reps += 1
-                if time.perf_counter() - c0 >= args.cpu_seconds:
-                    break
-            cdt = time.perf_counter() - c0
-            # the reference is single-threaded; with tracks as the parallel unit the same code on every
-            # host core is the most a CPU deployment could do, so that figure is reported next to it
-            from concurrent.futures import ThreadPoolExecutor
-
-            nthr = _usable_cores()
-            per_thread = max(1, int(reps * min(1.0, 4.0 / max(cdt, 1e-9))))  # about 4 s per thread
-            m0 = time.perf_counter()
-            with ThreadPoolExecutor(nthr) as pool:  # ctypes releases the GIL inside the C call
-                list(pool.map(lambda _: [po.analyze_pcm(l0, r0, rate0) for _ in range(per_thread)], range(nthr)))
-            mdt = time.perf_counter() - m0
-            cpu = {"value": fr0 * reps / cdt, "unit": "stereo samples/s", "cores": 1, "kind": "port",
-                   "sample": f"track {t0_} of the batch ({fr0} stereo frames @{rate0 / 1000:g} kHz) x{reps} = {cdt:.1f} s, "
-                             f"oracle/rg_oracle.c (C restatement of replaygain.rs, not the Rust binary), 1 thread, "
-                             f"host has {os.cpu_count()} cores, {_usable_cores()} usable by this process",
-                   "all_cores": {"value": fr0 * per_thread * nthr / mdt, "cores": nthr,
-                                 "sample": f"the same track x{per_thread} on each of {nthr} threads (tracks as the parallel unit)"}}
+            cpu = cpu_baseline_leg(po, l0, r0, rate0, fr0, f"track {t0_} of the batch", args.cpu_seconds)
         if args.mixed:
             wl = (f"configs[4], PCM side: {ntr} synthetic {args.minutes:g}-min tracks per GPU, half 44.1 kHz and half 48 kHz, every 10th mono, "
                   f"every 20th clipped at full scale (peak >= 1.0), {pcm_bytes / 1e9:.1f} GB planar f32 resident in HBM; "
@@ -712,6 +754,9 @@ def main() -> int:
                 "mode": "album (-a): RCCL all-gather of the per-rank [12000-bin histogram | peak] packs + device fold" if album else "track (-r)",
                 "exchange": exchange,
             },
+            "exchange": (exchange_block(an, "rccl (library communicator, ncclCommInitRank, bootstrapped over torch.distributed)" if exchange.startswith("rccl")
+                                        else "torch.distributed all_gather_into_tensor + device fold (library communicator unavailable)")
+                         if album else None),
             "roofline": roof,
             "one_shot": one_shot,
             "cpu_baseline": cpu,

@@ -236,6 +236,9 @@ int rg_comm_library(const char *librccl_path);
 int rg_comm_unique_id(void *id_out /* RG_COMM_ID_BYTES */);
 int rg_comm_init(rg_ctx *ctx, const void *id /* RG_COMM_ID_BYTES */, int world, int rank);
 int rg_comm_destroy(rg_ctx *ctx);
+/* ranks the context's communicator spans (0 = none) and the collective library's version (ncclGetVersion, 0 = unknown):
+ * what a multi-GPU benchmark line states about its exchange */
+int rg_comm_info(rg_ctx *ctx, int *world_out, int *version_out);
 int rg_album_exchange(rg_ctx *ctx);
 /* The same exchange as ONE collective: d_album_hist and d_album_peak are contiguous (12000 u32 + one f64 =
  * 12002 words, RG_ALBUM_PACK_WORDS).  All-gather every rank's pack (ncclAllGather / all_gather_into_tensor),

@@ -124,6 +124,7 @@ SYMBOLS = [
     ("rg_comm_unique_id", _int, [_vp]),
     ("rg_comm_init", _int, [_vp, _vp, _int, _int]),
     ("rg_comm_destroy", _int, [_vp]),
+    ("rg_comm_info", _int, [_vp, _P(_int), _P(_int)]),
     ("rg_album_exchange", _int, [_vp]),
     ("rg_album_reduce_gathered", _int, [_vp, _vp, _u32]),
     ("rg_album_result_enqueue", _int, [_vp]),

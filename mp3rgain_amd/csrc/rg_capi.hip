@@ -547,6 +547,21 @@ extern "C" int rg_comm_destroy(rg_ctx *c) {
     return RG_OK;
 }
 
+// what the context's communicator is: ranks it spans (0 = none: single GPU, rg_album_exchange is a no-op) and the version the
+// resolved library reports (ncclGetVersion; 0 when it has no such entry point, as the tests' stand-in)
+extern "C" int rg_comm_info(rg_ctx *c, int *world_out, int *version_out) {
+    if (!c) return RG_ERR_INVALID_ARG;
+    if (world_out) *world_out = c->comm ? c->comm_world : 0;
+    if (version_out) {
+        *version_out = 0;
+        typedef int (*nccl_version_fn)(int *);
+        nccl_version_fn f = c->comm ? (nccl_version_fn)resolve("ncclGetVersion") : nullptr;
+        int v = 0;
+        if (f && f(&v) == 0) *version_out = v;
+    }
+    return RG_OK;
+}
+
 extern "C" int rg_comm_init(rg_ctx *c, const void *id, int world, int rank) {
     if (!c || !id || world < 1 || rank < 0 || rank >= world) return RG_ERR_INVALID_ARG;
     nccl_init_rank_fn f = (nccl_init_rank_fn)resolve("ncclCommInitRank");

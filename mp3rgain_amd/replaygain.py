@@ -422,6 +422,12 @@ class Analyzer:
             self.comm_destroy()
             raise err or ReplayGainError(-7, "ncclCommInitRank failed on another rank")
 
+    def comm_info(self) -> dict:
+        """{"ranks": ranks of the context's communicator (0 = none), "nccl_version": ncclGetVersion of the library behind it}"""
+        w, v = C.c_int(0), C.c_int(0)
+        self._check(self._lib.rg_comm_info(self._ctx, C.byref(w), C.byref(v)))
+        return {"ranks": int(w.value), "nccl_version": int(v.value)}
+
     def comm_destroy(self):
         self._check(self._lib.rg_comm_destroy(self._ctx))
 

@@ -180,17 +180,39 @@ def test_bench_rank_mode_rehearsal(standin, oracle, world):
     loud, peak = _album_oracle(oracle, tracks_per_rank * world, frames)
     assert o["result"]["album_loudness_db"] == loud and o["result"]["album_peak"] == peak
     assert o["parity"]["differing_histogram_bins"] == 0 and o["parity"]["peaks_equal"]
+    # what an auditor of the first real SCALE run needs in the line itself: the communicator's size, the transport, the CPU leg
+    assert o["exchange"]["ranks"] == world and o["exchange"]["transport"].startswith("rccl") and "nccl_version" in o["exchange"]
+    assert o["cpu_baseline"]["cores"] == 1 and o["cpu_baseline"]["value"] > 0
+
+
+def test_bench_strong_scaling_rehearsal(standin, oracle):
+    """`--scaling strong --total-tracks T`: the album is fixed and sharded by cumulative frames; the line says so."""
+    total, minutes, world = 7, 0.1, 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), "bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "1", "--scaling", "strong",
+           "--total-tracks", str(total), "--minutes", str(minutes), "--cpu-seconds", "0", "--pre-roll", "0.001"]
+    p = subprocess.run(cmd, cwd=str(ROOT), env=_bench_env(standin), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:]
+    o = _json_line(p.stdout)
+    frames = int(round(minutes * 60 * RATE))
+    assert o["scaling"] == "strong" and o["config"]["total_tracks"] == total and o["exchange"]["ranks"] == world
+    assert o["value"] == pytest.approx(total * frames * 3 / (o["ms_per_step"] * 3e-3), rel=1e-9)
+    loud, peak = _album_oracle(oracle, total, frames)
+    assert o["result"]["album_loudness_db"] == loud and o["result"]["album_peak"] == peak
 
 
 def test_bench_node_mode_rehearsal(standin, oracle):
     """`bench.py --node --gpus 3` with three contexts on device 0: in-process communicators, one host thread per context."""
     tracks_per_rank, minutes = 2, 0.1
     cmd = [sys.executable, "bench.py", "--node", "--gpus", "3", "--steps", "4", "--warmup", "2", "--tracks-per-rank", str(tracks_per_rank),
-           "--minutes", str(minutes), "--pre-roll", "0.001"]
+           "--minutes", str(minutes), "--pre-roll", "0.001", "--cpu-seconds", "0.2", "--parity-tracks", "2"]
     p = subprocess.run(cmd, cwd=str(ROOT), env=_bench_env(standin), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:]
     o = _json_line(p.stdout)
     frames = int(round(minutes * 60 * RATE))
     assert o["n_gpus"] == 3 and "rehearsal" in o and o["result"]["every_device_agrees"]
+    assert o["exchange"]["ranks"] == 3 and o["exchange"]["transport"].startswith("rccl")
+    assert o["parity"]["differing_histogram_bins"] == 0 and o["parity"]["peaks_equal"] and o["parity"]["every_device_agrees_on_the_album"]
+    assert o["cpu_baseline"]["cores"] == 1 and o["cpu_baseline"]["value"] > 0
     loud, _ = _album_oracle(oracle, tracks_per_rank * 3, frames)
     assert o["result"]["album_loudness_db"] == loud
