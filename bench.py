@@ -122,9 +122,12 @@ def roofline_block(frames_per_launch: int, k_ms_sum: float, k_launches: int, k_s
               "valu_wave_insts_per_launch": pm["valu_insts_per_launch"]}
         fma = pm.get("fma_f64_insts_per_launch")
         if fma:
+            # the servo-form stage has two adds and one multiply among its 26 FP64 operations per channel-sample
+            addmul = (pm.get("add_f64_insts_per_launch") or 0.0) + (pm.get("mul_f64_insts_per_launch") or 0.0)
             ex["fma_f64_wave_insts_per_launch"] = fma
             ex["fma_f64_per_channel_sample"] = fma * launches_per_step * 64.0 / chs
-            ex["tflops"] = 2.0 * 64.0 * fma * k_launches / span_s / 1e12 if span_s > 0 else 0.0
+            ex["fp64_ops_per_channel_sample"] = (fma + addmul) * launches_per_step * 64.0 / chs
+            ex["tflops"] = 64.0 * (2.0 * fma + addmul) * k_launches / span_s / 1e12 if span_s > 0 else 0.0
             ex["frac_of_peak"] = ex["tflops"] / FP64_PEAK_TFLOPS
         else:  # no FP64-specific counter: every VALU instruction priced as an FMA (upper bound on the flops)
             ex["tflops_upper_bound"] = 2.0 * 64.0 * pm["valu_insts_per_launch"] * k_launches / span_s / 1e12 if span_s > 0 else 0.0
@@ -421,6 +424,7 @@ def main() -> int:
     ap.add_argument("--parity-tracks", type=int, default=16, help="tracks of the batch whose full histogram is compared with the oracle")
     ap.add_argument("--no-configs1", action="store_true", help="skip the secondary configs[1] measurement")
     ap.add_argument("--no-mp3", action="store_true", help="skip the MP3 end-to-end leg (decode + analysis from compressed files)")
+    ap.add_argument("--no-one-shot", action="store_true", help="skip the synchronous-call leg (profiling passes of the pipelined workload)")
     ap.add_argument("--mp3-files", type=int, default=256, help="files of the MP3 end-to-end leg (3-minute 320 kb/s streams; the two host-bound routes run on the first 64)")
     ap.add_argument("--configs1-steps", type=int, default=300)
     ap.add_argument("--pre-roll", type=float, default=PRE_ROLL_SECONDS, help="untimed pre-roll before the warm-up steps, seconds of work")
@@ -609,7 +613,7 @@ def main() -> int:
     # ---- one batch in flight: the synchronous entry point (rg_analyze_pcm_batch on the resident arena) -- the shape the
     # reference's blocking API has.  Nothing overlaps here: the dominant kernel's HIP-event duration IS one launch alone.
     one_shot = None
-    if world == 1 and not album and ntr > 0:
+    if world == 1 and not album and ntr > 0 and not args.no_one_shot:
         for _ in range(3):
             an.analyze_device(descs, ntr, pcm.data_ptr(), pcm_bytes)
         an.timing_enable(True)

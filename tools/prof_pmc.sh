@@ -9,7 +9,7 @@
 #   <round>_<tag>_pmc_summary.txt    every counter, every kernel
 # Each counter group is its own rocprofv3 run (no trace domains combined with --pmc), each under a timeout.
 TAG=$1; FRAMES=$2; shift 2
-export PROF_ROUND=${PROF_ROUND:-r03}
+export PROF_ROUND=${PROF_ROUND:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=gpurun_out/prof_$TAG
 cd /tmp && export TMPDIR=/tmp
@@ -17,11 +17,20 @@ export PROFILES_DIR=$R/gpurun_out/profiles   # only gpurun_out/ travels back: co
 mkdir -p $R/$OUT $PROFILES_DIR
 cd $R
 BENCH_ARGS="$*"
-run() { name=$1; shift; timeout ${PROF_TIMEOUT:-400} rocprofv3 "$@" -d $OUT/$name --output-format csv -- python bench.py --cpu-seconds 0 --no-configs1 --no-mp3 $BENCH_ARGS $EXTRA > $OUT/$name.log 2>&1 || echo "$name failed/timeout"; }
+# (--no-one-shot: the bench's synchronous leg launches the same kernel with another choice of windows per lane; the passes
+# below describe the pipelined workload's launches only, the pass kt1 the synchronous one)
+run() { name=$1; shift; timeout ${PROF_TIMEOUT:-400} rocprofv3 "$@" -d $OUT/$name --output-format csv -- python bench.py --cpu-seconds 0 --no-configs1 --no-mp3 --no-one-shot $BENCH_ARGS $EXTRA > $OUT/$name.log 2>&1 || echo "$name failed/timeout"; }
 EXTRA="${KT_EXTRA:-}"
 run kt --kernel-trace --stats
-EXTRA="${KT_EXTRA:-} --slots 1"
-run kt1 --kernel-trace --stats   # one pipeline slot: every launch alone
+# one launch alone.  ONESHOT="<tracks> <minutes>" (set for cfg2 / cfg1 below): the synchronous entry point on the same batch
+case "$TAG" in cfg2) ONESHOT=${ONESHOT:-"1000 3"};; cfg1) ONESHOT=${ONESHOT:-"1 10"};; esac
+if [ -n "$ONESHOT" ]; then
+  export KT1_CMD_TEXT="rocprofv3 --kernel-trace --stats -- python tools/ubench/oneshot_one.py $ONESHOT 0 30"
+  timeout ${PROF_TIMEOUT:-400} rocprofv3 --kernel-trace --stats -d $OUT/kt1 --output-format csv -- python tools/ubench/oneshot_one.py $ONESHOT 0 30 > $OUT/kt1.log 2>&1 || echo "kt1 failed/timeout"
+else
+  EXTRA="${KT_EXTRA:-} --slots 1"
+  run kt1 --kernel-trace --stats   # one pipeline slot: every launch alone
+fi
 # the counter passes serialise the dispatches and write one row per dispatch and counter: a short pre-roll and few
 # timed steps keep them small (the counters are per dispatch, they do not depend on how many there are)
 EXTRA="${PMC_EXTRA:---pre-roll 0.01 --steps 6 --warmup 1}"

@@ -87,11 +87,14 @@ if spans:
                                   "hbm_frac_span": algo / (step_ms * 1e-3) / 8e12,
                                   "bench_line_frac_same_run": bench_line["roofline"]["frac"],
                                   "bench_line_kernel_ms_same_run": bench_line["roofline"]["kernel_ms"]}
-    # one launch alone: the same command with one pipeline slot (--slots 1), where launches cannot overlap (pass kt1)
+    # one launch alone (pass kt1): the synchronous entry point over the same resident batch (tools/ubench/oneshot_one.py,
+    # rg_analyze_pcm_batch: one batch in flight, the library's own choice of windows per lane), or the bench command with one
+    # pipeline slot; either way launches cannot overlap and the stats file's average IS a launch alone
+    kt1_cmd = os.environ.get("KT1_CMD_TEXT") or (doc["command"] + " --slots 1")
     for f in newest(f"{d}/kt1/*/*kernel_stats.csv"):
         for r in csv.DictReader(open(f)):
             if MAIN in r["Name"]:
-                doc["one_launch_alone"] = {"command": doc["command"] + " --slots 1", "calls": int(r["Calls"]),
+                doc["one_launch_alone"] = {"command": kt1_cmd, "calls": int(r["Calls"]),
                                            "avg_duration_ms": float(r["AverageNs"]) / 1e6, "min_ms": float(r["MinNs"]) / 1e6,
                                            "achieved_GBps": frames * 8 / (float(r["AverageNs"]) * 1e-9) / 1e9,
                                            "hbm_frac": frames * 8 / (float(r["AverageNs"]) * 1e-9) / 8e12}
