@@ -168,7 +168,7 @@ int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out, u
     g.aff_lin = D.servo ? 2.0 * D.dinf / D.beta : 0.0;
     g.aff_n = D.servo ? D.dinf * D.dinf : 0.0;
     g.aff_sig = D.servo ? 2.0 * D.dinf : 0.0;
-    if (m > 1 && rg_tm_lds_bytes(D.L, D.H10, g.block) > RG_TM_LDS_BYTES) {  // multi-window segments run on the LDS path only
+    if (m > 1 && rg_tm_lds_bytes(D.L, D.H10, g.block, m) > RG_TM_LDS_BYTES) {  // multi-window segments run on the LDS path only
         tb->design.ok = false;
         return RG_ERR_INVALID_ARG;
     }
@@ -273,7 +273,7 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
         if (!c->one_shot) waves *= c->n_slots < RG_SLOT_STREAMS ? c->n_slots : RG_SLOT_STREAMS;
         const double cost = (double)stride * 28.0 + (double)L * 2.0 + (double)std::min(L, H10) * 10.0 + 1500.0 + 1500.0 + 60.0 * (m - 1);
         // residency: the LDS image of the response tables + one 4 KiB tile per wave bound the blocks per CU
-        const double lds = (double)rg_tm_lds_bytes(L, Hl, block);
+        const double lds = (double)rg_tm_lds_bytes(L, Hl, block, m);
         if (m > 1 && lds > (double)RG_TM_LDS_BYTES) continue;
         // waves per SIMD that can be resident: three narrow blocks, or one wide block, per CU
         const double blocks_cu = block == RG_TM_BLOCK ? std::max(1.0, std::min(3.0, floor((double)RG_TM_LDS_BYTES / lds))) : (double)block / 256.0;

@@ -268,7 +268,7 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
                                              const __attribute__((address_space(1))) typename Fmt<FMT>::elem *rowp,
                                              const uint32_t len,
                                              const double *__restrict__ T12, const double *__restrict__ T2,
-                                             char *const wtile /* RG_TM_WAVE_TILE_BYTES */) {
+                                             char *const wtile /* RG_TM_WAVE_TILE_BYTES, twice that when !MOM */) {
     typedef Fmt<FMT> F;
     typedef const __attribute__((address_space(1))) typename F::elem gelem;
     const int lane = threadIdx.x & 63;
@@ -290,7 +290,14 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
     const int rswz = (lane >> 2) & 3;
     const uint32_t ntiles = (L + RG_TM_TILE - 1) / RG_TM_TILE;
 
-    rg_u32x4 stage[4];  // four samples of one row as 32-bit LDS words (float bits, or sign-extended integers)
+    // Staging registers: four samples of one row as 32-bit LDS words (float bits, or sign-extended integers) per load.
+    // Windows without moments (MOM == false) have TWO sets and two LDS slots: the twelve moments' registers are dead there.
+    // A pair of tiles goes to LDS together, the loads of the next pair are issued at once and have TWO tile periods to land,
+    // not one -- a wave stalls on the slowest of its outstanding 64-byte requests, and with one period (about 3 us at three
+    // waves per SIMD) the tail of the HBM latency distribution showed: the same launch with every descriptor pointing at one
+    // track's PCM (Infinity Cache resident) ran 17 % faster (tools/ubench/alias_tracks.py).
+    constexpr int NSTAGE = MOM ? 1 : 2;
+    rg_u32x4 stage[NSTAGE][4];
     auto load4 = [&](gelem *src) -> rg_u32x4 {
         if constexpr (FMT == RG_FMT_S16_PLANAR) {
             const rg_s16x4u v = *(const __attribute__((address_space(1))) rg_s16x4u *)src;
@@ -299,7 +306,9 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
             return *(const __attribute__((address_space(1))) rg_u32x4u *)src;
         }
     };
-    auto load_tile = [&](uint32_t tile) {
+    auto load_tile = [&](uint32_t tile, auto buf, auto whole) {
+        constexpr int SB = decltype(buf)::value;
+        constexpr bool WHOLE = decltype(whole)::value;  // the tile is known to be a whole one: no guards
         const uint32_t n0 = tile * RG_TM_TILE;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -308,39 +317,41 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
             const uint32_t pn = n0 + 4u * piece;  // frame index of the piece within its row
             if (!TAIL) {
                 // pieces starting past the row's end are never read; only the last tile can have such pieces
-                if (n0 + RG_TM_TILE <= L || pn < L) stage[q] = load4(lfirst[q] + n0);
+                if (WHOLE || n0 + RG_TM_TILE <= L || pn < L) stage[SB][q] = load4(lfirst[q] + n0);
             } else {
                 gelem *src = lfirst[q] + n0;
                 if (pn + 4u <= llen[q]) {
-                    stage[q] = load4(src);
+                    stage[SB][q] = load4(src);
                 } else {
-                    stage[q].x = pn + 0u < llen[q] ? F::word(src[0]) : 0u;
-                    stage[q].y = pn + 1u < llen[q] ? F::word(src[1]) : 0u;
-                    stage[q].z = pn + 2u < llen[q] ? F::word(src[2]) : 0u;
-                    stage[q].w = pn + 3u < llen[q] ? F::word(src[3]) : 0u;
+                    stage[SB][q].x = pn + 0u < llen[q] ? F::word(src[0]) : 0u;
+                    stage[SB][q].y = pn + 1u < llen[q] ? F::word(src[1]) : 0u;
+                    stage[SB][q].z = pn + 2u < llen[q] ? F::word(src[2]) : 0u;
+                    stage[SB][q].w = pn + 3u < llen[q] ? F::word(src[3]) : 0u;
                 }
             }
         }
     };
-    auto store_tile = [&]() {
+    // staging set SB -> LDS slot SB of the wave
+    auto store_tile = [&](auto buf) {
+        constexpr int SB = decltype(buf)::value;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<uint4 *>(wtile + q * 1024 + lane * 16) = make_uint4(stage[q].x, stage[q].y, stage[q].z, stage[q].w);
+            *reinterpret_cast<uint4 *>(wtile + SB * RG_TM_WAVE_TILE_BYTES + q * 1024 + lane * 16) =
+                make_uint4(stage[SB][q].x, stage[SB][q].y, stage[SB][q].z, stage[SB][q].w);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    auto read_piece = [&](int p) -> uint4 { return *reinterpret_cast<const uint4 *>(rrow + 16 * (p ^ rswz)); };
+    auto read_piece = [&](int p, int slot) -> uint4 { return *reinterpret_cast<const uint4 *>(rrow + slot * RG_TM_WAVE_TILE_BYTES + 16 * (p ^ rswz)); };
 
     // One tile.  MODE 1: every piece of the tile lies below H (all 12 moments live); MODE 2: every piece lies at or
     // past H (slow pair only); MODE 0: decided per piece (the one tile H falls into, and the last tile of a row);
     // MODE 3: no moments, whole tile; MODE 4: no moments, the ragged last tile.
     // Whole-tile modes keep the piece loop on a single path: with both frame bodies behind a branch inside one
     // loop the register allocator reconciles the rotated filter state with 15 v_mov_b64 per piece on one of them.
-    auto run_tile = [&](const uint32_t tile, auto mode) {
+    auto compute_tile = [&](const uint32_t tile, auto mode, auto buf) {
         constexpr int MODE = decltype(mode)::value;
-        store_tile();                                // tile `tile` -> LDS (every read of the previous tile is behind us)
-        if (tile + 1 < ntiles) load_tile(tile + 1);  // in flight during this tile's arithmetic
+        constexpr int SLOT = decltype(buf)::value;
         const uint32_t n0 = tile * RG_TM_TILE;
         const int np = (MODE != 0 && MODE != 4) ? 4 : (L - n0 >= RG_TM_TILE ? 4 : (int)((L - n0) >> 2));  // full 4-frame pieces in this tile
         auto piece = [&](const int p, const uint4 v) {
@@ -371,18 +382,18 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
         if constexpr (MODE != 0 && MODE != 4) {
             // whole-tile modes: the four pieces are unrolled (no loop counter, no copy of the prefetched piece)
             uint4 v[4];
-            v[0] = read_piece(0);
+            v[0] = read_piece(0, SLOT);
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                if (p + 1 < 4) v[p + 1] = read_piece(p + 1);
+                if (p + 1 < 4) v[p + 1] = read_piece(p + 1, SLOT);
                 piece(p, v[p]);
             }
         } else {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (np) v = read_piece(0);
+            if (np) v = read_piece(0, SLOT);
 #pragma unroll 1
             for (int p = 0; p < np; ++p) {
-                const uint4 vn = p + 1 < np ? read_piece(p + 1) : v;
+                const uint4 vn = p + 1 < np ? read_piece(p + 1, SLOT) : v;
                 piece(p, v);
                 v = vn;
             }
@@ -391,7 +402,7 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
             // L & 3 trailing frames, in this (the last) tile
             for (uint32_t n = L & ~3u; n < L; ++n) {
                 const uint32_t o = n - n0;
-                const uint32_t f = *reinterpret_cast<const uint32_t *>(rrow + 16 * ((int)(o >> 2) ^ rswz) + 4 * (o & 3));
+                const uint32_t f = *reinterpret_cast<const uint32_t *>(rrow + SLOT * RG_TM_WAVE_TILE_BYTES + 16 * ((int)(o >> 2) ^ rswz) + 4 * (o & 3));
                 if (MODE == 4) {
                     tm_frame<FMT, 0, TAIL, true, SERVO>(st, f, pk, nullptr, K, n, len);
                 } else if (n < H) {
@@ -411,19 +422,45 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
     typedef std::integral_constant<int, 3> None;
     typedef std::integral_constant<int, 4> NoneRagged;
 
-    load_tile(0);
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, NSTAGE - 1> S1;
+    typedef std::false_type Guarded;
+    typedef std::true_type Whole;
+    // one tile: LDS <- its staging set (every read of what the slot held is behind us), the next load into that set, the arithmetic
+    auto run_tile = [&](const uint32_t tile, auto mode, auto buf) {
+        store_tile(buf);
+        if (tile + NSTAGE < ntiles) load_tile(tile + NSTAGE, buf, Guarded{});  // in flight during the next NSTAGE tiles' arithmetic
+        compute_tile(tile, mode, buf);
+    };
+    load_tile(0, S0{}, Guarded{});
     const uint32_t full_tiles = L / RG_TM_TILE;                         // tiles with four whole pieces
     uint32_t tile = 0;
     if constexpr (!MOM) {
-        for (; tile < full_tiles; ++tile) run_tile(tile, None{});
-        for (; tile < ntiles; ++tile) run_tile(tile, NoneRagged{});
+        if (ntiles > 1) load_tile(1, S1{}, Guarded{});
+        // pairs of whole tiles (the staging set is a compile-time choice: registers cannot be indexed): both to LDS, the
+        // next pair's eight loads issued together, two tiles of arithmetic under them
+        for (; tile + 3 < full_tiles; tile += 2) {
+            store_tile(S0{});
+            store_tile(S1{});
+            load_tile(tile + 2, S0{}, Whole{});
+            load_tile(tile + 3, S1{}, Whole{});
+            compute_tile(tile, None{}, S0{});
+            compute_tile(tile + 1, None{}, S1{});
+        }
+        // what is left, tile by tile: up to three whole tiles and the ragged last one; `tile` is even at every turn
+        while (tile < ntiles) {
+            if (tile < full_tiles) run_tile(tile, None{}, S0{}); else run_tile(tile, NoneRagged{}, S0{});
+            if (++tile >= ntiles) break;
+            if (tile < full_tiles) run_tile(tile, None{}, S1{}); else run_tile(tile, NoneRagged{}, S1{});
+            ++tile;
+        }
         return;
     }
     const uint32_t t12 = (H / RG_TM_TILE) < full_tiles ? H / RG_TM_TILE : full_tiles;  // tiles entirely below H
-    for (; tile < t12; ++tile) run_tile(tile, All12{});
-    if (tile < ntiles && (tile * RG_TM_TILE < H || tile >= full_tiles)) { run_tile(tile, Mixed{}); ++tile; }  // the tile H falls into
-    for (; tile < full_tiles; ++tile) run_tile(tile, All2{});
-    for (; tile < ntiles; ++tile) run_tile(tile, Mixed{});              // the ragged last tile
+    for (; tile < t12; ++tile) run_tile(tile, All12{}, S0{});
+    if (tile < ntiles && (tile * RG_TM_TILE < H || tile >= full_tiles)) { run_tile(tile, Mixed{}, S0{}); ++tile; }  // the tile H falls into
+    for (; tile < full_tiles; ++tile) run_tile(tile, All2{}, S0{});
+    for (; tile < ntiles; ++tile) run_tile(tile, Mixed{}, S0{});              // the ragged last tile
 }
 
 // MULTI = multi-window segments (G.m > 1); a separate instantiation, so that the one-window kernel's register
@@ -529,7 +566,7 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
             }
             const double *const T12 = reinterpret_cast<const double *>(smem);
             const double *const T2 = T12 + (size_t)H * 12;
-            char *const wtile = smem + (size_t)tbl_doubles * sizeof(double) + (threadIdx.x >> 6) * RG_TM_WAVE_TILE_BYTES;
+            char *const wtile = smem + (size_t)tbl_doubles * sizeof(double) + (threadIdx.x >> 6) * (RG_TM_WAVE_TILE_BYTES * (MULTI ? 2 : 1));
             // a 16-byte piece may reach up to 3 frames past its row: full rows that end exactly at the end
             // of the channel go through the element-wise staging of the TAIL variant too
             const bool plain = len == L && start + ((L + 3u) & ~3u) <= tr.frames;
@@ -680,7 +717,7 @@ rg_tm_plain_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restri
         st.t[0][1] = active ? r[(size_t)24 * total_recs] : 0.0;
         if (active) pk = F::peak_denorm(r[(size_t)25 * total_recs]);
     }
-    char *const wtile = smem + (threadIdx.x >> 6) * RG_TM_WAVE_TILE_BYTES;
+    char *const wtile = smem + (threadIdx.x >> 6) * (RG_TM_WAVE_TILE_BYTES * 2);
     auto note_nonfinite = [&](const double energy, const uint32_t unit, const bool counts) {
         const bool bad = counts && !(fabs(energy) <= 1.7976931348623157e308);
         if (__any(bad) && bad) atomicMax(&nonfinite[tracks[t].track_index], 0xFFFFFFFFu - unit);
@@ -1169,7 +1206,7 @@ static hipError_t launch_main_fmt(int nch, const RgTmCoef &K, const RgTmGeom &G,
                                   uint32_t total_windows, uint32_t *d_nonfinite, uint32_t *d_zero, uint64_t zero_count,
                                   int split, hipStream_t s) {
     // LDS: T12 (H10 x 12 doubles) + T2 ((L - H10) x 2 doubles) + one 4 KiB PCM tile per wave
-    size_t lds = rg_tm_lds_bytes(G.L, G.H10, G.block);
+    size_t lds = rg_tm_lds_bytes(G.L, G.H10, G.block, G.m);
     uint32_t lds_tables = lds <= RG_TM_LDS_BYTES ? 1u : 0u;
     if (!lds_tables) lds = 0;
     // the attribute belongs to the function ON THE CURRENT DEVICE: a node drives several devices from one process
@@ -1190,7 +1227,7 @@ static hipError_t launch_main_fmt(int nch, const RgTmCoef &K, const RgTmGeom &G,
         if (split) {  // windows 2..m at four waves per SIMD; the same lanes, in blocks of 256
             const uint64_t lanes = (uint64_t)grid * G.block;
             const uint32_t pgrid = (uint32_t)((lanes + RG_TM_BLOCK - 1) / RG_TM_BLOCK);
-            hipLaunchKernelGGL((rg_tm_plain_kernel<FMT, SERVO>), dim3(pgrid), dim3(RG_TM_BLOCK), (RG_TM_BLOCK / 64) * RG_TM_WAVE_TILE_BYTES, s, K, G,
+            hipLaunchKernelGGL((rg_tm_plain_kernel<FMT, SERVO>), dim3(pgrid), dim3(RG_TM_BLOCK), (RG_TM_BLOCK / 64) * RG_TM_WAVE_TILE_BYTES * 2, s, K, G,
                                d_tracks, n_tracks, d_rec, total_recs, d_win, total_windows, d_nonfinite);
         }
     } else {

@@ -126,13 +126,15 @@ struct RgTmFixTables {
     const double *ST;      // [L][12]  servo: prefix sums of the responses, ST[len-1] = sum_{n<len} T[n] (the affine cross term)
 };
 
-// LDS bytes of a main-kernel block of `block` threads, and the block size for an (L, H10) design
-static inline size_t rg_tm_lds_bytes(uint32_t L, uint32_t H10, uint32_t block) {
-    return ((size_t)H10 * 12 + (size_t)(L - H10) * 2) * sizeof(double) + (size_t)(block / 64) * RG_TM_WAVE_TILE_BYTES;
+// LDS bytes of a main-kernel block of `block` threads, and the block size for an (L, H10) design.  A wave of a
+// multi-window launch (m > 1) has TWO tile slots: the windows without moments keep two tiles in LDS and two in flight
+// (rg_k2_tm.hip: tm_fast_path).
+static inline size_t rg_tm_lds_bytes(uint32_t L, uint32_t H10, uint32_t block, uint32_t m = 1) {
+    return ((size_t)H10 * 12 + (size_t)(L - H10) * 2) * sizeof(double) + (size_t)(block / 64) * RG_TM_WAVE_TILE_BYTES * (m > 1 ? 2u : 1u);
 }
 static inline uint32_t rg_tm_choose_block(uint32_t L, uint32_t H10, uint32_t m = 1) {
-    if (3 * rg_tm_lds_bytes(L, H10, RG_TM_BLOCK) <= RG_TM_LDS_BYTES) return RG_TM_BLOCK;
+    if (3 * rg_tm_lds_bytes(L, H10, RG_TM_BLOCK, m) <= RG_TM_LDS_BYTES) return RG_TM_BLOCK;
     const uint32_t wide = m > 1 ? RG_TM_BLOCK_WIDE_MULTI : RG_TM_BLOCK_WIDE;
-    if (rg_tm_lds_bytes(L, H10, wide) <= RG_TM_LDS_BYTES) return wide;
+    if (rg_tm_lds_bytes(L, H10, wide, m) <= RG_TM_LDS_BYTES) return wide;
     return RG_TM_BLOCK;
 }
