@@ -28,7 +28,7 @@ Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (IIR+RMS+his
 events on the streams it is launched on.  It carries BOTH bounds: `hbm` (algorithmic 8 B per stereo frame /
 8 TB/s -- what BASELINE asks for) and `fp64` (algorithmic 108 flop per stereo frame / 78.6 TFLOP/s FP64
 vector FMA -- the one that binds: 13.5 flop/B is above the ridge).  `traffic` and the executed instruction
-counts come from committed PMC passes of THIS workload (profiles/r03_pmc_<workload>.json), else null.
+counts come from committed PMC passes of THIS workload (profiles/r04_pmc_<workload>.json), else null.
 `cpu_baseline` is the CPU oracle (a C restatement of the reference's sequential algorithm -- not the Rust
 binary, which cannot be built in this image) on a bounded sample of the same tracks.
 """
@@ -76,7 +76,7 @@ def _usable_cores() -> int:
 
 
 def workload_tag(ntr: int, frames: int, album: bool) -> str:
-    """Name under which PMC passes of a workload are committed (profiles/r03_pmc_<tag>.json)."""
+    """Name under which PMC passes of a workload are committed (profiles/r04_pmc_<tag>.json)."""
     if ntr == 1000 and frames == FRAMES_3MIN:
         return "cfg3_album" if album else "cfg2"
     if ntr == 1 and frames == FRAMES_10MIN:

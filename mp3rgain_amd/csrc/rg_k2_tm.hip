@@ -10,7 +10,8 @@
 //                       50 ms window, converts to the 0.01 dB bin (finish_window, src/replaygain.rs:743-765)
 //                       and merges equal bins in LDS before one global atomic per distinct bin.
 //
-// FP64 vector FMA bound (27 FMA + 1 convert per channel-sample, plus 2..12 moment FMAs); MFMA is
+// FP64 vector pipe: 26 operations + 1 convert per channel-sample with the Butterworth stage in servo form (rg_tm.h; 27
+// multiply-adds in the classic form kept for four rates), plus 2..12 moment FMAs in the window the moments cover; MFMA is
 // not used.  Compiled with the default -ffp-contract (explicit fma() everywhere anyway).
 #include <hip/hip_runtime.h>
 

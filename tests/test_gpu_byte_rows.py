@@ -29,10 +29,10 @@ def test_gain_patch_and_undo_on_the_gpu_box_build(tmp_path):
     dst = tmp_path / "t.mp3"
     shutil.copy(src, dst)
     before = mp3gain.analyze(dst)
-    n = mp3gain.apply_gain_with_undo(dst, 2)
+    n = mp3gain.apply_gain_with_undo(dst, -2)  # (the fixture sits at global_gain 255: upwards would saturate)
     assert n == before.frame_count
     after = mp3gain.analyze(dst)
-    assert after.min_gain == before.min_gain + 2 and after.max_gain == before.max_gain + 2
+    assert after.min_gain == before.min_gain - 2 and after.max_gain == before.max_gain - 2
     mp3gain.undo_gain(dst)
     again = mp3gain.analyze(dst)
     assert (again.min_gain, again.max_gain) == (before.min_gain, before.max_gain)
