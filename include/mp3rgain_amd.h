@@ -194,6 +194,12 @@ int rg_set_tuning(rg_ctx *ctx, int key, int64_t value);
  * gram_last_out: [78]; either may be NULL.  RG_ERR_INVALID_ARG when no design exists. */
 int rg_tm_design_info(uint32_t sample_rate, uint32_t L, uint32_t *H10, uint32_t *rounds, uint32_t *rounds_fast,
                       double *decoupling_residual, double *T_out, double *gram_last_out);
+/* diagnostic (host only): the affine side of that design.  servo = 1 when the Butterworth stage runs as output minus double
+ * integrator with linear lanes (its numerator is exactly g (1, -2, 1)); alpha = 2 + a1, beta = 1 + a1 + a2, g = butter b0;
+ * d_inf = the constant every true output carries from the reference's "+1e-10" terms (0 in the classic form, where the
+ * lanes inject them); sigma0: [12] track-start state in the coordinates of T.  Any pointer may be NULL. */
+int rg_tm_design_affine(uint32_t sample_rate, uint32_t L, int *servo, double *alpha, double *beta, double *g, double *d_inf,
+                        double *sigma0_out);
 
 /* ---- synchronous analysis (mirrors analyze_track / analyze_album minus the decoder) -------- */
 /* analyze_track_internal from the filters onwards, for n independent tracks (`-r` mode).

@@ -112,6 +112,7 @@ SYMBOLS = [
     ("rg_set_kernel", _int, [_vp, _int]),
     ("rg_set_tuning", _int, [_vp, _int, C.c_int64]),
     ("rg_tm_design_info", _int, [_u32, _u32, _P(_u32), _P(_u32), _P(_u32), _P(_dbl), _vp, _vp]),
+    ("rg_tm_design_affine", _int, [_u32, _u32, _P(_int), _P(_dbl), _P(_dbl), _P(_dbl), _P(_dbl), _vp]),
     ("rg_analyze_pcm_batch", _int, [_vp, _P(TrackDesc), _sz, _vp, _sz, _int, _P(TrackResult), _vp]),
     ("rg_analyze_album_pcm", _int, [_vp, _P(TrackDesc), _sz, _vp, _sz, _int, _P(TrackResult), _P(AlbumResult), _vp]),
     ("rg_find_peak_pcm", _int, [_vp, _P(TrackDesc), _vp, _sz, _int, _P(PeakResult)]),

@@ -351,6 +351,24 @@ extern "C" int rg_tm_design_info(uint32_t sr, uint32_t L, uint32_t *H10, uint32_
     return RG_OK;
 }
 
+// diagnostic (host only): the affine side of variant 2's design -- which form the Butterworth stage runs in, its constants,
+// the constant output offset of the reference's "+1e-10" terms and the track-start state in the carried coordinates
+extern "C" int rg_tm_design_affine(uint32_t sr, uint32_t L, int *servo, double *alpha, double *beta, double *g, double *d_inf,
+                                   double *sigma0_out) {
+    const int ri = rg_rate_index(sr);
+    if (ri < 0) return RG_ERR_UNSUPPORTED_RATE;
+    RgTmDesign d;
+    rg_tm_design(RG_RATE_TABLE[ri], L, &d);
+    if (!d.ok) return RG_ERR_INVALID_ARG;
+    if (servo) *servo = d.servo ? 1 : 0;
+    if (alpha) *alpha = d.alpha;
+    if (beta) *beta = d.beta;
+    if (g) *g = d.g;
+    if (d_inf) *d_inf = d.dinf;
+    if (sigma0_out) memcpy(sigma0_out, d.sigma0, sizeof d.sigma0);
+    return RG_OK;
+}
+
 extern "C" int rg_timing_enable(rg_ctx *c, int on) {
     if (!c) return RG_ERR_INVALID_ARG;
     c->timing = on != 0;

@@ -156,3 +156,76 @@ def test_graft_entry_build_succeeds():
     import __graft_entry__
 
     __graft_entry__.build()
+
+
+def _coeffs(rate):
+    import re as _re
+
+    src = (ROOT / "include" / "rg_coeffs.h").read_text()
+    rows = _re.findall(r"\{\s*(\d+)u,\s*\{([^}]*)\},\s*\{([^}]*)\},\s*\{([^}]*)\},\s*\{([^}]*)\},", src)
+    for r in rows:
+        if int(r[0]) == rate:
+            return [[float(v) for v in part.split(",")] for part in r[1:]]  # yule a, yule b, butter a, butter b
+    raise KeyError(rate)
+
+
+@pytest.mark.parametrize("rate", [96000, 64000, 48000, 44100, 32000, 22050, 8000])
+def test_design_reproduces_the_references_response_to_silence(capi, rate):
+    """The affine side of variant 2's design, checked on the host against the reference's own recursion (src/replaygain.rs:586-616,
+    restated here in extended precision): with zero input the reference's output -- driven by its "+1e-10" per stage alone -- must
+    equal, frame for frame over the first window,
+        servo form    d_inf + sigma0 . T[n]                      (linear lanes: nothing else contributes)
+        classic form  (the lanes' zero-state output with their injected 1e-10) + sigma0 . T[n]
+    which pins the track-start state, the decoupling X, the response table and d_inf = 1e-10 / beta at once."""
+    import numpy as np
+
+    ya, yb, ba, bb = _coeffs(rate)
+    W = rate * 50 // 1000
+    H, r, rf, res = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_double()
+    T = np.zeros((W, 12))
+    assert capi.rg_tm_design_info(rate, W, C.byref(H), C.byref(r), C.byref(rf), C.byref(res), T.ctypes.data, None) == 0
+    servo, alpha, beta, g, dinf = C.c_int(), C.c_double(), C.c_double(), C.c_double(), C.c_double()
+    s0 = np.zeros(12)
+    assert capi.rg_tm_design_affine(rate, W, C.byref(servo), C.byref(alpha), C.byref(beta), C.byref(g), C.byref(dinf), s0.ctypes.data) == 0
+    exact = bb[1] == -2.0 * bb[0] and bb[2] == bb[0]
+    assert bool(servo.value) == exact
+    ld = np.longdouble
+    c = ld(1e-10)
+    # the reference, zero input, zero history
+    yx, yy, bx, by = [ld(0)] * 11, [ld(0)] * 11, [ld(0)] * 3, [ld(0)] * 3
+    aff = []
+    for n in range(W):
+        yx = [ld(0)] + yx[:10]
+        yy = [ld(0)] + yy[:10]
+        acc = ld(0)
+        for i in range(1, 11):
+            acc += ld(yb[i]) * yx[i] - ld(ya[i]) * yy[i]
+        y = (c + ld(yb[0]) * yx[0]) + acc
+        yy[0] = y
+        bx = [y] + bx[:2]
+        by = [ld(0)] + by[:2]
+        acc2 = ld(0)
+        for i in range(1, 3):
+            acc2 += ld(bb[i]) * bx[i] - ld(ba[i]) * by[i]
+        z = (c + ld(bb[0]) * bx[0]) + acc2
+        by[0] = z
+        aff.append(z)
+    aff = np.array(aff, dtype=ld)
+    hom = (T.astype(ld) * s0.astype(ld)).sum(axis=1)
+    if servo.value:
+        assert alpha.value == 2.0 + ba[1] and abs(beta.value - (1.0 + ba[1] + ba[2])) <= 1e-18 and g.value == bb[0]
+        assert abs(dinf.value * beta.value - 1e-10) <= 1e-22
+        model = ld(dinf.value) + hom
+    else:
+        assert dinf.value == 0.0
+        # the classic lanes: DF2T with 1e-10 injected at the deepest state of each stage, zero input, zero state
+        s, t, zs = [ld(0)] * 10, [ld(0)] * 2, []
+        for n in range(W):
+            y = s[0]
+            s = [s[i + 1] - ld(ya[i + 1]) * y for i in range(9)] + [c - ld(ya[10]) * y]
+            z = ld(bb[0]) * y + t[0]
+            t = [t[1] + ld(bb[1]) * y - ld(ba[1]) * z, c + ld(bb[2]) * y - ld(ba[2]) * z]
+            zs.append(z)
+        model = np.array(zs, dtype=ld) + hom
+    scale = float(np.max(np.abs(aff)))
+    assert float(np.max(np.abs(model - aff))) <= 2e-12 * scale, (float(np.max(np.abs(model - aff))), scale)
