@@ -23,7 +23,11 @@ for t in range(NT):
         an.synth_fill_device(pcm[t, c].data_ptr(), 0x5EED0000 + t, c, rate, 0, frames)
 torch.cuda.synchronize()
 out = (_capi.TrackResult * NT)()
-for label, alias in (("streamed from HBM", False), ("one track's PCM for every descriptor", True), ("streamed from HBM", False), ("one track's PCM for every descriptor", True)):
+import os
+_mode = os.environ.get("RG_ALIAS_MODE")  # "stream" / "alias": one mode only (counter passes)
+_runs = {"stream": (("streamed from HBM", False),), "alias": (("one track's PCM for every descriptor", True),)}.get(
+    _mode, (("streamed from HBM", False), ("one track's PCM for every descriptor", True)) * 2)
+for label, alias in _runs:
     d = (_capi.TrackDesc * NT)()
     for t in range(NT):
         d[t].offset_bytes, d[t].frames, d[t].sample_rate, d[t].channels, d[t].format = (0 if alias else t * 2 * frames * 4), frames, rate, 2, 0
