@@ -244,6 +244,14 @@ def test_device_synth_matches_host_and_device_resident_path(analyzer, oracle, ca
     aw, awh = oracle.album_from_hists([w[1] for w in wants], [w[0]["peak"] for w in wants])
     assert np.array_equal(ah, awh)
     assert alb.album_loudness_db == aw["album_loudness_db"] and alb.album_peak == aw["album_peak"]
+    # the synchronous call over the same resident arena (rg_analyze_pcm_batch, pcm_on_device = 1: one batch in flight, its
+    # own choice of windows per lane) returns the same results and histograms; with a caller's record array nothing is converted
+    got2, h2 = analyzer.analyze_device(descs, len(seeds), buf.data_ptr(), buf.numel() * 4, want_hist=True)
+    for t, (w, wh) in enumerate(wants):
+        _check(got2[t], h2[t], w, wh)
+    raw = (_capi.TrackResult * len(seeds))()
+    assert analyzer.analyze_device(descs, len(seeds), buf.data_ptr(), buf.numel() * 4, out=raw) is raw
+    assert [raw[t].loudness_db for t in range(len(seeds))] == [g.loudness_db for g in got2]
 
 
 @pytest.mark.parametrize("where", ["start", "middle", "last_window", "both_channels", "window_end", "window_end_right", "track_end",
