@@ -725,7 +725,7 @@ def main() -> int:
                       "tracks_flagged_imprecise": n_imprecise, "tracks_flagged_nonfinite": n_nonfinite,
                       "tracks_in_batch": ntr,
                       "note": "async enqueue/collect path: a flagged track may have windows off by <= 3 bins (0.03 dB); "
-                              "the synchronous entry points re-run flagged tracks on the order-faithful kernel"}
+                              "the synchronous entry points and rg_collect_exact re-run flagged tracks on the order-faithful kernel"}
             # ---- CPU baseline: a bounded sample of the same workload (one of its tracks, repeated) ----
             cpu = cpu_baseline_leg(po, l0, r0, rate0, fr0, f"track {t0_} of the batch", args.cpu_seconds)
         if args.mixed:

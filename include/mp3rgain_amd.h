@@ -224,6 +224,11 @@ int rg_enqueue_pcm_batch(rg_ctx *ctx, const rg_track_desc *tracks, size_t n, con
 int rg_device_view_get(rg_ctx *ctx, rg_device_view *view);
 /* wait for the stream and copy back; any of the outputs may be NULL */
 int rg_collect(rg_ctx *ctx, rg_track_result *tracks_out, uint32_t *hist_out);
+/* The same with the synchronous calls' guarantee (track mode): if a collected track carries RG_TRACK_FLAG_IMPRECISE the batch --
+ * described again by the caller, its PCM still in place -- is run once more with the flagged tracks on the order-faithful
+ * kernel, and the exact results are returned.  tracks / n must be what the last rg_enqueue_pcm_batch was given. */
+int rg_collect_exact(rg_ctx *ctx, const rg_track_desc *tracks, size_t n, const void *d_pcm_base, size_t pcm_bytes,
+                     rg_track_result *tracks_out, uint32_t *hist_out);
 /* album across GPUs (src/replaygain.rs:1056-1066 as a collective): in-place
  * all-reduce(sum) of d_album_hist and all-reduce(max) of d_album_peak over `nccl_comm`
  * (an ncclComm_t; NULL = single GPU, no-op).  The RCCL entry points are resolved from the

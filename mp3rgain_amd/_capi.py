@@ -119,6 +119,7 @@ SYMBOLS = [
     ("rg_enqueue_pcm_batch", _int, [_vp, _P(TrackDesc), _sz, _vp, _sz, _int]),
     ("rg_device_view_get", _int, [_vp, _P(DeviceView)]),
     ("rg_collect", _int, [_vp, _P(TrackResult), _vp]),
+    ("rg_collect_exact", _int, [_vp, _P(TrackDesc), _sz, _vp, _sz, _P(TrackResult), _vp]),
     ("rg_album_allreduce", _int, [_vp, _vp]),
     ("rg_album_finish", _int, [_vp, _P(AlbumResult), _vp]),
     ("rg_comm_library", _int, [C.c_char_p]),

@@ -855,6 +855,23 @@ extern "C" int rg_analyze_pcm_batch(rg_ctx *c, const rg_track_desc *tracks, size
     return rg_collect(c, out, hist_out);
 }
 
+// rg_collect for callers of the asynchronous pair that want the synchronous calls' guarantee: the batch most recently enqueued
+// with exactly these descriptors is collected, and if the fast kernels flagged a track whose bins rounding could have moved, the
+// batch is run once more with those tracks on the order-faithful kernel (auto mode only; track mode -- an album's pack has
+// already been produced from the first run).  The PCM must still be where it was.
+extern "C" int rg_collect_exact(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *d_pcm_base, size_t pcm_bytes,
+                                rg_track_result *out, uint32_t *hist_out) {
+    if (!c || (n && (!tracks || !d_pcm_base || !out))) return RG_ERR_INVALID_ARG;
+    if (c->slot().n_enqueued != n) return rg_set_err(c, RG_ERR_STATE, "rg_collect_exact: the last enqueue held %zu tracks, not %zu", c->slot().n_enqueued, n);
+    int rc = rg_collect(c, out, hist_out);
+    if (rc != RG_OK || !needs_exact_pass(c, out, n)) return rc;
+    ExactPass exact(c);
+    OneShot one(c);
+    rc = rg_enqueue_impl(c, tracks, n, d_pcm_base, pcm_bytes, 0);
+    if (rc != RG_OK) return rc;
+    return rg_collect(c, out, hist_out);
+}
+
 extern "C" int rg_analyze_album_pcm(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void *pcm_base,
                                     size_t pcm_bytes, int on_device, rg_track_result *tracks_out,
                                     rg_album_result *album_out, uint32_t *album_hist_out) {

@@ -365,6 +365,16 @@ class Analyzer:
         res = [_to_result(out[i], AudioFileType.Mp3) for i in range(n)]
         return (res, hist[:n]) if want_hist else res
 
+    def collect_exact(self, descs, n: int, d_pcm_base: int, pcm_bytes: int, want_hist: bool = False):
+        """collect() with the synchronous calls' guarantee: a batch that has a track flagged imprecise is run once more with
+        that track on the order-faithful kernel (the PCM must still be in place)."""
+        out = (_capi.TrackResult * max(1, n))()
+        hist = np.zeros((max(1, n), _capi.HISTOGRAM_SIZE), dtype=np.uint32) if want_hist else None
+        self._check(self._lib.rg_collect_exact(self._ctx, descs, n, d_pcm_base, pcm_bytes, out,
+                                               hist.ctypes.data if hist is not None else None))
+        res = [_to_result(out[i], AudioFileType.Mp3) for i in range(n)]
+        return (res, hist[:n]) if want_hist else res
+
     def device_view(self) -> _capi.DeviceView:
         v = _capi.DeviceView()
         self._check(self._lib.rg_device_view_get(self._ctx, C.byref(v)))

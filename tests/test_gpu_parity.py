@@ -555,3 +555,43 @@ def test_exact_repeat_touches_only_the_flagged_tracks(_ctx, oracle):
     for g, hh, tr in zip(got, h, tracks):
         want, wh = oracle.analyze_pcm(tr.channels[0], tr.channels[1], rate)
         assert np.array_equal(hh, wh) and g.loudness_db == want["loudness_db"] and not g.flags & 2
+
+
+def test_collect_exact_gives_the_asynchronous_pair_the_synchronous_guarantee(_ctx, oracle):
+    """rg_enqueue_pcm_batch + rg_collect_exact in auto mode: pathological float tracks resident on the device -- those the fast
+    kernels flag are run again on the order-faithful kernel -- come back with the oracle's bins, no flag left."""
+    import torch
+
+    from mp3rgain_amd import _capi
+
+    an = _ctx
+    an.set_kernel(0)
+    for key in (1, 2, 4):
+        an.set_tuning(key, 0)
+    cases = [c for c in _pathological_cases(240) if c[1][0].dtype == np.float32 and len(c[1]) == 2][:32]
+    assert len(cases) >= 8
+    seen_flag = False
+    for lo in range(0, len(cases), 8):
+        part = cases[lo:lo + 8]
+        n = len(part)
+        total = sum(2 * len(ch[0]) for _, ch, _ in part)
+        buf = torch.empty(total, dtype=torch.float32, device="cuda:0")
+        descs = (_capi.TrackDesc * n)()
+        off = 0
+        for t, (rate, ch, _) in enumerate(part):
+            f = len(ch[0])
+            buf[off:off + f] = torch.from_numpy(np.ascontiguousarray(ch[0]))
+            buf[off + f:off + 2 * f] = torch.from_numpy(np.ascontiguousarray(ch[1]))
+            descs[t].offset_bytes, descs[t].frames, descs[t].sample_rate, descs[t].channels, descs[t].format = off * 4, f, rate, 2, _capi.FMT_F32_PLANAR
+            off += 2 * f
+        torch.cuda.synchronize()
+        an.enqueue_device(descs, n, buf.data_ptr(), total * 4)
+        plain = an.collect(n)
+        seen_flag = seen_flag or any(r.flags & 2 for r in plain)
+        an.enqueue_device(descs, n, buf.data_ptr(), total * 4)
+        got, h = an.collect_exact(descs, n, buf.data_ptr(), total * 4, want_hist=True)
+        for t, (rate, ch, kinds) in enumerate(part):
+            want, wh = oracle.analyze_pcm(ch[0], ch[1], rate)
+            assert np.array_equal(h[t], wh), f"case {lo + t} ({rate} Hz, {kinds}): bins differ"
+            assert got[t].peak == want["peak"] and not (got[t].flags & 2)
+    assert seen_flag, "no pathological track was flagged by the fast kernels: the test exercises nothing"
