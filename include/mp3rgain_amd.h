@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION 3
+#define RG_ABI_VERSION 4
 #define RG_HISTOGRAM_SIZE 12000         /* HISTOGRAM_SIZE        src/replaygain.rs:630 */
 #define RG_HISTOGRAM_OFFSET 2000        /* HISTOGRAM_OFFSET      src/replaygain.rs:635 */
 #define RG_REPLAYGAIN_REFERENCE_DB 89.0 /* REPLAYGAIN_REFERENCE_DB src/replaygain.rs:37 */
