@@ -269,6 +269,8 @@ extern "C" void rg_destroy(rg_ctx *c) {
     for (int k = 0; k < 2; ++k) {
         c->d_mp3_recs_set[k].release();
         c->d_mp3_tiles_set[k].release();
+        c->d_mp3_perm_set[k].release();
+        c->d_mp3_sortw_set[k].release();
     }
     c->h_mp3_results.release();
     if (c->mp3_copy_stream) (void)hipStreamDestroy(c->mp3_copy_stream);

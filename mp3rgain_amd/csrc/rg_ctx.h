@@ -157,6 +157,10 @@ struct rg_ctx {
     // kernels of chunk k: what it writes (records, tile sums) is per staging set.
     DevBuf<unsigned char> d_mp3_recs_set[2];
     DevBuf<uint32_t> d_mp3_tiles_set[2];
+    // the Huffman stage's lane sort (rg_mp3_sort_*): per staging set the units ordered by big_values and the sort's working words
+    // (RG_MP3_SORT_WORDS, allocated once and zeroed: the kernels leave the histogram zero behind them)
+    DevBuf<uint32_t> d_mp3_perm_set[2];
+    DevBuf<uint32_t> d_mp3_sortw_set[2];
     PinnedBuf<uint32_t> h_mp3_results;
     hipEvent_t *mp3_bench_ev = nullptr;      // rg_mp3_decode_bench: four events recorded around the three decode stages of a chunk
     void *mp3_pipe = nullptr;                // rg_files.hip: pinned staging blocks of the loader pipeline

@@ -1045,6 +1045,19 @@ extern "C" void rg_mp3_fill_device_huff(RgMp3DevHuff *o) {
         at += (uint32_t)n;
     }
     o->n_entries = at;
+    if (at + 2 > RG_MP3_HUFF_LDS_ENTRIES) abort();  // two zero entries follow the tables (rg_mp3dev.hip: a table that codes nothing)
+    for (uint32_t i = 0; i < at; ++i) {  // the 16-bit image (rg_mp3dev.h)
+        const uint32_t e = o->e[i];
+        if (e & 0x80000000u) {
+            const uint32_t sub = e & 0xFFu, off = (e >> 8) & 0x7FFFFFu;
+            if (sub > 15 || off > 2047) abort();
+            o->e16[i] = (uint16_t)(0x8000u | sub | (off << 4));
+        } else {
+            const uint32_t len = e & 0xFFu, xy = (e >> 8) & 0xFFu;
+            if (len > 15) abort();
+            o->e16[i] = (uint16_t)(len | (xy << 4));
+        }
+    }
     memcpy(o->quadA, T.quadA, sizeof o->quadA);
 }
 

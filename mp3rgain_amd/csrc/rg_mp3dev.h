@@ -10,10 +10,14 @@
 #define RG_MP3_GAIN_Q_MAX 64
 #define RG_MP3_HUFF_LDS_ENTRIES 7808  // room for the flattened Huffman tables in the Huffman kernel's LDS (they have 7752 entries)
 #define RG_MP3_RUN 32             // consecutive granules per block of the back-half kernel (both channels)
-#ifndef RG_MP3_IS_GROUP_LOG2
-#define RG_MP3_IS_GROUP_LOG2 3    // 2^3 units interleaved 16-byte piece by piece in the Huffman kernel's output (rg_mp3dev.hip: rg_mp3_is_index)
-#endif
-#define RG_MP3_IS_GROUP (1u << RG_MP3_IS_GROUP_LOG2)
+// The quantised spectra between the device Huffman stage and the back half: one row of RG_MP3_ROW_BYTES per unit, sign and
+// magnitude in two planes of a byte per line -- at i: sign << 7 | |v| & 127, at 576 + i: |v| >> 7, the second plane written
+// only for the first 4 * rg_mp3_unit::reserved[0] lines (no other line holds a value above 127).  (Spectra parsed on the
+// host -- rg_mp3_parse_units -- are rows of 576 int16 in the same RG_MP3_ROW_BYTES.)
+#define RG_MP3_ROW_BYTES 1152
+#define RG_MP3_SORT_BUCKETS 96    // lane sort of the Huffman stage: big_values >> 2, heaviest first (73 buckets in use)
+#define RG_MP3_SORT_WORDS 256     // per staging set: [0, 96) histogram (zero between uses), [96, 192) bucket cursors, [192] units that decode
+#define RG_MP3_SORT_NVALID 192
 
 // Every constant the device stages use, built once on the host from the very tables the host decoder uses, so that
 // the two halves work with identical numbers.
@@ -46,6 +50,9 @@ struct RgMp3DevHuff {
     uint8_t quadA[64];          // count1 table A: 6 peeked bits -> len << 4 | vwxy
     uint32_t n_entries;
     uint32_t e[14000];
+    // the same entries in 16 bits, what the Huffman kernel keeps in LDS: leaf = len | y << 4 | x << 8 (len <= 10),
+    // link = 0x8000 | sub_bits | offset << 4 (sub_bits <= 10, offset < 2048; rg_mp3_fill_device_huff checks)
+    uint16_t e16[RG_MP3_HUFF_LDS_ENTRIES];
 };
 
 // One granule of one channel of a decodable frame, as the host's frame indexer hands it to the device Huffman

@@ -45,41 +45,9 @@ __device__ __forceinline__ uint32_t find_by_unit(const RgMp3DevTrack *__restrict
 }
 
 
-// The quantised spectra between the Huffman stage and the back half: 72 pieces of 16 bytes (8 lines) per unit.  With the
-// Huffman stage on the device, groups of G = 8 units are interleaved piece by piece -- the Huffman kernel's lanes are
-// consecutive units at the same piece, so eight lanes fill a 128-byte line with one store, where rows of their own made
-// every 16-byte store a partial line (read for ownership + a masked write: 3.5 KB of traffic per unit for 1.2 KB of
-// spectrum).  G = 1: plain rows (what the host's rg_mp3_parse_units writes).  Index in 16-byte pieces; G = 2^group_log2.
 typedef float rg_f32x2 __attribute__((ext_vector_type(2)));
 typedef short rg_s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short rg_u16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint64_t rg_mp3_is_index(uint64_t unit, int chunk, uint32_t group_log2) {
-    return ((((unit >> group_log2) * 72 + (uint64_t)chunk) << group_log2) | (unit & ((1u << group_log2) - 1u)));
-}
-
-// Bit reader over the batch's main-data buffer; bits at or past `limit` (the end of the frame's own main data) read
-// as zero, which is what the host decoder's private copy of the frame's data does.
-struct DevBits {
-    const uint8_t *__restrict__ p;
-    uint64_t pos, end, limit;
-    __device__ __forceinline__ uint32_t window() const {  // 32 bits starting at the byte that holds `pos`
-        const uint64_t byte = pos >> 3;
-        const uint8_t *q = p + byte;
-        uint32_t w = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
-        const int64_t valid = (int64_t)limit - (int64_t)(byte << 3);
-        if (valid < 32) w = valid <= 0 ? 0u : (w & (0xFFFFFFFFu << (32 - (int)valid)));
-        return w;
-    }
-    __device__ __forceinline__ uint32_t peek(int n) const { return (window() << (pos & 7)) >> (32 - n); }  // 1 <= n <= 25
-    __device__ __forceinline__ uint32_t get(int n) {
-        if (n == 0) return 0;
-        const uint32_t v = peek(n);
-        pos += n;
-        return v;
-    }
-    __device__ __forceinline__ uint32_t get1() { return get(1); }
-};
 
 }  // namespace
 
@@ -136,7 +104,7 @@ extern "C" int rg_bh_dbg2_read(void *out) { return (int)hipMemcpyFromSymbol(out,
 #define RG_MP3_BH_THREADS 256
 __global__ void __launch_bounds__(RG_MP3_BH_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks,
-                       const rg_mp3_unit *__restrict__ units, const int16_t *__restrict__ is, const uint32_t is_group_log2) {
+                       const rg_mp3_unit *__restrict__ units, const int16_t *__restrict__ is, const uint32_t planes) {
     constexpr int R = RG_MP3_RUN;
     __shared__ float xrb[2][2][576];   // [buffer][channel][line]
     __shared__ __attribute__((aligned(16))) rg_mp3_unit Ub[3][2];
@@ -200,8 +168,10 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         // the block's step is as long as this wave's: where it shares a SIMD with the other blocks' lighter waves it goes first
         // (priorities for the other stages as well were slower)
         __builtin_amdgcn_s_setprio(3);
-        auto requant_wave = [&](auto nch_c) {
+        // PLANES: the spectra come from the device Huffman stage, a byte per line in two planes (rg_mp3dev.h); else rows of int16
+        auto requant_wave = [&](auto nch_c, auto planes_c) {
         constexpr int nch = decltype(nch_c)::value;
+        constexpr bool PLANES = decltype(planes_c)::value;
         constexpr int kRounds = 3;
         uint32_t rq_lb[kRounds] = {0u, 0u, 0u};  // long-block band numbers of a piece's four lines
 #pragma unroll
@@ -243,33 +213,56 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         uint2 rq_next[kRounds][2];
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) rq_next[r][0] = rq_next[r][1] = make_uint2(0u, 0u);
-        // 16-byte piece `chunk` of unit U sits at ((U / G) 72 + chunk) G + U % G (rg_mp3_is_index): a lane's share of that
-        // is fixed, the unit's share is a scalar
-        uint32_t rq_off[kRounds];  // bytes from the unit's first piece to this lane's four lines
+        // a lane's four lines of a round: 8 bytes of an int16 row, or 4 bytes of each plane
+        uint32_t rq_off[kRounds];
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) {  // the third round's idle lanes read its last piece again: no branch around a load
             const uint32_t piece = (uint32_t)(lane + 64 * r < 144 ? lane + 64 * r : 143);
-            rq_off[r] = ((piece >> 1) << (is_group_log2 + 4)) + 8u * (piece & 1u);
+            rq_off[r] = PLANES ? 4u * piece : 8u * piece;
         }
-        // the block's spectra start at the group its first unit lies in; from there 32-bit offsets do (a run is 68 units)
-        const uint32_t group_mask = (1u << is_group_log2) - 1u;
-        const uint32_t u_in_group0 = (uint32_t)(ubase & group_mask);
-        const uint8_t *const is_block = reinterpret_cast<const uint8_t *>(is) + (ubase >> is_group_log2) * ((uint64_t)(72 * 16) << is_group_log2);
-        auto fetch_spectra = [&](const int step) {  // every load of it is issued whatever the step: the compiler can count them
+        const uint8_t *const is_block = reinterpret_cast<const uint8_t *>(is) + ubase * (uint64_t)RG_MP3_ROW_BYTES;  // 32-bit offsets from here (a run is 68 units)
+        // Every load is issued whatever the step (the compiler can count them), but not every load has to move bytes: lines
+        // from the unit's nz on were never written and are replaced by zeros below, and the second plane exists for the first
+        // hi_q words only -- such lanes ask for their round-0 word again, which is on its way anyway.  `hd`: the unit headers of
+        // the step asked for (its nz and hi_q are the wave's).
+        auto fetch_spectra = [&](const int step, const uint32_t (&hd)[2][4]) {
 #pragma unroll
             for (int c = 0; c < nch; ++c) {
-                const uint32_t ul = u_in_group0 + (uint32_t)step * nch + c;
-                const uint8_t *const row = is_block + ((((ul >> is_group_log2) * 72u) << is_group_log2) + (ul & group_mask)) * 16u;
+                const uint8_t *const row = is_block + ((uint32_t)step * nch + c) * (uint32_t)RG_MP3_ROW_BYTES;
+                const uint32_t nz = hd[c][0] & 0xFFFFu;
+                if (PLANES) {
+                    const uint32_t last = nz ? ((nz + 3u) & ~3u) - 4u : 0u;  // byte offset of the last word with lines in it
+                    const uint32_t hi_q = (hd[c][3] >> 16) & 0xFFu;
 #pragma unroll
-                for (int r = 0; r < kRounds; ++r) rq_next[r][c] = *reinterpret_cast<const uint2 *>(row + rq_off[r]);
+                    for (int r = 0; r < kRounds; ++r) {
+                        const uint32_t lo_at = rq_off[r] < last ? rq_off[r] : last;
+                        const uint32_t hi_at = (uint32_t)(lane + 64 * r) < hi_q ? (uint32_t)(RG_MP3_ROW_BYTES / 2) + rq_off[r] : lo_at;
+                        rq_next[r][c].x = *reinterpret_cast<const uint32_t *>(row + lo_at);
+                        rq_next[r][c].y = *reinterpret_cast<const uint32_t *>(row + hi_at);
+                    }
+                } else {
+                    const uint32_t last = nz ? 2u * (((nz + 3u) & ~3u) - 4u) : 0u;
+#pragma unroll
+                    for (int r = 0; r < kRounds; ++r) rq_next[r][c] = *reinterpret_cast<const uint2 *>(row + (rq_off[r] < last ? rq_off[r] : last));
+                }
             }
+        };
+        // magnitudes of a word's two lines: the word is two int16, or (PLANES, rounds with a second plane) sign << 15 | magnitude
+        auto mag2 = [](const uint32_t w) -> rg_u16x2 {
+            if (PLANES) return __builtin_bit_cast(rg_u16x2, w & 0x7FFF7FFFu);
+            return __builtin_bit_cast(rg_u16x2, __builtin_elementwise_abs(__builtin_bit_cast(rg_s16x2, w)));
+        };
+        auto mag1 = [](const uint32_t w, const int half) -> int {
+            if (PLANES) return (int)((w >> (16 * half)) & 0x7FFFu);
+            const int v = (int)(int16_t)(w >> (16 * half));
+            return v < 0 ? -v : v;
         };
         auto wave_sync = [] {  // LDS hand-over between lanes of this wave
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
         };
-        fetch_spectra(0);
+        fetch_spectra(0, h_next);
         rg_lds_barrier();
         for (int k = 0; k <= nsteps + 2; ++k) {
             RG_BH_STAMP(1, k, 0);
@@ -289,16 +282,47 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                 uint2 raw[kRounds][2];
 #pragma unroll
                 for (int r = 0; r < kRounds; ++r) { raw[r][0] = rq_next[r][0]; raw[r][1] = rq_next[r][1]; }
-                // The lines from a unit's nz on are zero and the Huffman stage does not write them (it completes the
-                // 16-byte piece the last value falls into): what was fetched from there is replaced by zeros.
+                // The lines from a unit's nz on are zero and were neither written by the Huffman stage (it completes the sector
+                // the last value falls into) nor asked for (fetch_spectra): what arrived in their place is replaced by zeros.
                 int nz8_max = 0;  // lines from here on are zero in every channel
 #pragma unroll
                 for (int c = 0; c < nch; ++c) {
-                    const int nz8 = ((int)(h[c][0] & 0xFFFFu) + 7) & ~7;
+                    const int nz8 = ((int)(h[c][0] & 0xFFFFu) + 3) & ~3;
                     nz8_max = nz8 > nz8_max ? nz8 : nz8_max;
 #pragma unroll
                     for (int r = 0; r < kRounds; ++r)
                         if (nz8 < 256 * (r + 1) && 4 * (lane + 64 * r) >= nz8) raw[r][c] = make_uint2(0u, 0u);  // the first test is the wave's
+                }
+                // Two planes of a byte per line.  Past the longest second plane of the step's units (hi_q words of four lines: as far
+                // as a magnitude above 127 was actually found, usually nowhere, else in the first few dozen lines) a byte is its
+                // line's index into the LDS part of the x^(4/3) table -- no absolute value, no clamp, no large-value pass.  A round
+                // with lines below that mark is put into sign << 15 | magnitude, two lines per word, and goes the int16 form's
+                // way from there.
+                uint32_t hi_q_max = 0u;
+                if (PLANES) {
+#pragma unroll
+                    for (int c = 0; c < nch; ++c) {
+                        const uint32_t hq = (h[c][3] >> 16) & 0xFFu;
+                        hi_q_max = hq > hi_q_max ? hq : hi_q_max;
+                    }
+                }
+                bool bytes_r[kRounds];  // the wave's
+#pragma unroll
+                for (int r = 0; r < kRounds; ++r) {
+                    bytes_r[r] = PLANES && (uint32_t)(64 * r) >= hi_q_max;
+                    if (PLANES && !bytes_r[r]) {
+#pragma unroll
+                        for (int c = 0; c < nch; ++c) {
+                            const uint32_t lo = raw[r][c].x, hi = (uint32_t)(lane + 64 * r) < ((h[c][3] >> 16) & 0xFFu) ? raw[r][c].y : 0u;
+                            uint32_t sm[2];
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {  // bytes lo[2q], hi[2q], lo[2q + 1], hi[2q + 1]
+                                const uint32_t t = __builtin_amdgcn_perm(hi, lo, q ? 0x07030602u : 0x05010400u);
+                                sm[q] = ((t & 0xFF00FF00u) >> 1) | (t & 0x007F007Fu) | ((t & 0x00800080u) << 8);
+                            }
+                            raw[r][c] = make_uint2(sm[0], sm[1]);
+                        }
+                    }
                 }
                 RG_BH_STAMP2(k, 2);
                 // Order matters from here to the end of the step.  Everything this step needs from memory has arrived; the
@@ -314,11 +338,11 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
 #pragma unroll
                     for (int r = 0; r < kRounds; ++r) {
                         rg_u16x2 amax = {0, 0};
-                        if (nz8_max > 256 * r) {
+                        if (!bytes_r[r] && nz8_max > 256 * r) {
 #pragma unroll
                             for (int c = 0; c < nch; ++c) {
-                                amax = __builtin_elementwise_max(amax, __builtin_bit_cast(rg_u16x2, __builtin_elementwise_abs(__builtin_bit_cast(rg_s16x2, raw[r][c].x))));
-                                amax = __builtin_elementwise_max(amax, __builtin_bit_cast(rg_u16x2, __builtin_elementwise_abs(__builtin_bit_cast(rg_s16x2, raw[r][c].y))));
+                                amax = __builtin_elementwise_max(amax, mag2(raw[r][c].x));
+                                amax = __builtin_elementwise_max(amax, mag2(raw[r][c].y));
                             }
                         }
                         big_r[r] = __builtin_amdgcn_ballot_w64((amax.x > amax.y ? amax.x : amax.y) >= kPowLds) != 0;
@@ -334,8 +358,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                                 const uint32_t w[2] = {raw[r][c].x, raw[r][c].y};
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
-                                    const int v = (int)(int16_t)(w[j >> 1] >> (16 * (j & 1)));
-                                    const int a = v < 0 ? -v : v;
+                                    const int a = mag1(w[j >> 1], j & 1);
                                     big[c][j] = a >= kPowLds ? T->pow43[a] : 0.0f;
                                 }
                             }
@@ -358,7 +381,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                 }
                 RG_BH_STAMP2(k, 3);
                 if (uq) u_reg = reinterpret_cast<const uint4 *>(units + ubase + (uint64_t)(k + 2 < nsteps ? k + 2 : nsteps - 1) * nch)[uq_t];
-                fetch_spectra(k + 1 < nsteps ? k + 1 : nsteps - 1);
+                fetch_spectra(k + 1 < nsteps ? k + 1 : nsteps - 1, h_next);
                 int bt_s[2] = {0, 0}, ll_s[2] = {0, 0}, so_s[2] = {0, 0};
                 int gq_idx[2] = {0, 0};
                 uint32_t gq_sf[2] = {0u, 0u};
@@ -426,16 +449,21 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                                 gv[c][j] = gtab[c][idx];
                             }
                         }
-                        // two lines per 32-bit word: |v|, the largest of them and the index into the LDS part of the power
-                        // table as packed 16-bit operations
-                        const uint32_t w[2] = {raw[r][c].x, raw[r][c].y};
+                        if (bytes_r[r]) {  // the byte is the index
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const rg_u16x2 ua = __builtin_bit_cast(rg_u16x2, __builtin_elementwise_abs(__builtin_bit_cast(rg_s16x2, w[h])));
-                            const rg_u16x2 top = {(unsigned short)(kPowLds - 1), (unsigned short)(kPowLds - 1)};
-                            const rg_u16x2 ci = __builtin_elementwise_min(ua, top);
-                            mg[c][2 * h] = pow_l[ci.x];
-                            mg[c][2 * h + 1] = pow_l[ci.y];
+                            for (int j = 0; j < 4; ++j) mg[c][j] = pow_l[(raw[r][c].x >> (8 * j)) & 127u];
+                        } else {
+                            // two lines per 32-bit word: |v|, the largest of them and the index into the LDS part of the power
+                            // table as packed 16-bit operations
+                            const uint32_t w[2] = {raw[r][c].x, raw[r][c].y};
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const rg_u16x2 ua = mag2(w[h]);
+                                const rg_u16x2 top = {(unsigned short)(kPowLds - 1), (unsigned short)(kPowLds - 1)};
+                                const rg_u16x2 ci = __builtin_elementwise_min(ua, top);
+                                mg[c][2 * h] = pow_l[ci.x];
+                                mg[c][2 * h + 1] = pow_l[ci.y];
+                            }
                         }
                     }
                     if (big_r[r]) {  // rare: a value beyond the LDS part of the table
@@ -445,8 +473,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                             const uint32_t w[2] = {raw[r][c].x, raw[r][c].y};
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const int v = (int)(int16_t)(w[j >> 1] >> (16 * (j & 1)));
-                                const int a = v < 0 ? -v : v;
+                                const int a = mag1(w[j >> 1], j & 1);
                                 if (a >= kPowLds) mg[c][j] = XP[c][rq_l0 + j];  // put there at the top of the step
                             }
                         }
@@ -461,7 +488,8 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                             // the product is >= +0; a negative value takes its sign (-t, also of a product that underflowed):
                             // bit 31 of the word, shifted up for the low half
                             const float t = mg[c][j] * gv[c][j];
-                            val[c][j] = __builtin_copysignf(t, __uint_as_float((j & 1) ? w[j >> 1] : w[j >> 1] << 16));
+                            const uint32_t sign_at_31 = bytes_r[r] ? w[0] << (24 - 8 * j) : ((j & 1) ? w[j >> 1] : w[j >> 1] << 16);
+                            val[c][j] = __builtin_copysignf(t, __uint_as_float(sign_at_31));
                         }
                     }
                     // ---- stage C, the plain case: mid/side on the lines below the longer channel's end; the end is the same
@@ -613,8 +641,13 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
             rg_lds_barrier();
         }
         };
-        if (nch == 2) requant_wave(std::integral_constant<int, 2>{});
-        else requant_wave(std::integral_constant<int, 1>{});
+        if (planes) {
+            if (nch == 2) requant_wave(std::integral_constant<int, 2>{}, std::true_type{});
+            else requant_wave(std::integral_constant<int, 1>{}, std::true_type{});
+        } else {
+            if (nch == 2) requant_wave(std::integral_constant<int, 2>{}, std::false_type{});
+            else requant_wave(std::integral_constant<int, 1>{}, std::false_type{});
+        }
         return;
     }
 
@@ -791,8 +824,8 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
 // =====================================================================================================================
 // Stage A's heavy part on the device: scalefactors + Huffman-coded spectrum (rg_mp3dec.cpp: read_scalefactors_v1 /
 // read_scalefactors_lsf / decode_spectrum), one thread per granule and channel.  Integer work throughout: the outputs
-// (576 int16 per unit + one rg_mp3_unit) are the values rg_mp3_parse_units writes on the host; the spectra are laid out for
-// this kernel's stores (rg_mp3_is_index).
+// (576 quantised values per unit + one rg_mp3_unit) are the values rg_mp3_parse_units writes on the host; the spectra leave as
+// sign and magnitude, a byte per line in two planes (rg_mp3dev.h: RG_MP3_ROW_BYTES).
 //
 // The decode is a chain of dependent look-ups per symbol, so everything a symbol touches is kept close: the code tables
 // of all 32 table numbers sit in LDS (31 KB, copied once per block of 512 units), the bit stream is read through three
@@ -803,75 +836,93 @@ namespace {
 
 constexpr int kHuffThreads = 512;  // 1024 (eight waves per SIMD instead of six) is slower: 0.44 against 0.38 ms on the dense stream
 
-// 96 bits of the track's main data around the read position, big-endian words; bits at or past `limit` (the end of the
-// frame's own main data) read as zero, which is what the host decoder's private copy of the frame's data does.  All
-// positions are 32-bit bit counts from the 32-bit word the granule starts in (a granule is at most 4095 bits long, its
-// frame's data ends at most a few thousand bits later).
-struct BitCache {
-    const uint32_t *__restrict__ w;  // the word the granule starts in (the track's main data is 4-byte aligned)
+// The bit reader.  Under SIMT whatever ONE lane of a wave has to do now and then -- take the next word of its stream, ask
+// for the next bytes, follow a long code into a second table -- the wave does every time, so the reader has no state to keep
+// in step with the position: a lane's stream passes through a ring of eight words in LDS (column `tid` of ring[8][threads],
+// big-endian words with everything at or past `limit` -- the end of the frame's own main data -- already zero, which is what
+// the host decoder's private copy of the frame's data reads there), and a look at the stream is three words from the ring and
+// two 64-bit shifts by the position's low five bits, whatever the position.  The ring is fed sixteen bytes at a time -- one
+// such group in flight per lane, asked for when the one before goes into the ring: the lanes of a wave are units of equal
+// length from anywhere in the chunk and every request is a DRAM page of its own -- at points of the loops where the whole
+// wave feeds together.  Positions are 32-bit bit counts from the 16-byte group the granule starts in (a granule is at most
+// 4095 bits long).
+struct BitRing {
+    uint32_t *__restrict__ ring;     // the thread's column: word i of the stream at ring[(i & 7) * kHuffThreads]
+    const uint4 *__restrict__ g;     // the next group to ask for (the track's main data is 16-byte aligned)
+    uint4 c;                         // the group in flight: words filled .. filled + 3
+    uint32_t filled;                 // words in the ring (a multiple of 4)
     uint32_t pos, end;               // read position, end of the granule's bits
     int32_t limit;                   // end of the frame's own data; may lie before `pos` in damaged streams
-    uint32_t idx;                    // word index of w0
-    uint32_t w0, w1, w2, w3;         // words idx .. idx + 2 (and idx + 3 while idx is even): fetched in aligned pairs
-    __device__ __forceinline__ uint32_t mask_word(uint32_t raw, uint32_t i) const {
-        const int32_t valid = limit - (int32_t)(i << 5);
-        if (valid <= 0) return 0u;
-        uint32_t x = __builtin_bswap32(raw);
-        if (valid < 32) x &= 0xFFFFFFFFu << (32 - valid);
-        return x;
+    __device__ __forceinline__ uint32_t masked(uint32_t raw, uint32_t i) const {
+        int v = limit - (int32_t)(i << 5);
+        v = v < 0 ? 0 : (v > 32 ? 32 : v);
+        return __builtin_bswap32(raw) & (uint32_t)(0xFFFFFFFF00000000ull >> v);
     }
-    // words i and i + 1 (i even, relative to an 8-byte aligned base): one 8-byte load -- the stream is read in half as
-    // many requests as word by word, and every request of a thread costs a line fetch when 400 000 threads stream at once
-    __device__ __forceinline__ void load_pair(uint32_t i, uint32_t *a, uint32_t *b) const {
-        if (limit - (int32_t)(i << 5) <= 0) { *a = 0u; *b = 0u; return; }
-        const uint2 raw = *reinterpret_cast<const uint2 *>(w + i);
-        *a = mask_word(raw.x, i);
-        *b = mask_word(raw.y, i + 1);
+    __device__ __forceinline__ void commit(const uint4 &q) {
+        uint32_t *const at = ring + (filled & 4u) * kHuffThreads;
+        if ((int32_t)((filled + 4u) << 5) <= limit) {  // far from the end of the frame's data: nothing to mask
+            at[0 * kHuffThreads] = __builtin_bswap32(q.x);
+            at[1 * kHuffThreads] = __builtin_bswap32(q.y);
+            at[2 * kHuffThreads] = __builtin_bswap32(q.z);
+            at[3 * kHuffThreads] = __builtin_bswap32(q.w);
+        } else {
+            at[0 * kHuffThreads] = masked(q.x, filled);
+            at[1 * kHuffThreads] = masked(q.y, filled + 1u);
+            at[2 * kHuffThreads] = masked(q.z, filled + 2u);
+            at[3 * kHuffThreads] = masked(q.w, filled + 3u);
+        }
+        filled += 4u;
+    }
+    // The group in flight goes into the ring if half of the ring is free, and the next one is asked for.  Called once per
+    // step of at most three words (two big_values pairs: 94 bits; four quadruples: 40 bits), this keeps at least five words
+    // ahead of the position at the top of every step: a look needs three, and the step's second pair may be two words on.
+    __device__ __forceinline__ void feed() {
+        if (filled - (pos >> 5) <= 4u) {
+            commit(c);
+            c = *g++;
+        }
     }
     // granule at absolute bit `bit_off` of the stream `base`, `length` bits long, frame data ending at `frame_end_bit`
     __device__ __forceinline__ void open(const uint8_t *base, uint64_t bit_off, uint32_t length, uint64_t frame_end_bit) {
-        const uint64_t word0 = (bit_off >> 6) << 1;  // even: the pairs are 8-byte aligned (the stream is)
-        w = reinterpret_cast<const uint32_t *>(base) + word0;
-        pos = (uint32_t)(bit_off - (word0 << 5));
+        const uint64_t group0 = bit_off >> 7;
+        g = reinterpret_cast<const uint4 *>(base) + group0;
+        pos = (uint32_t)(bit_off - (group0 << 7));
         end = pos + length;
-        const int64_t lim = (int64_t)frame_end_bit - (int64_t)(word0 << 5);
+        const int64_t lim = (int64_t)frame_end_bit - (int64_t)(group0 << 7);
         limit = lim < -(1 << 30) ? -(1 << 30) : (lim > (1 << 30) ? (1 << 30) : (int32_t)lim);
-        idx = pos >> 5;  // 0 or 1
-        uint32_t a, b, c, d;
-        load_pair(0, &a, &b);
-        load_pair(2, &c, &d);
-        if (idx == 0) { w0 = a; w1 = b; w2 = c; w3 = d; }
-        else { w0 = b; w1 = c; w2 = d; w3 = 0u; }
+        const uint4 p0 = g[0], p1 = g[1];
+        c = g[2];
+        g += 3;
+        filled = 0u;
+        commit(p0);
+        commit(p1);
     }
-    // the 32 bits at the read position
-    __device__ __forceinline__ uint32_t window() const {
-        const uint64_t two = ((uint64_t)w0 << 32) | (uint64_t)w1;
-        return (uint32_t)((two << (pos & 31)) >> 32);
+    // the 64 bits at the read position
+    __device__ __forceinline__ void window64(uint32_t &hi, uint32_t &lo) const {
+        const uint32_t wi = pos >> 5, sh = pos & 31u;
+        const uint32_t w0 = ring[(wi & 7u) * kHuffThreads], w1 = ring[((wi + 1u) & 7u) * kHuffThreads], w2 = ring[((wi + 2u) & 7u) * kHuffThreads];
+        hi = (uint32_t)(((((uint64_t)w0 << 32) | w1) << sh) >> 32);
+        lo = (uint32_t)(((((uint64_t)w1 << 32) | w2) << sh) >> 32);
     }
-    __device__ __forceinline__ uint32_t peek(int n) const { return window() >> (32 - n); }  // 1 <= n <= 32
-    __device__ __forceinline__ void skip(int n) {  // n <= 32
-        pos += (uint32_t)n;
-        if ((pos >> 5) != idx) {
-            ++idx;
-            w0 = w1;
-            w1 = w2;
-            w2 = w3;
-            if ((idx & 1u) == 0) load_pair(idx + 2, &w2, &w3);  // idx even again: the next aligned pair
-        }
+    __device__ __forceinline__ uint32_t window() const {  // the 32 bits at the read position
+        const uint32_t wi = pos >> 5, sh = pos & 31u;
+        const uint32_t w0 = ring[(wi & 7u) * kHuffThreads], w1 = ring[((wi + 1u) & 7u) * kHuffThreads];
+        return (uint32_t)(((((uint64_t)w0 << 32) | w1) << sh) >> 32);
     }
+    // scalefactors (at most five bits at a time; lanes on different paths): a lane feeds when it has to
     __device__ __forceinline__ uint32_t get(int n) {
         if (n == 0) return 0;
-        const uint32_t v = peek(n);
-        skip(n);
+        if (filled < (pos >> 5) + 2u) feed();
+        const uint32_t v = window() >> (32 - n);
+        pos += (uint32_t)n;
         return v;
     }
-    __device__ __forceinline__ uint32_t get1() { return get(1); }
 };
 
 // Scalefactors of one granule into the thread's LDS column sf[i * kHuffThreads] (rg_mp3dec.cpp: read_scalefactors_v1 /
 // read_scalefactors_lsf).  `reuse` = granule 1 of an MPEG-1 long block whose column already holds granule 0's values:
 // the groups flagged in scfsi keep them.
-__device__ __forceinline__ void huff_scalefactors(BitCache &b, const RgMp3HuffRec &r, bool lsf, bool reuse, uint8_t *__restrict__ sf,
+__device__ __forceinline__ void huff_scalefactors(BitRing &b, const RgMp3HuffRec &r, bool lsf, bool reuse, uint8_t *__restrict__ sf,
                                                   uint64_t *illegal, int *preflag) {
     constexpr int S = kHuffThreads;
     *illegal = 0;
@@ -882,22 +933,17 @@ __device__ __forceinline__ void huff_scalefactors(BitCache &b, const RgMp3HuffRe
         const int s2 = (int)((0x3232132132103210ull >> (4 * sc)) & 15);   // {0,1,2,3,0,1,2,3,1,2,3,1,2,3,2,3}
         if (r.block_type == 2) {
             int i = 0;
-            if (r.mixed) {
-                for (; i < 17; ++i) sf[i * S] = (uint8_t)b.get(s1);
-                for (int k = 0; k < 18; ++k) sf[(i++) * S] = (uint8_t)b.get(s2);
-            } else {
-                for (int k = 0; k < 18; ++k) sf[(i++) * S] = (uint8_t)b.get(s1);
-                for (int k = 0; k < 18; ++k) sf[(i++) * S] = (uint8_t)b.get(s2);
-            }
-            for (; i < 40; ++i) sf[i * S] = 0;
+            const int n1 = r.mixed ? 17 : 18;  // one loop, one copy of the bit reader's code
+            _Pragma("nounroll") for (; i < n1 + 18; ++i) sf[i * S] = (uint8_t)b.get(i < n1 ? s1 : s2);
+            _Pragma("nounroll") for (; i < 40; ++i) sf[i * S] = 0;
         } else {
-            for (int k = 0; k < 4; ++k) {
+            _Pragma("nounroll") for (int k = 0; k < 4; ++k) {
                 const int lo = k == 0 ? 0 : 1 + 5 * k, hi = 6 + 5 * k;  // bands 0-5, 6-10, 11-15, 16-20
                 const int bits = k < 2 ? s1 : s2;
                 if (reuse && ((r.scfsi >> k) & 1)) continue;
-                for (int band = lo; band < hi; ++band) sf[band * S] = (uint8_t)b.get(bits);
+                _Pragma("nounroll") for (int band = lo; band < hi; ++band) sf[band * S] = (uint8_t)b.get(bits);
             }
-            for (int i = 21; i < 40; ++i) sf[i * S] = 0;
+            _Pragma("nounroll") for (int i = 21; i < 40; ++i) sf[i * S] = 0;
         }
     } else {
         int slen[4], set;
@@ -919,37 +965,17 @@ __device__ __forceinline__ void huff_scalefactors(BitCache &b, const RgMp3HuffRe
             {{6, 6, 6, 3}, {12, 9, 9, 6}, {6, 12, 9, 6}},  {{8, 8, 5, 0}, {15, 12, 9, 0}, {6, 18, 9, 0}}};
         const int kind = r.block_type == 2 ? (r.mixed ? 2 : 1) : 0;
         int i = 0;
-        for (int k = 0; k < 4; ++k) {
+        _Pragma("nounroll") for (int k = 0; k < 4; ++k) {
             const int n = kPart[set][kind][k];
-            for (int q = 0; q < n; ++q, ++i) {
+            _Pragma("nounroll") for (int q = 0; q < n; ++q, ++i) {
                 const int v = (int)b.get(slen[k]);
                 sf[i * S] = (uint8_t)v;
                 if (r.intensity_right && slen[k] > 0 && v == (1 << slen[k]) - 1) *illegal |= 1ull << i;
             }
         }
-        for (; i < 40; ++i) sf[i * S] = 0;
+        _Pragma("nounroll") for (; i < 40; ++i) sf[i * S] = 0;
     }
 }
-
-// the spectrum leaves four words (eight lines) at a time, into the interleaved layout of rg_mp3_is_index
-struct RowOut {
-    uint4 *__restrict__ row;  // the unit's first piece; its 72 pieces are 2^RG_MP3_IS_GROUP_LOG2 pieces apart
-    uint32_t a, b, c;
-    // `line` even; words arrive in order, one per pair of lines, from line 0 on.  The last three wait in a shift register: no
-    // choice of a slot per word (three branches per call in a loop whose lanes sit at different lines), the fourth word of a
-    // piece finds the other three in place.
-    __device__ __forceinline__ void put(int line, uint32_t word) {
-        if (((line >> 1) & 3) == 3) row[(line >> 3) << RG_MP3_IS_GROUP_LOG2] = make_uint4(a, b, c, word);
-        a = b;
-        b = c;
-        c = word;
-    }
-    // zeros from `line` (even) to the end of its 16-byte piece; the pieces behind it stay unwritten: the back half does not
-    // read past the unit's nz (rounded up to a piece)
-    __device__ __forceinline__ void finish(int line) {
-        for (; (line & 7) != 0 && line < 576; line += 2) put(line, 0u);
-    }
-};
 
 }  // namespace
 
@@ -961,32 +987,59 @@ extern "C" int rg_hf_dbg_read(void *out) { return (int)hipMemcpyFromSymbol(out, 
 #else
 #define RG_HF_STAMP(e) do { } while (0)
 #endif
-__global__ void __launch_bounds__(kHuffThreads)
+#ifndef RG_HF_WAVES
+#define RG_HF_WAVES 4
+#endif
+__global__ void __launch_bounds__(kHuffThreads) __attribute__((amdgpu_waves_per_eu(RG_HF_WAVES, RG_HF_WAVES)))
 rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *__restrict__ H,
                       const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks, const RgMp3HuffRec *__restrict__ recs,
-                      const uint8_t *__restrict__ main, rg_mp3_unit *__restrict__ units, int16_t *__restrict__ is, uint64_t total_units) {
-    __shared__ uint32_t E_all[RG_MP3_HUFF_LDS_ENTRIES];
-    __shared__ uint32_t t_base[32];
-    __shared__ uint8_t t_pbits[32], t_linbits[32], quadA[64];
+                      const uint8_t *__restrict__ main, rg_mp3_unit *__restrict__ units, int16_t *__restrict__ is,
+                      const uint32_t *__restrict__ perm, const uint32_t *__restrict__ sortw, uint64_t total_units) {
+    __shared__ uint16_t E_all[RG_MP3_HUFF_LDS_ENTRIES];
+    __shared__ uint32_t t_rp[32];
+    __shared__ uint8_t quadA[64];
     __shared__ uint8_t sf_all[40 * kHuffThreads];
+    __shared__ uint32_t stg_all[8 * kHuffThreads];
+    __shared__ uint32_t ring_all[8 * kHuffThreads];
     const int tid = threadIdx.x;
     RG_HF_STAMP(0);
-    const uint32_t n_e = H->n_entries;  // <= RG_MP3_HUFF_LDS_ENTRIES: checked when the tables are uploaded
-    for (uint32_t i = tid; i < n_e; i += kHuffThreads) E_all[i] = H->e[i];
-    if (tid < 32) { t_base[tid] = H->base[tid]; t_pbits[tid] = H->primary_bits[tid]; t_linbits[tid] = H->linbits[tid]; }
+    const uint32_t n_e = H->n_entries;  // + 2 <= RG_MP3_HUFF_LDS_ENTRIES: checked when the tables are uploaded; e16[n_e], [n_e + 1] = 0
+    for (uint32_t i = tid; 2 * i < n_e + 2; i += kHuffThreads) reinterpret_cast<uint32_t *>(E_all)[i] = reinterpret_cast<const uint32_t *>(H->e16)[i];
+    // what the big_values loop needs of a table in one word: first entry | (32 - primary bits) << 16 | linbits << 24.  A table
+    // that codes nothing (0, 4, 14) is the two zero entries behind the last table looked at through one bit: a code of no bits
+    // for the pair (0, 0) -- the loop has no case for it
+    if (tid < 32) {
+        const uint32_t P = H->primary_bits[tid];
+        t_rp[tid] = P ? (H->base[tid] | ((32u - P) << 16) | ((uint32_t)H->linbits[tid] << 24)) : (n_e | (31u << 16));
+    }
     if (tid < 64) quadA[tid] = H->quadA[tid];
     __syncthreads();
     RG_HF_STAMP(1);
-    const uint64_t u = (uint64_t)blockIdx.x * kHuffThreads + (uint64_t)tid;
-    if (u >= total_units) return;
+    // Lane i takes the i-th unit of the chunk's units ordered by big_values (rg_mp3_sort_*): a wave lasts as long as its
+    // longest lane, and in stream order a wave holds mid and side channels, loud and quiet granules side by side -- 2 to 3
+    // times the iterations its units need on average.
+#ifdef RG_HF_NOSTRIPE
+    const uint32_t slot = blockIdx.x * kHuffThreads + (uint32_t)tid;
+#else
+    // The sorted order is dealt to the blocks in stripes: wave w of a block takes the block's share of the w-th eighth of the
+    // order (waves w and w + 4, which share a SIMD, the eighths w and 7 - w), so that every block, every CU and every SIMD gets
+    // the same mix of long and short waves whatever the dispatcher does: a chunk is one generation of blocks, and the launch
+    // lasts as long as its most loaded SIMD.
+    const uint32_t wv = (uint32_t)tid >> 6;
+    const uint32_t slot = (((wv < 4u ? wv : 11u - wv) * gridDim.x + blockIdx.x) << 6) + ((uint32_t)tid & 63u);
+#endif
+    const uint32_t n_valid = sortw[RG_MP3_SORT_NVALID];
+    if ((slot & ~63u) >= n_valid) return;  // the whole wave lies behind the last unit that decodes
+    // the lanes behind it in the one wave that holds it decode that last unit once more (the same bytes to the same places):
+    // the loops below are the wave's, and nothing in them has to ask whether a lane is there
+    const uint64_t u = perm[slot < n_valid ? slot : n_valid - 1u];
     const uint32_t ti = find_by_unit(tracks, n_tracks, u);
     const RgMp3DevTrack tr = tracks[ti];
     const int nch = (int)tr.channels, rr = (int)tr.rate_row;
-    const uint64_t local = u - tr.unit_base;
-    if (local >= (uint64_t)tr.n_granules * nch) return;  // past what the frame parser found decodable
     const RgMp3HuffRec r = recs[u];
     uint8_t *__restrict__ sf = sf_all + tid;
-    BitCache b;  // the records' bit offsets are relative to the track's stream
+    BitRing b;  // the records' bit offsets are relative to the track's stream
+    b.ring = ring_all + tid;
     uint64_t illegal = 0;
     int preflag = 0;
     const bool reuse = !tr.lsf && r.gr == 1 && r.block_type != 2 && r.scfsi != 0;
@@ -1015,88 +1068,151 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
         r1e = T->sfb_long[rr][i1 > 22 ? 22 : i1];
     }
     // ---- Huffman-coded spectrum ----
-    RowOut out{reinterpret_cast<uint4 *>(is) + rg_mp3_is_index(u, 0, RG_MP3_IS_GROUP_LOG2), 0u, 0u, 0u};
-    int line = 0;
-    // One loop over the big_values pairs of all three regions: which table a pair uses is a per-lane choice made with
-    // selects, so the lanes of a wave -- which sit in different regions of different granules -- run the same instructions
-    // instead of taking turns through three region loops.
+    // Out: the unit's row of RG_MP3_ROW_BYTES, sign and magnitude (rg_mp3dev.h): line i's byte `sign << 7 | |v| & 127` at i,
+    // and |v| >> 7 at 576 + i for the lines below hi_lines -- the end of the last region whose table has seven or more
+    // linbits; no other line can hold a value above 127 -- which for most units is none.  Both loops run over LINE NUMBERS
+    // that are the same for the whole wave (a lane whose run is shorter sits out): so the word a lane has just finished is
+    // the same word of its row for every lane, it goes to the lane's LDS column, and when the eighth word of a 32-byte sector
+    // is in, every lane stores its sector from there at once -- one branch of the wave, not 64 lanes taking the detour in
+    // turns; a 16-byte store per lane, half a sector, would be a read-modify-write at the memory, since no two lanes of a wave
+    // share a line (they are units of equal length from anywhere in the chunk).
+    const int e0 = r0e < bv2 ? r0e : bv2, e1 = r1e < bv2 ? r1e : bv2;
+    const uint32_t rp0 = t_rp[r.table_select[0]], rp1 = t_rp[r.table_select[1]], rp2 = t_rp[r.table_select[2]];
+    const int hi_lines = ((rp2 >> 24) >= 7u && e1 < bv2) ? bv2 : (((rp1 >> 24) >= 7u && e0 < e1) ? e1 : (((rp0 >> 24) >= 7u && e0 > 0) ? e0 : 0));
+    const int hi_q = (hi_lines + 3) >> 2;
+    uint32_t *__restrict__ const row = reinterpret_cast<uint32_t *>(is) + u * (RG_MP3_ROW_BYTES / 4);
+    uint32_t *__restrict__ const stg = stg_all + tid;
+    auto store_sector = [&](const int m) {  // the eight words of sector m from the lane's column
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = stg[i * kHuffThreads];
+#ifdef RG_HF_NOSTORE  // experiment (wrong results): the spectrum is not written
+        if (w[0] == 0x12345678u)
+#endif
+        {
+            uint4 *const dst = reinterpret_cast<uint4 *>(row + 8 * m);
+            dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+    };
+    auto wave_max = [](int v) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(v, d); v = o > v ? o : v; }
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    uint32_t pend = 0u, pend_hi = 0u;  // the first pair of the word under way
+    int hi_found = 0;                  // words of the second plane up to the last one that holds anything
     {
-        const int e0 = r0e < bv2 ? r0e : bv2, e1 = r1e < bv2 ? r1e : bv2;
-        const int t0 = r.table_select[0], t1 = r.table_select[1], t2 = r.table_select[2];
-        const uint32_t tb0 = t_base[t0], tb1 = t_base[t1], tb2 = t_base[t2];
-        const int P0 = t_pbits[t0], P1 = t_pbits[t1], P2 = t_pbits[t2];
-        const int lb0 = t_linbits[t0], lb1 = t_linbits[t1], lb2 = t_linbits[t2];
-        while (line < bv2) {
-            const bool in0 = line < e0, in1 = line < e1;
-            const int P = in0 ? P0 : (in1 ? P1 : P2);
-            uint32_t word = 0u;
-            if (P != 0 && b.pos < b.end) {  // table 0 codes nothing; a granule whose bits have run out is zeros from here on
-                const uint32_t *__restrict__ E = E_all + (in0 ? tb0 : (in1 ? tb1 : tb2));
-                const int linbits = in0 ? lb0 : (in1 ? lb1 : lb2);
-                // code, escapes and signs come out of one 32-bit window whenever they fit (a code is at most 19 bits long)
-                const uint32_t win = b.window();
-                uint32_t e = E[win >> (32 - P)];
-                int used = 0;
-                if (e & 0x80000000u) {
-                    e = E[((e >> 8) & 0x7FFFFF) + ((win << P) >> (32 - (int)(e & 0xFF)))];
-                    used = P;
-                }
-                used += (int)(e & 0xFF);
-                int x = (int)((e >> 12) & 15), y = (int)((e >> 8) & 15);
-                if (linbits == 0 || (x != 15 && y != 15)) {
-                    // a sign bit follows each non-zero value: selects, no branches (a code is at most 19 bits long)
-                    const int nx = x != 0;
-                    x = (((win << used) >> 31) & (uint32_t)nx) ? -x : x;
-                    used += nx;
-                    const int ny = y != 0;
-                    y = (((win << used) >> 31) & (uint32_t)ny) ? -y : y;
-                    used += ny;
-                    b.skip(used);
-                } else {
-                    b.skip(used);
-                    if (x) {
-                        if (x == 15) x += (int)b.get(linbits);
-                        if (b.get1()) x = -x;
-                    }
-                    if (y) {
-                        if (y == 15) y += (int)b.get(linbits);
-                        if (b.get1()) y = -y;
-                    }
-                }
-                word = ((uint32_t)x & 0xFFFFu) | ((uint32_t)y << 16);
+        // One loop over the big_values pairs of all three regions, and one path through it: which table a pair uses, whether
+        // its code runs on into a second table, whether its values have linbits or signs are per-lane SELECTS -- the lanes of a
+        // wave sit in different regions of different granules, and a branch that one lane takes costs the wave its whole body.
+        const int wave_bv2 = wave_max(bv2);
+        for (int L = 0; L < wave_bv2; L += 4) {  // a word of the row per step
+            b.feed();
+            uint32_t lo16[2], hi16[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int Lh = L + 2 * h;
+                const bool live = Lh < bv2 && b.pos < b.end;  // a granule whose bits have run out is zeros from here on
+                const uint32_t rp = Lh < e0 ? rp0 : (Lh < e1 ? rp1 : rp2);
+                const uint16_t *__restrict__ E = E_all + (rp & 0xFFFFu);
+                const uint32_t sP = (rp >> 16) & 0xFFu, linbits = rp >> 24;
+                uint32_t W0, W1;
+                b.window64(W0, W1);
+                const uint32_t e1st = E[W0 >> sP];
+                // a code longer than the primary bits: the entry names a second table and how many more bits index it; for a
+                // leaf the same arithmetic reads some entry of the table that is then not used
+                const uint32_t sub = e1st & 15u;
+                const uint32_t e2nd = E[((e1st >> 4) & 0x7FFu) + __builtin_amdgcn_ubfe(W0 << (32u - sP), 32u - sub, sub)];
+                const bool link = (e1st & 0x8000u) != 0u;
+                const uint32_t e = link ? e2nd : e1st;
+                uint32_t used = (link ? 32u - sP : 0u) + (e & 15u);
+                uint32_t x = (e >> 8) & 15u, y = (e >> 4) & 15u;
+                // behind the code: [linbits of x] [sign of x] [linbits of y] [sign of y], each only if its value calls for it
+                uint32_t T = (uint32_t)(((((uint64_t)W0 << 32) | W1) << used) >> 32);
+                const uint32_t lx = x == 15u ? linbits : 0u;
+                x += __builtin_amdgcn_ubfe(T, 32u - lx, lx);
+                T <<= lx;
+                const uint32_t nx = x != 0u ? 1u : 0u, sx = (T >> 31) & nx;
+                T <<= nx;
+                const uint32_t ly = y == 15u ? linbits : 0u;
+                y += __builtin_amdgcn_ubfe(T, 32u - ly, ly);
+                T <<= ly;
+                const uint32_t ny = y != 0u ? 1u : 0u, sy = (T >> 31) & ny;
+                used += lx + nx + ly + ny;
+                b.pos += live ? used : 0u;
+                lo16[h] = live ? ((x & 127u) | (sx << 7) | ((y & 127u) << 8) | (sy << 15)) : 0u;
+                hi16[h] = live ? ((x >> 7) | ((y >> 7) << 8)) : 0u;
             }
-            out.put(line, word);
-            line += 2;
+            const uint32_t lo0 = lo16[0], lo1 = lo16[1], hi0 = hi16[0], hi1 = hi16[1];
+            const int w = L >> 2;
+            if (L + 2 < bv2) {  // both pairs are the lane's
+                stg[(w & 7) * kHuffThreads] = lo0 | (lo1 << 16);
+                if (w < hi_q) {
+                    const uint32_t hw = hi0 | (hi1 << 16);
+                    row[RG_MP3_ROW_BYTES / 8 + w] = hw;
+                    if (hw) hi_found = w + 1;
+                }
+                if ((w & 7) == 7) store_sector(w >> 3);  // the test of w is the wave's
+            } else if (L < bv2) {  // the run ends inside this word: count1 goes on in it
+                pend = lo0;
+                pend_hi = hi0;
+            }
+        }
+        if ((bv2 & 2) && (bv2 >> 2) < hi_q) {  // the count1 lines beside it are 0 or +-1
+            row[RG_MP3_ROW_BYTES / 8 + (bv2 >> 2)] = pend_hi;
+            if (pend_hi) hi_found = (bv2 >> 2) + 1;
         }
     }
     RG_HF_STAMP(3);
-    while (line <= 572 && b.pos < b.end) {
-        const uint32_t win = b.window();
-        int v, used;
-        if (r.count1table) {
-            v = (int)(~(win >> 28)) & 15;
-            used = 4;
-        } else {
-            const uint8_t q = quadA[win >> 26];
-            used = q >> 4;
-            v = q & 15;
-        }
-        int q4[4];
+    // count1: a quadruple is four bytes.  Where the big_values run ends in the middle of a word (bv2 = 2 mod 4) the lane's
+    // quadruples straddle the words: it carries two bytes from word to word.
+    int line = bv2, nz = bv2;
+    {
+        const int w_first = bv2 >> 2, sh = (bv2 & 2) ? 16 : 0;
+        uint32_t carry = pend;
+        bool done = false;
+        int zero_until = -1;  // a lane that is through fills its last sector with zeros
+        b.feed();
+        for (int w = 143 - wave_max(143 - w_first); w < 144; ++w) {
+            if ((w & 3) == 3) b.feed();  // a quadruple is ten bits at most
+            const bool mine = !done && w >= w_first;  // then line == 4 w (+ 2)
+            const bool take = mine && line <= 572 && b.pos < b.end;
+            const uint32_t win = b.window();
+            const uint32_t qa = quadA[win >> 26];
+            const uint32_t v = r.count1table ? (~(win >> 28)) & 15u : qa & 15u;
+            uint32_t used = r.count1table ? 4u : qa >> 4;
+            uint32_t q = 0u;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {  // 0, or +-1 with the sign in the next bit of the stream: no branches
-            const int bit = (v >> (3 - k)) & 1;
-            q4[k] = bit - 2 * (bit & (int)((win << used) >> 31));
-            used += bit;
+            for (int k = 0; k < 4; ++k) {  // 0, or 1 with its sign in the next bit of the stream
+                const uint32_t bit = (v >> (3 - k)) & 1u;
+                q |= (bit | ((bit & ((win << used) >> 31)) << 7)) << (8 * k);
+                used += bit;
+            }
+            const bool got = take && b.pos + used <= b.end;  // else the quadruple ran past the granule's bits: stuffing, not data
+            if (take) b.pos += used;
+            if (got) {
+                const uint64_t full = (uint64_t)carry | ((uint64_t)q << sh);
+                stg[(w & 7) * kHuffThreads] = (uint32_t)full;
+                carry = (uint32_t)(full >> 32);
+                line += 4;
+            } else if (mine) {
+                done = true;
+                nz = line;
+                stg[(w & 7) * kHuffThreads] = carry;  // lines 4 w, 4 w + 1 if the lane carries, else nothing: zeros
+                zero_until = w | 7;
+            } else if (w <= zero_until) {
+                stg[(w & 7) * kHuffThreads] = 0u;
+            }
+            if ((w & 7) == 7) {
+                // lanes with lines in this sector that the big_values loop has not stored already
+                if (w_first <= w && (!done || ((nz + 3) >> 2) > (w & ~7))) store_sector(w >> 3);
+                if (__builtin_amdgcn_ballot_w64(!done && w_first < 144) == 0) break;
+            }
         }
-        b.skip(used);
-        if (b.pos > b.end) break;  // the quadruple ran past the granule's bits: stuffing, not data
-        out.put(line, ((uint32_t)q4[0] & 0xFFFFu) | ((uint32_t)q4[1] << 16));
-        out.put(line + 2, ((uint32_t)q4[2] & 0xFFFFu) | ((uint32_t)q4[3] << 16));
-        line += 4;
+        if (!done) nz = line > 576 ? 576 : line;
     }
     RG_HF_STAMP(4);
-    const int nz = line;
-    out.finish(line);
     // ---- the unit ----
     rg_mp3_unit o;
 #pragma unroll
@@ -1113,7 +1229,8 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
     o.short_start = (uint8_t)short_start;
     o.mode_ext = r.mode_ext;
     o.intensity_scale = r.intensity_scale;
-    o.reserved[0] = o.reserved[1] = 0;
+    o.reserved[0] = (uint8_t)hi_found;  // words of the row's second plane worth reading (device spectra only)
+    o.reserved[1] = 0;
     units[u] = o;
     RG_HF_STAMP(5);
 }
@@ -1227,22 +1344,115 @@ rg_mp3_frames_scan_kernel(RgMp3DevTrack *__restrict__ tracks, const uint32_t *__
     }
 }
 
-extern "C" hipError_t rg_launch_mp3_huffman(const RgMp3DevTables *d_tab, const RgMp3DevHuff *d_huff, const RgMp3DevTrack *d_tracks,
-                                            uint32_t n_tracks, const RgMp3HuffRec *d_recs, const uint8_t *d_main, rg_mp3_unit *d_units,
-                                            int16_t *d_is, uint64_t total_units, hipStream_t s) {
+// ---------------------------------------------------------------------------------------------------------------------
+// The lane sort of the Huffman stage.  The Huffman kernel runs one thread per unit and a wave lasts as long as its longest
+// lane: in stream order a wave holds both channels of sixteen frames -- the mid channel of a loud granule beside the side
+// channel of a quiet one -- and executes 2 to 3 times the iterations its units need on average (the dense 128 kb/s
+// joint-stereo stream: sum over waves of (longest big_values run + longest count1 run) = 2.9 x the mean; ordered by
+// big_values 1.3 x).  So the units of a chunk are dealt to the lanes by a counting sort on big_values >> 2, heaviest first:
+// a histogram, a scan of its 73 buckets, a scatter with one returning atomic per bucket and block.  The order inside a bucket
+// is whatever the atomics make it -- every unit is decoded to its own row whichever lane takes it.
+namespace {
+constexpr int kSortThreads = 1024, kSortPer = 4;
+// bucket of unit u, -1 for a unit past what the frame parser found decodable
+__device__ __forceinline__ int rg_mp3_sort_key(const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks, const RgMp3HuffRec *__restrict__ recs,
+                                               uint64_t u, uint64_t total_units) {
+    if (u >= total_units) return -1;
+    const uint32_t ti = find_by_unit(tracks, n_tracks, u);
+    const uint64_t local = u - tracks[ti].unit_base;
+    if (local >= (uint64_t)tracks[ti].n_granules * tracks[ti].channels) return -1;
+    const uint32_t bv = recs[u].big_values;
+    return 72 - (int)((bv > 288u ? 288u : bv) >> 2);
+}
+}  // namespace
+
+__global__ void __launch_bounds__(kSortThreads)
+rg_mp3_sort_hist_kernel(const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks, const RgMp3HuffRec *__restrict__ recs, uint64_t total_units,
+                        uint32_t *__restrict__ sortw) {
+    __shared__ uint32_t h[RG_MP3_SORT_BUCKETS];
+    const int tid = threadIdx.x;
+    if (tid < RG_MP3_SORT_BUCKETS) h[tid] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortPer; ++k) {
+        const int key = rg_mp3_sort_key(tracks, n_tracks, recs, ((uint64_t)blockIdx.x * kSortPer + k) * kSortThreads + tid, total_units);
+        if (key >= 0) atomicAdd(&h[key], 1u);
+    }
+    __syncthreads();
+    if (tid < RG_MP3_SORT_BUCKETS && h[tid]) atomicAdd(&sortw[tid], h[tid]);
+}
+
+// one block of 128 threads: exclusive prefix of the histogram -> the buckets' cursors, the total -> sortw[NVALID]; the
+// histogram is zero again afterwards (the next chunk of this staging set adds into it)
+__global__ void __launch_bounds__(128) rg_mp3_sort_scan_kernel(uint32_t *__restrict__ sortw) {
+    __shared__ uint32_t first_wave_total;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t v = tid < RG_MP3_SORT_BUCKETS ? sortw[tid] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t x = __shfl_up(inc, d);
+        if (lane >= d) inc += x;
+    }
+    if (tid == 63) first_wave_total = inc;
+    __syncthreads();
+    const uint32_t excl = inc - v + (tid >= 64 ? first_wave_total : 0u);
+    if (tid < RG_MP3_SORT_BUCKETS) {
+        sortw[RG_MP3_SORT_BUCKETS + tid] = excl;
+        sortw[tid] = 0u;
+    }
+    if (tid == 127) sortw[RG_MP3_SORT_NVALID] = excl + v;
+}
+
+__global__ void __launch_bounds__(kSortThreads)
+rg_mp3_sort_scatter_kernel(const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks, const RgMp3HuffRec *__restrict__ recs, uint64_t total_units,
+                           uint32_t *__restrict__ sortw, uint32_t *__restrict__ perm) {
+    __shared__ uint32_t h[RG_MP3_SORT_BUCKETS], base[RG_MP3_SORT_BUCKETS];
+    const int tid = threadIdx.x;
+    if (tid < RG_MP3_SORT_BUCKETS) h[tid] = 0u;
+    __syncthreads();
+    int key[kSortPer];
+    uint32_t rank[kSortPer];
+#pragma unroll
+    for (int k = 0; k < kSortPer; ++k) {
+        key[k] = rg_mp3_sort_key(tracks, n_tracks, recs, ((uint64_t)blockIdx.x * kSortPer + k) * kSortThreads + tid, total_units);
+        rank[k] = key[k] >= 0 ? atomicAdd(&h[key[k]], 1u) : 0u;
+    }
+    __syncthreads();
+    if (tid < RG_MP3_SORT_BUCKETS && h[tid]) base[tid] = atomicAdd(&sortw[RG_MP3_SORT_BUCKETS + tid], h[tid]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortPer; ++k)
+        if (key[k] >= 0) perm[base[key[k]] + rank[k]] = (uint32_t)(((uint64_t)blockIdx.x * kSortPer + k) * kSortThreads + tid);
+}
+
+// sortw: RG_MP3_SORT_WORDS words, zero before the first use; perm: total_units words
+extern "C" hipError_t rg_launch_mp3_sort(const RgMp3DevTrack *d_tracks, uint32_t n_tracks, const RgMp3HuffRec *d_recs, uint64_t total_units,
+                                         uint32_t *d_sortw, uint32_t *d_perm, hipStream_t s) {
     if (total_units == 0) return hipSuccess;
-    hipLaunchKernelGGL(rg_mp3_huffman_kernel, dim3((uint32_t)((total_units + kHuffThreads - 1) / kHuffThreads)), dim3(kHuffThreads), 0, s, d_tab,
-                       d_huff, d_tracks, n_tracks, d_recs, d_main, d_units, d_is, total_units);
+    const uint32_t blocks = (uint32_t)((total_units + kSortThreads * kSortPer - 1) / (kSortThreads * kSortPer));
+    hipLaunchKernelGGL(rg_mp3_sort_hist_kernel, dim3(blocks), dim3(kSortThreads), 0, s, d_tracks, n_tracks, d_recs, total_units, d_sortw);
+    hipLaunchKernelGGL(rg_mp3_sort_scan_kernel, dim3(1), dim3(128), 0, s, d_sortw);
+    hipLaunchKernelGGL(rg_mp3_sort_scatter_kernel, dim3(blocks), dim3(kSortThreads), 0, s, d_tracks, n_tracks, d_recs, total_units, d_sortw, d_perm);
     return hipGetLastError();
 }
 
-// n_runs: blocks of the grid, one per run of RG_MP3_RUN granules (RgMp3DevTrack::run_base); is_group_log2: layout of d_is
-// (rg_mp3_is_index): RG_MP3_IS_GROUP_LOG2 behind the device Huffman stage, 0 for spectra parsed on the host
+extern "C" hipError_t rg_launch_mp3_huffman(const RgMp3DevTables *d_tab, const RgMp3DevHuff *d_huff, const RgMp3DevTrack *d_tracks,
+                                            uint32_t n_tracks, const RgMp3HuffRec *d_recs, const uint8_t *d_main, rg_mp3_unit *d_units,
+                                            int16_t *d_is, uint64_t total_units, const uint32_t *d_perm, const uint32_t *d_sortw, hipStream_t s) {
+    if (total_units == 0) return hipSuccess;
+    hipLaunchKernelGGL(rg_mp3_huffman_kernel, dim3((uint32_t)((total_units + kHuffThreads - 1) / kHuffThreads)), dim3(kHuffThreads), 0, s, d_tab,
+                       d_huff, d_tracks, n_tracks, d_recs, d_main, d_units, d_is, d_perm, d_sortw, total_units);
+    return hipGetLastError();
+}
+
+// n_runs: blocks of the grid, one per run of RG_MP3_RUN granules (RgMp3DevTrack::run_base); planes: the form of d_is (rg_mp3dev.h):
+// 1 = two planes of a byte per line (behind the device Huffman stage), 0 = rows of int16 (spectra parsed on the host)
 extern "C" hipError_t rg_launch_mp3_backhalf(const RgMp3DevTables *d_tab, const RgMp3DevTrack *d_tracks, uint32_t n_tracks,
-                                             uint32_t n_runs, const rg_mp3_unit *d_units, const int16_t *d_is, uint32_t is_group_log2,
+                                             uint32_t n_runs, const rg_mp3_unit *d_units, const int16_t *d_is, uint32_t planes,
                                              hipStream_t s) {
     if (n_runs == 0) return hipSuccess;
-    hipLaunchKernelGGL(rg_mp3_backhalf_kernel, dim3(n_runs), dim3(RG_MP3_BH_THREADS), 0, s, d_tab, d_tracks, n_tracks, d_units, d_is, is_group_log2);
+    hipLaunchKernelGGL(rg_mp3_backhalf_kernel, dim3(n_runs), dim3(RG_MP3_BH_THREADS), 0, s, d_tab, d_tracks, n_tracks, d_units, d_is, planes);
     return hipGetLastError();
 }
 

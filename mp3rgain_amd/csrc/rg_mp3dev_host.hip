@@ -11,7 +11,8 @@
 
 extern "C" {
 hipError_t rg_launch_mp3_huffman(const RgMp3DevTables *, const RgMp3DevHuff *, const RgMp3DevTrack *, uint32_t, const RgMp3HuffRec *,
-                                 const uint8_t *, rg_mp3_unit *, int16_t *, uint64_t, hipStream_t);
+                                 const uint8_t *, rg_mp3_unit *, int16_t *, uint64_t, const uint32_t *, const uint32_t *, hipStream_t);
+hipError_t rg_launch_mp3_sort(const RgMp3DevTrack *, uint32_t, const RgMp3HuffRec *, uint64_t, uint32_t *, uint32_t *, hipStream_t);
 hipError_t rg_launch_mp3_backhalf(const RgMp3DevTables *, const RgMp3DevTrack *, uint32_t, uint32_t, const rg_mp3_unit *,
                                   const int16_t *, uint32_t, hipStream_t);
 hipError_t rg_launch_mp3_frames(RgMp3DevTrack *, uint32_t, uint32_t, const uint8_t *, uint32_t *, RgMp3HuffRec *, uint32_t *, hipStream_t);
@@ -32,6 +33,17 @@ int rg_mp3_rate_row(uint32_t sample_rate) {
     return -1;
 }
 
+// the lane sort's buffers of staging set `set` for a chunk of `units` units
+static int ensure_sort(rg_ctx *c, int set, uint64_t units, hipStream_t s) {
+    if (!c->d_mp3_sortw_set[set].p) {
+        RG_HIP(c, c->d_mp3_sortw_set[set].reserve(RG_MP3_SORT_WORDS));
+        RG_HIP(c, hipMemsetAsync(c->d_mp3_sortw_set[set].p, 0, RG_MP3_SORT_WORDS * sizeof(uint32_t), s));
+        RG_HIP(c, hipStreamSynchronize(s));  // the sort may run on another stream than `s`
+    }
+    RG_HIP(c, c->d_mp3_perm_set[set].reserve(units ? units : 1));
+    return RG_OK;
+}
+
 static int ensure_tables(rg_ctx *c) {
     if (!c->mp3_tab_ready && !rg_cpu_has_fma()) return rg_set_err(c, RG_ERR_DEVICE, "this build of the MP3 decoder needs a host CPU with FMA3");
     if (!c->mp3_tab_ready) {
@@ -43,7 +55,7 @@ static int ensure_tables(rg_ctx *c) {
         RG_HIP(c, e);
         RgMp3DevHuff *hf = new RgMp3DevHuff();
         rg_mp3_fill_device_huff(hf);
-        if (hf->n_entries > RG_MP3_HUFF_LDS_ENTRIES) {
+        if (hf->n_entries + 2 > RG_MP3_HUFF_LDS_ENTRIES) {
             const uint32_t ne = hf->n_entries;
             delete hf;
             return rg_set_err(c, RG_ERR_DEVICE, "Huffman tables (%u entries) do not fit the kernel's LDS image", ne);
@@ -92,7 +104,7 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
             if (it.recs) { any_recs = true; mainb += (it.main_len + 15) & ~(uint64_t)15; }
         }
         if (units) {
-            RG_HIP(c, c->d_mp3_is.reserve(((units + RG_MP3_IS_GROUP - 1) / RG_MP3_IS_GROUP) * RG_MP3_IS_GROUP * 576));  // whole groups (rg_mp3_is_index)
+            RG_HIP(c, c->d_mp3_is.reserve(units * (RG_MP3_ROW_BYTES / 2) + 64));
             RG_HIP(c, c->d_mp3_units.reserve(units * sizeof(rg_mp3_unit)));
             RG_HIP(c, c->d_mp3_tracks.reserve(tr.size() * sizeof(RgMp3DevTrack)));
             if (any_recs) {
@@ -118,11 +130,16 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
             const RgMp3DevTrack *d_tr = reinterpret_cast<const RgMp3DevTrack *>(c->d_mp3_tracks.p);
             if (any_recs) {
                 // a chunk is all of one kind (the file layer never mixes them); the Huffman stage fills d_mp3_is / d_mp3_units
+                rc = ensure_sort(c, 0, ub, s);
+                if (rc != RG_OK) return rc;
+                RG_HIP(c, rg_launch_mp3_sort(d_tr, (uint32_t)tr.size(), reinterpret_cast<const RgMp3HuffRec *>(c->d_mp3_recs.p), ub,
+                                             c->d_mp3_sortw_set[0].p, c->d_mp3_perm_set[0].p, s));
                 RG_HIP(c, rg_launch_mp3_huffman(d_tab, d_huff, d_tr, (uint32_t)tr.size(), reinterpret_cast<const RgMp3HuffRec *>(c->d_mp3_recs.p),
-                                                c->d_mp3_main.p, reinterpret_cast<rg_mp3_unit *>(c->d_mp3_units.p), c->d_mp3_is.p, ub, s));
+                                                c->d_mp3_main.p, reinterpret_cast<rg_mp3_unit *>(c->d_mp3_units.p), c->d_mp3_is.p, ub,
+                                                c->d_mp3_perm_set[0].p, c->d_mp3_sortw_set[0].p, s));
             }
             RG_HIP(c, rg_launch_mp3_backhalf(d_tab, d_tr, (uint32_t)tr.size(), hb, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p),
-                                             c->d_mp3_is.p, any_recs ? RG_MP3_IS_GROUP_LOG2 : 0u, s));
+                                             c->d_mp3_is.p, any_recs ? 1u : 0u, s));
             // the chunk buffers (and `tr`) are reused by the next chunk
             RG_HIP(c, hipStreamSynchronize(s));
         }
@@ -195,10 +212,12 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
     // grow-only buffers; growing one frees the old allocation, which waits for the kernels still using it
     RG_HIP(c, c->d_mp3_stage[set].reserve(bytes + 64));
     if (ub) {
-        RG_HIP(c, c->d_mp3_is.reserve(((ub + RG_MP3_IS_GROUP - 1) / RG_MP3_IS_GROUP) * RG_MP3_IS_GROUP * 576));  // whole groups (rg_mp3_is_index)
+        RG_HIP(c, c->d_mp3_is.reserve(ub * (RG_MP3_ROW_BYTES / 2) + 64));
         RG_HIP(c, c->d_mp3_units.reserve(ub * sizeof(rg_mp3_unit)));
         RG_HIP(c, c->d_mp3_recs_set[set].reserve(ub * sizeof(RgMp3HuffRec)));
         RG_HIP(c, c->d_mp3_tiles_set[set].reserve((size_t)tb * 2));
+        rc = ensure_sort(c, set, ub, s);
+        if (rc != RG_OK) return rc;
     }
     hipStream_t cs = c->mp3_copy_stream;
     hipEvent_t *ev = c->mp3_bench_ev;  // measurement hook (rg_mp3_decode_bench): the kernels' boundaries on their own stream
@@ -210,7 +229,11 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
     // The frame parser -- three small launches, a block per 256 frames: latency, not work -- follows its block's copy on the copy
     // stream, i.e. it runs beside the Huffman / back-half kernels of the chunk before instead of between them and this chunk's.
     // (Under the measurement hook it stays in line, so that the three stages' times remain what the events around them say.)
-    if (ub && !ev) RG_HIP(c, rg_launch_mp3_frames(d_tr, (uint32_t)n, tb, d_chunk, c->d_mp3_tiles_set[set].p, d_recs, c->d_mp3_results.p, cs));
+    // The lane sort of the Huffman stage (three more small launches) reads the records the parser has just written.
+    if (ub && !ev) {
+        RG_HIP(c, rg_launch_mp3_frames(d_tr, (uint32_t)n, tb, d_chunk, c->d_mp3_tiles_set[set].p, d_recs, c->d_mp3_results.p, cs));
+        RG_HIP(c, rg_launch_mp3_sort(d_tr, (uint32_t)n, d_recs, ub, c->d_mp3_sortw_set[set].p, c->d_mp3_perm_set[set].p, cs));
+    }
     RG_HIP(c, hipEventRecord(staged, cs));
     RG_HIP(c, hipStreamWaitEvent(s, staged, 0));
     if (ub) {
@@ -219,13 +242,14 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
         if (ev) {
             RG_HIP(c, hipEventRecord(ev[0], s));
             RG_HIP(c, rg_launch_mp3_frames(d_tr, (uint32_t)n, tb, d_chunk, c->d_mp3_tiles_set[set].p, d_recs, c->d_mp3_results.p, s));
+            RG_HIP(c, rg_launch_mp3_sort(d_tr, (uint32_t)n, d_recs, ub, c->d_mp3_sortw_set[set].p, c->d_mp3_perm_set[set].p, s));
             RG_HIP(c, hipEventRecord(ev[1], s));
         }
         RG_HIP(c, rg_launch_mp3_huffman(d_tab, d_huff, d_tr, (uint32_t)n, d_recs, d_chunk, reinterpret_cast<rg_mp3_unit *>(c->d_mp3_units.p),
-                                        c->d_mp3_is.p, ub, s));
+                                        c->d_mp3_is.p, ub, c->d_mp3_perm_set[set].p, c->d_mp3_sortw_set[set].p, s));
         if (ev) RG_HIP(c, hipEventRecord(ev[2], s));
         RG_HIP(c, rg_launch_mp3_backhalf(d_tab, d_tr, (uint32_t)n, hb, reinterpret_cast<const rg_mp3_unit *>(c->d_mp3_units.p), c->d_mp3_is.p,
-                                         RG_MP3_IS_GROUP_LOG2, s));
+                                         1u, s));
         if (ev) RG_HIP(c, hipEventRecord(ev[3], s));
     }
     RG_HIP(c, hipEventRecord(c->mp3_set_free[set], s));

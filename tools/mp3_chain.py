@@ -18,12 +18,17 @@ import torch  # noqa: E402,F401
 import mp3rgain_amd as rg  # noqa: E402
 from mp3rgain_amd import mp3dec  # noqa: E402
 
+import os  # noqa: E402
+
 target = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 18
+only = os.environ.get("MP3_CHAIN_ONLY", "")  # substring of a stream's label: that stream alone
 an = rg.Analyzer(0)
 out = {}
 for label, src in (("dense320_synthetic", ROOT / "tests/golden/mp3/v1_44k_stereo_long.mp3"),
                    ("dense128_joint_music", ROOT / "tests/golden/mp3/dense_44k_joint_128.mp3"),
                    ("vbr_fixture_sine", ROOT / "tests/golden/fixtures/test_vbr.mp3")):
+    if only and only not in label:
+        continue
     data = src.read_bytes()
     info = mp3dec.scan(data)
     body = data[int(info.first_frame_offset):]
