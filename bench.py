@@ -52,7 +52,7 @@ ALGO_BYTES_PER_FRAME = 8           # 2 channels x f32, read once (SURVEY.md sect
 ALGO_FLOP_PER_FRAME = 108          # 2 x (21 + 5 + 1) FMA
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6            # MI355X FP64 vector: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 class _DevArray:
@@ -85,11 +85,16 @@ def workload_tag(ntr: int, frames: int, album: bool) -> str:
 
 
 def pmc_for(tag: str, frames_per_launch: int):
-    try:
-        pm = json.loads((ROOT / "profiles" / f"{PROFILE_ROUND}_pmc_{tag}.json").read_text())
-    except (OSError, ValueError):
-        return None
-    return pm if pm.get("frames_per_launch") == frames_per_launch else None
+    """The newest committed PMC pass of this workload (this round's if the kernel changed this round, else the last one taken)."""
+    for rnd in (PROFILE_ROUND, "r04"):
+        try:
+            pm = json.loads((ROOT / "profiles" / f"{rnd}_pmc_{tag}.json").read_text())
+        except (OSError, ValueError):
+            continue
+        if pm.get("frames_per_launch") == frames_per_launch:
+            pm["_source"] = f"profiles/{rnd}_pmc_{tag}.json"
+            return pm
+    return None
 
 
 def roofline_block(frames_per_launch: int, k_ms_sum: float, k_launches: int, k_span_ms: float, tag: str,
@@ -114,11 +119,11 @@ def roofline_block(frames_per_launch: int, k_ms_sum: float, k_launches: int, k_s
     pm = pmc_for(tag, frames_per_launch)
     traffic = pm["hbm_bytes_per_launch"] if pm else None
     fp64 = {"achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
-            "algorithmic_flop_per_launch": algo_flop, "executed": None}
+            "algorithmic_flop_per_launch": algo_flop, "from_profiles": None}
     if pm and pm.get("valu_insts_per_launch"):
         # executed: PMC wave-instruction counts (mean per launch) x launches per step x 64 lanes; FMA = 2 flop
         chs = channel_samples or 2 * frames_per_launch
-        ex = {"source": f"profiles/{PROFILE_ROUND}_pmc_{tag}.json",
+        ex = {"source": pm["_source"],
               "valu_wave_insts_per_launch": pm["valu_insts_per_launch"]}
         fma = pm.get("fma_f64_insts_per_launch")
         if fma:
@@ -132,7 +137,7 @@ def roofline_block(frames_per_launch: int, k_ms_sum: float, k_launches: int, k_s
         else:  # no FP64-specific counter: every VALU instruction priced as an FMA (upper bound on the flops)
             ex["tflops_upper_bound"] = 2.0 * 64.0 * pm["valu_insts_per_launch"] * k_launches / span_s / 1e12 if span_s > 0 else 0.0
         ex["valu_per_channel_sample"] = pm["valu_insts_per_launch"] * launches_per_step * 64.0 / chs
-        fp64["executed"] = ex
+        fp64["from_profiles"] = ex  # NOT measured in this run: counters of a committed PMC pass of the same workload (ex["source"])
     return {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
             "traffic": traffic,
             "binding_bound": "fp64 (vector FMA): 13.5 algorithmic flop/B is above the 9.8 flop/B ridge, see roofline.fp64",
@@ -187,11 +192,45 @@ def mp3_end_to_end(an, nfiles: int) -> dict:
         tmp.rmdir()
     loud = {r["album_loudness_db"] for r in leg["routes"].values()}
     leg["routes_agree"] = len(loud) == 1
+    # ---- how many of these decoded tracks does the fast kernel flag (RG_TRACK_FLAG_IMPRECISE), and what does the exact
+    # repeat of the synchronous entry points cost then?  The file-level calls above return the repeated (exact) results, whose
+    # flag is gone; here the decoded PCM of one file, 16 copies, goes through the asynchronous pair (hands the flag over)
+    # and through the synchronous call.
+    try:
+        import numpy as np
+        import torch
+
+        from mp3rgain_amd.replaygain import PcmTrack, pack_tracks
+
+        pcm1, di = an.decode_mp3_device(stream)
+        trk = [PcmTrack([np.ascontiguousarray(pcm1[c]) for c in range(pcm1.shape[0])], int(di.sample_rate))] * 16
+        arena, descs_f = pack_tracks(trk)
+        dev = torch.from_numpy(arena).cuda()
+        for _ in range(2):
+            an.enqueue_device(descs_f, 16, dev.data_ptr(), arena.nbytes)
+            rf = an.collect(16)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        an.enqueue_device(descs_f, 16, dev.data_ptr(), arena.nbytes)
+        rf = an.collect(16)
+        t_async = time.perf_counter() - t0
+        an.analyze_device(descs_f, 16, dev.data_ptr(), arena.nbytes)
+        t0 = time.perf_counter()
+        an.analyze_device(descs_f, 16, dev.data_ptr(), arena.nbytes)
+        t_sync = time.perf_counter() - t0
+        leg["tracks_flagged_imprecise"] = {"tracks": 16, "flagged": sum(1 for r in rf if r.flags & 2),
+                                           "async_pair_ms": t_async * 1e3, "synchronous_call_ms": t_sync * 1e3,
+                                           "note": "decoded PCM of one of the files, 16 copies resident in HBM; the synchronous call repeats a batch "
+                                                   "that has a flagged track with it on the order-faithful kernel; profiles/r05_flag_rate.txt has "
+                                                   "every golden stream"}
+        del dev
+    except Exception as ex:  # noqa: BLE001
+        leg["tracks_flagged_imprecise"] = {"error": str(ex)}
     # ---- the decode chain alone, measured like the headline kernel: HIP events on the stream the kernels run on
     # (rg_mp3_decode_bench), algorithmic bytes = compressed bytes in + 4 bytes per decoded sample out ----
     try:
         units_per = si.audio_frames * (2 if si.mpeg_version == 1 else 1) * si.channels
-        copies = max(1, round(393216 / units_per))
+        copies = max(1, round(786432 / units_per))
         ch = an.decode_mp3_bench(stream, copies, reps=30)
         algo = ch["compressed_bytes"] + 4 * ch["frames"] * si.channels
         chain_s = ch["ms"]["chain"] * 1e-3
@@ -261,14 +300,14 @@ def exchange_block(an, transport: str) -> dict:
 
 
 def node_main(args) -> int:
-    import numpy as np
-
     """`--node` / `--gpus N` without torch.distributed.run: the album workload of configs[3] in ONE process.  A node
     (mp3rgain_amd.Node: one context per GPU) with the library's in-process RCCL communicators (ncclCommInitAll), one host
     thread per GPU: every thread fills its device's arena with its share of the album (tracks i, i + N, ...), and a step is
     enqueue -> all-gather of the 48 KB album packs + fold on the batch's stream -> album percentile, exactly the calls a
     torchrun rank makes.  Threads meet at a barrier before and after the timed steps; the time is the slowest thread's."""
     import threading
+
+    import numpy as np
 
     import torch
 
@@ -375,7 +414,9 @@ def node_main(args) -> int:
                   "max_abs_db_delta": max_db, "peaks_equal": peaks_equal,
                   "every_device_agrees_on_the_album": len({(o["album"].album_loudness_db, o["album"].album_peak) for o in out}) == 1,
                   "tracks_flagged_imprecise": sum(o["flagged"] for o in out)}
-        cpu = cpu_baseline_leg(po, l, r, RATE, frames, "one track of the album", args.cpu_seconds)
+        seed0 = out[0]["seeds"][0]  # the CPU baseline's sample: the album's first track, regenerated here
+        cpu = cpu_baseline_leg(po, po.synth_f32(seed0, 0, RATE, frames), po.synth_f32(seed0, 1, RATE, frames), RATE, frames,
+                               "the first track of the album", args.cpu_seconds)
     line = {
         "metric": "stereo PCM samples/s through IIR+RMS+histogram", "value": total_frames / dt, "unit": "stereo samples/s",
         "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -653,6 +694,11 @@ def main() -> int:
     roof = roofline_block(batch_frames, k1_ms_sum, k1_launches, k1_span_ms, tag, algo_bytes=batch_algo_bytes,
                           algo_flop=batch_algo_flop, launches_per_step=groups,
                           channel_samples=sum(sp[2] * sp[3] for sp in specs))
+    if one_shot:
+        # `kernel_ms` above is the OVERLAPPED duration of a launch (kernel_concurrency launches are resident at once on the
+        # pipeline streams, so it exceeds ms_per_step); this is the same kernel with nothing beside it (one_shot below)
+        roof["kernel_ms_alone"] = one_shot["kernel_ms_alone"]
+        roof["frac_one_launch_alone"] = one_shot["hbm_frac_one_launch_alone"]
 
     # ---- secondary workload on one GPU: configs[1], one 10-minute track (fits the Infinity Cache) ----------
     configs1 = None

@@ -653,7 +653,11 @@ Mp3Pipe &mp3_pipe(rg_ctx *c) {
     return *static_cast<Mp3Pipe *>(c->mp3_pipe);
 }
 
-constexpr uint64_t kPipeChunkUnits = 393216;          // granule-channels per chunk = the threads the Huffman kernel can have resident (256 CUs x 4 SIMDs x 6 waves x 64): one full wave of them
+// Granule-channels per chunk.  The Huffman kernel deals a chunk's units to its lanes heaviest first (rg_mp3_sort_*): a chunk
+// has to be several generations of its blocks (256 CUs x 2 blocks x 512 threads = 262144 resident) for the light tail to fill
+// in behind the heavy head, and the six small launches in front of it (frame parser, sort) are paid per chunk: per 256 K units
+// the chain takes 0.68 / 0.63 / 0.56 / 0.56 ms in chunks of 256 K / 384 K / 768 K / 1 M on the dense 320 kb/s stream.
+constexpr uint64_t kPipeChunkUnits = 786432;
 constexpr size_t kPipeStageBytes = (size_t)128 << 20;  // staging block (a 3-minute 320 kb/s file is 7.2 MB and 27 600 granule-channels)
 
 struct PipeChunk {

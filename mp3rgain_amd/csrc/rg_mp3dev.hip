@@ -221,14 +221,22 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
             rq_off[r] = PLANES ? 4u * piece : 8u * piece;
         }
         const uint8_t *const is_block = reinterpret_cast<const uint8_t *>(is) + ubase * (uint64_t)RG_MP3_ROW_BYTES;  // 32-bit offsets from here (a run is 68 units)
-        // Every load is issued whatever the step (the compiler can count them), but not every load has to move bytes: lines
-        // from the unit's nz on were never written and are replaced by zeros below, and the second plane exists for the first
-        // hi_q words only -- such lanes ask for their round-0 word again, which is on its way anyway.  `hd`: the unit headers of
-        // the step asked for (its nz and hi_q are the wave's).
+        // Every load is issued whatever the step (the compiler can count them: a load under a condition makes the next wait
+        // a wait for everything in flight, and this very prefetch with it -- tried: 0.36 -> 0.45 ms), but not every load has to
+        // move bytes: lines from the unit's nz on were never written and are replaced by zeros below -- such lanes ask for the
+        // last word that holds lines once more -- and the second plane is asked for in the first round only (a memory
+        // instruction costs this wave, the pipeline's longest stage, about a hundred cycles to issue whatever it moves), by the
+        // lanes below hi_q, the others asking for a word next to their first-plane word; a second plane longer than 64 words (large
+        // values above line 256: rare) is read at the top of the step that needs it.  `hd`: the unit headers of the step asked
+        // for (its nz and hi_q are the wave's).
         auto fetch_spectra = [&](const int step, const uint32_t (&hd)[2][4]) {
 #pragma unroll
             for (int c = 0; c < nch; ++c) {
+#ifdef RG_BH_SAMEROW  // experiment (wrong results): every step reads the run's first rows again -- what memory latency costs the step
+                const uint8_t *const row = is_block + (uint32_t)c * (uint32_t)RG_MP3_ROW_BYTES + 0u * (uint32_t)step;
+#else
                 const uint8_t *const row = is_block + ((uint32_t)step * nch + c) * (uint32_t)RG_MP3_ROW_BYTES;
+#endif
                 const uint32_t nz = hd[c][0] & 0xFFFFu;
                 if (PLANES) {
                     const uint32_t last = nz ? ((nz + 3u) & ~3u) - 4u : 0u;  // byte offset of the last word with lines in it
@@ -236,9 +244,10 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
 #pragma unroll
                     for (int r = 0; r < kRounds; ++r) {
                         const uint32_t lo_at = rq_off[r] < last ? rq_off[r] : last;
-                        const uint32_t hi_at = (uint32_t)(lane + 64 * r) < hi_q ? (uint32_t)(RG_MP3_ROW_BYTES / 2) + rq_off[r] : lo_at;
                         rq_next[r][c].x = *reinterpret_cast<const uint32_t *>(row + lo_at);
-                        rq_next[r][c].y = *reinterpret_cast<const uint32_t *>(row + hi_at);
+                        // (the neighbour of the first-plane word, not the word itself: the compiler would reuse the first load's
+                        // result for those lanes, i.e. wait for it right here)
+                        if (r == 0) rq_next[r][c].y = *reinterpret_cast<const uint32_t *>(row + ((uint32_t)lane < hi_q ? (uint32_t)(RG_MP3_ROW_BYTES / 2) + rq_off[r] : (lo_at ^ 4u)));
                     }
                 } else {
                     const uint32_t last = nz ? 2u * (((nz + 3u) & ~3u) - 4u) : 0u;
@@ -304,6 +313,18 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                     for (int c = 0; c < nch; ++c) {
                         const uint32_t hq = (h[c][3] >> 16) & 0xFFu;
                         hi_q_max = hq > hi_q_max ? hq : hi_q_max;
+                    }
+                    if (hi_q_max > 64u) {  // rare: the second plane's words of rounds 1 and 2, read here and now (nothing is in flight)
+#pragma unroll
+                        for (int c = 0; c < nch; ++c) {
+                            const uint8_t *const row = is_block + ((uint32_t)k * nch + c) * (uint32_t)RG_MP3_ROW_BYTES + (uint32_t)(RG_MP3_ROW_BYTES / 2);
+#pragma unroll
+                            for (int r = 1; r < kRounds; ++r) raw[r][c].y = *reinterpret_cast<const uint32_t *>(row + rq_off[r]);
+                        }
+#pragma unroll
+                        for (int c = 0; c < nch; ++c)
+#pragma unroll
+                            for (int r = 1; r < kRounds; ++r) asm volatile("" ::"v"(raw[r][c].y));  // consumed on this path (see below)
                     }
                 }
                 bool bytes_r[kRounds];  // the wave's
@@ -389,7 +410,9 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                 for (int c = 0; c < 2; ++c) {  // the scalefactor each lane's gain needs: one byte read per channel, asked for together
                     if (c >= nch) continue;
                     const int long_end = (int)((h[c][2] >> 16) & 0xFFu), short_start = (int)(h[c][2] >> 24);
-                    const int rel = gq_kk - 3 * short_start;
+                    // (no multiplication: for gq_kk - 3 short_start the compiler takes v_mad_u64_u32, whose 64-bit addend's unused upper half
+                    // landed in a register of the prefetch just issued -- and the wave waited for memory right here, every step)
+                    const int rel = gq_kk - (short_start == 0 ? 0 : (short_start == 3 ? 9 : 39));  // 3 short_start: it is 0, 3 or 13
                     const bool short_sf = lane >= 22 && gq_band < 12 && rel >= 0;
                     gq_idx[c] = lane < 22 ? lane : (short_sf ? long_end + rel : -1);
                     gq_sf[c] = UP[c].sf[gq_idx[c] < 0 ? 0 : gq_idx[c]];
@@ -415,8 +438,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
                     if (c < nch) gtab[c][lane] = lane < 61 ? gq_g[c] : 0.0f;
-                const int nz0 = (int)(h[0][0] & 0xFFFFu), nz1 = (int)(h[1][0] & 0xFFFFu);
-                const int ms_n = (nch == 2 && (h[0][3] & 3u) == 2u) ? (nz0 > nz1 ? nz0 : nz1) : 0;
+                const bool ms_all = nch == 2 && (h[0][3] & 3u) == 2u;  // plain mid/side (no intensity stereo in the frame)
                 wave_sync();
                 RG_BH_STAMP2(k, 0);
                 // This wave is the pipeline's longest stage and it runs alone on its data, so its length is the sum of its
@@ -492,25 +514,15 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                             val[c][j] = __builtin_copysignf(t, __uint_as_float(sign_at_31));
                         }
                     }
-                    // ---- stage C, the plain case: mid/side on the lines below the longer channel's end; the end is the same
-                    // for all lanes, so at most one round has lanes on both sides of it
-                    if (ms_n > 256 * r) {
+                    // ---- stage C, the plain case: mid/side.  On every line: the host stops at the longer channel's end, and
+                    // behind it both values are +0, whose sum and difference times a constant are +0 again
+                    if (ms_all) {
                         const float isq2 = 0.70710678118654752440f;
-                        if (ms_n >= 256 * r + 256) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float a = val[0][j], b = val[1][j];
-                                val[0][j] = (a + b) * isq2;
-                                val[1][j] = (a - b) * isq2;
-                            }
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (4 * piece + j < ms_n) {
-                                    const float a = val[0][j], b = val[1][j];
-                                    val[0][j] = (a + b) * isq2;
-                                    val[1][j] = (a - b) * isq2;
-                                }
+                        for (int j = 0; j < 4; ++j) {
+                            const float a = val[0][j], b = val[1][j];
+                            val[0][j] = (a + b) * isq2;
+                            val[1][j] = (a - b) * isq2;
                         }
                     }
                     if (piece < 144) {
