@@ -456,7 +456,6 @@ def main() -> int:
     ap.add_argument("--tm-segment", type=int, default=0, help="force variant 2 segment length (tuning)")
     ap.add_argument("--tm-windows", type=int, default=0, help="most windows per lane of variant 2 (tuning; 0 = library default, 1 = one)")
     ap.add_argument("--slots", type=int, default=0, help="pipeline slots of the library (0 = default)")
-    ap.add_argument("--tm-split", type=int, default=-1, help="tuning key 9: 1 = windows 2..m of multi-window segments in a kernel of their own")
     ap.add_argument("--mixed", action="store_true",
                     help="BASELINE configs[4]'s PCM side instead: half the tracks at 44.1 kHz, half at 48 kHz, every 10th mono, "
                          "every 20th with full-scale (clipped) peaks")
@@ -528,8 +527,6 @@ def main() -> int:
         an.set_tuning(3, args.slots)
     if args.tm_windows:
         an.set_tuning(4, args.tm_windows)
-    if args.tm_split >= 0:
-        an.set_tuning(9, args.tm_split)
     # No caller stream is attached: every batch, its album tail and the collective in between run on the
     # context's own pipeline streams (rg_batch_stream), which costs no cross-stream event per step.
 
@@ -715,6 +712,9 @@ def main() -> int:
                     "value": FRAMES_10MIN * args.configs1_steps / d1, "unit": "stereo samples/s",
                     "steps": args.configs1_steps, "ms_per_step": d1 / args.configs1_steps * 1e3,
                     "roofline": roofline_block(FRAMES_10MIN, s1, l1, sp1, "cfg1"),
+                    "bound": "block-retire arithmetic (DESIGN.md section 7): 24 000 windows are too few lanes for multi-window segments, so "
+                             "L = 735 (35.1 vector instructions per channel-sample against 28.3); 282 blocks of 256 lanes, three per CU, "
+                             "181 us each at three waves per SIMD and 88 % issue -> 256 CUs retire one launch per 66.5 us = 0.398 of HBM",
                     "result": {"loudness_db": r1[0].loudness_db, "gain_db": r1[0].gain_db, "peak": r1[0].peak,
                                "flags": r1[0].flags}}
         del pcm1

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION 4
+#define RG_ABI_VERSION 5
 #define RG_HISTOGRAM_SIZE 12000         /* HISTOGRAM_SIZE        src/replaygain.rs:630 */
 #define RG_HISTOGRAM_OFFSET 2000        /* HISTOGRAM_OFFSET      src/replaygain.rs:635 */
 #define RG_REPLAYGAIN_REFERENCE_DB 89.0 /* REPLAYGAIN_REFERENCE_DB src/replaygain.rs:37 */
@@ -46,7 +46,9 @@ typedef enum rg_status {
     RG_ERR_STATE = -6,            /* e.g. collect with nothing enqueued */
     RG_ERR_COLLECTIVE = -7,       /* RCCL symbol lookup or call failed */
     RG_ERR_IO = -8,               /* "Failed to open: {path}" src/replaygain.rs:804-805 */
-    RG_ERR_FORMAT = -9            /* "Failed to probe format: {path}" src/replaygain.rs:815-822 */
+    RG_ERR_FORMAT = -9,           /* "Failed to probe format: {path}" src/replaygain.rs:815-822 */
+    RG_ERR_REFUSED = -10          /* rg_comm_library / rg_node_create_backend: a test seam (a collective library not called
+                                     librccl.so[.N], foreign engines) without MP3RGAIN_AMD_TEST_SEAMS=1 in the environment */
 } rg_status;
 
 /* planar sample formats, the three AudioBufferRef arms of src/replaygain.rs:959-1024 */
@@ -186,9 +188,8 @@ int rg_set_kernel(rg_ctx *ctx, int variant);
  * the host's cores, the rest on the GPU; 0 = the host decoder.  (An album of 64 three-minute 320 kb/s files:
  * 0.96 s / 0.25 s / 0.04 s / 0.017 s for 0 / 1 / 2 / 3.),
  * key 7 = host threads the file-level entry points load files with (0 = every core this process may use; a node of
- * several contexts gives each its share, mp3rgain_amd_node.h),
- * key 9 = 1: windows 2..m of variant 2's multi-window segments run in a kernel of their own at four waves per SIMD instead of
- * three (same results; measured +0.3 % on configs[2]: the path is power-bound; default 0). */
+ * several contexts gives each its share, mp3rgain_amd_node.h).
+ * (Key 9 of ABI 4 -- windows 2..m in a kernel of their own -- is gone with that kernel: it spilled and was never faster.) */
 int rg_set_tuning(rg_ctx *ctx, int key, int64_t value);
 /* diagnostic (host only): variant 2's design for one rate and segment length.  T_out: [L][12],
  * gram_last_out: [78]; either may be NULL.  RG_ERR_INVALID_ARG when no design exists. */

@@ -77,7 +77,8 @@ typedef struct rg_mp3_unit {
     uint8_t short_start;     /* first short band (13 = none)                                                            */
     uint8_t mode_ext;        /* joint stereo only: bit 0 intensity, bit 1 mid/side; 0 otherwise                         */
     uint8_t intensity_scale; /* LSF: low bit of the right channel's scalefac_compress                                   */
-    uint8_t reserved[2];
+    uint8_t reserved[2];     /* [0]: units written by the DEVICE Huffman stage only (mp3rgain_amd/csrc/rg_mp3dev.h): 4-line words of
+                              *      the spectrum row's second byte plane worth reading; 0 from rg_mp3_parse_units               */
 } rg_mp3_unit;               /* 64 bytes */
 
 /* is_out: int16 [capacity_units][576]; units_out: [capacity_units].  out->frames / audio_frames / skipped_frames as

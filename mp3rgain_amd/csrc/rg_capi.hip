@@ -325,7 +325,6 @@ extern "C" int rg_set_tuning(rg_ctx *c, int key, int64_t value) {
         case RG_TUNE_TM_WINDOWS: c->tune_tm_windows = (uint32_t)(value > 255 ? 255 : value); return RG_OK;
         case RG_TUNE_INGEST_CHUNK_KIB: c->tune_ingest_chunk_kib = (uint64_t)value; return RG_OK;
         case RG_TUNE_GPU_MP3_DECODE: c->gpu_mp3_decode = value > 3 ? 3 : (int)value; return RG_OK;
-        case RG_TUNE_TM_SPLIT: c->tm_split = value ? 1 : 0; return RG_OK;
         case RG_TUNE_LOADER_THREADS: c->loader_threads = (unsigned)(value > 1024 ? 1024 : value); return RG_OK;
         case RG_TUNE_PIPELINE_SLOTS: {
             if (sync_all(c) != RG_OK) return RG_ERR_DEVICE;
@@ -536,7 +535,7 @@ extern "C" int rg_comm_library(const char *path) {
         base = base ? base + 1 : path;
         const bool rccl = strncmp(base, "librccl.so", 10) == 0 && (base[10] == 0 || base[10] == '.');
         const char *seams = getenv("MP3RGAIN_AMD_TEST_SEAMS");
-        if (!rccl && !(seams && seams[0] == '1')) return RG_ERR_INVALID_ARG;
+        if (!rccl && !(seams && seams[0] == '1')) return RG_ERR_REFUSED;  // rg_status: not a librccl.so[.N]
     }
     void *h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
     if (!h) return RG_ERR_COLLECTIVE;
@@ -865,6 +864,9 @@ extern "C" int rg_collect_exact(rg_ctx *c, const rg_track_desc *tracks, size_t n
                                 rg_track_result *out, uint32_t *hist_out) {
     if (!c || (n && (!tracks || !d_pcm_base || !out))) return RG_ERR_INVALID_ARG;
     if (c->slot().n_enqueued != n) return rg_set_err(c, RG_ERR_STATE, "rg_collect_exact: the last enqueue held %zu tracks, not %zu", c->slot().n_enqueued, n);
+    if (c->slot().enq_album) return rg_set_err(c, RG_ERR_STATE, "rg_collect_exact: the last enqueue was an album enqueue (track mode only)");
+    if (c->slot().enq_base != d_pcm_base || c->slot().enq_bytes != pcm_bytes)
+        return rg_set_err(c, RG_ERR_STATE, "rg_collect_exact: not the PCM arena of the last enqueue");
     int rc = rg_collect(c, out, hist_out);
     if (rc != RG_OK || !needs_exact_pass(c, out, n)) return rc;
     ExactPass exact(c);

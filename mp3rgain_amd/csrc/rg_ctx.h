@@ -63,7 +63,7 @@ struct RgTmDeviceTables {
 };
 
 enum { RG_TUNE_TM_SEGMENT = 1, RG_TUNE_TM_TARGET_LANES = 2, RG_TUNE_PIPELINE_SLOTS = 3, RG_TUNE_TM_WINDOWS = 4, RG_TUNE_INGEST_CHUNK_KIB = 5,
-       RG_TUNE_GPU_MP3_DECODE = 6, RG_TUNE_LOADER_THREADS = 7, RG_TUNE_TM_SPLIT = 9 };
+       RG_TUNE_GPU_MP3_DECODE = 6, RG_TUNE_LOADER_THREADS = 7 };
 
 #define RG_MAX_SLOTS 8
 #define RG_SLOT_STREAMS 4   // HIP streams the slots are spread over (the runtime has 4 hardware queues by default)
@@ -101,6 +101,9 @@ struct RgSlot {
     DevBuf<uint32_t> d_gather;               // rg_album_exchange: every rank's [histogram | peak] pack
     PinnedBuf<rg_album_result> h_album_result;
     size_t n_enqueued = 0;
+    int enq_album = 0;                        // what the slot's last enqueue was given (rg_collect_exact repeats it)
+    const void *enq_base = nullptr;
+    size_t enq_bytes = 0;
     bool album_ready = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // timing of the dominant kernel
     size_t ev_used = 0;
@@ -114,7 +117,6 @@ struct rg_ctx {
     uint32_t tune_tm_windows = 0;          // windows per segment: 0 = choose from the workload, 1 = never more than one
     uint64_t tune_tm_target_lanes = 0;     // 0 = cost model
     int n_slots = RG_DEFAULT_SLOTS;
-    int tm_split = 0;                      // tuning key 9: windows 2..m of multi-window segments run in rg_tm_plain_kernel (four waves per SIMD)
 
     RgSlot slots[RG_MAX_SLOTS];
     int cur = 0;                        // slot of the most recent enqueue

@@ -25,7 +25,7 @@ hipError_t rg_launch_track_results(const uint32_t *, const unsigned long long *,
 hipError_t rg_launch_album_merge(const uint32_t *, const unsigned long long *, uint32_t, uint32_t *, double *,
                                  hipStream_t);
 hipError_t rg_launch_tm_main(int fmt, int nch, const RgTmCoef *, const RgTmGeom *, const RgTmTrack *, uint32_t, uint32_t,
-                             double *, uint32_t, double *, uint32_t, uint32_t *, uint32_t *, uint64_t, int, hipStream_t);
+                             double *, uint32_t, double *, uint32_t, uint32_t *, uint32_t *, uint64_t, hipStream_t);
 hipError_t rg_launch_tm_fix(int nch, const RgTmGeom *, const RgTmFixTables *, const RgTmTrack *, uint32_t, uint32_t,
                             const double *, uint32_t, const double *, uint32_t, uint32_t *, uint32_t *, uint32_t *,
                             unsigned long long *, uint32_t *, rg_track_result *, hipStream_t);
@@ -354,6 +354,17 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
     if (n > 0x7FFFFFFFull) return rg_set_err(c, RG_ERR_INVALID_ARG, "too many tracks");
     int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
+    // A design is cached per (rate, windows per lane, segment length) -- up to 4 MB of device memory each -- and a long-lived
+    // context that sees many batch shapes would keep them all: past kTmTablesMax the cache is emptied at this one safe point
+    // (no launch group of this enqueue holds a table yet; the streams are drained because earlier batches may still read
+    // theirs) and what is needed is designed again.
+    constexpr size_t kTmTablesMax = 48;
+    if (c->tm_tables.size() > kTmTablesMax) {
+        for (int k = 0; k < RG_MAX_SLOTS; ++k)
+            if (c->slots[k].stream) RG_HIP(c, hipStreamSynchronize(c->slots[k].stream));
+        rg_tm_tables_release(c);
+        c->tm_choice.clear();
+    }
     rc = validate(c, tracks, n, pcm_bytes);
     if (rc != RG_OK) return rc;
     // next pipeline slot: its stream orders this batch behind the batch that used the slot before
@@ -512,6 +523,9 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
     if (max_win_doubles) RG_HIP(c, S.d_tm_win.reserve(max_win_doubles));
 
     S.n_enqueued = n;
+    S.enq_album = album;
+    S.enq_base = d_pcm_base;
+    S.enq_bytes = pcm_bytes;
     S.album_ready = false;
     const RgTrackDev *d_tracks = nullptr, *d_k1_tracks = nullptr;
     const RgTmTrack *d_tm_tracks = nullptr;
@@ -554,7 +568,7 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
             if (rc != RG_OK) return rc;
             RG_HIP(c, rg_launch_tm_main(gl.fmt, gl.nch, &gl.K, &gl.tb->geom, d_tm_tracks + gl.list_off,
                                         (uint32_t)gl.list_n, gl.main_grid, S.d_tm_rec.p, gl.total_recs, S.d_tm_win.p,
-                                        gl.total_windows, S.d_nonfinite.p, cleared ? nullptr : S.d_hist.p, (uint64_t)acc_words, c->tm_split, s));
+                                        gl.total_windows, S.d_nonfinite.p, cleared ? nullptr : S.d_hist.p, (uint64_t)acc_words, s));
             if (gl.main_grid != 0) cleared = true;
             if (e1) RG_HIP(c, hipEventRecord(e1, s));
             RG_HIP(c, rg_launch_tm_fix(gl.nch, &gl.tb->geom, &gl.tb->fix, d_tm_tracks + gl.list_off,

@@ -192,6 +192,13 @@ __device__ __forceinline__ void tm_frame(TmLane<1> &st, const uint32_t wbits, ty
     double (&t)[2] = st.t[0];
     // frames past the end were staged as zeros; the peak is tracked here or, for whole pieces, by the caller (peak4)
     const double x = PEAK ? Fmt<FMT>::cvt_word(wbits, pk) : Fmt<FMT>::word_value(wbits);
+#ifdef RG_TM_LOADER_ONLY
+    // Measurement build (tools/build_variant.sh loader -DRG_TM_LOADER_ONLY; never shipped, wrong results): the kernel's own
+    // loads, LDS staging and reads with ONE operation per sample instead of the cascade -- the memory-side floor of this access
+    // pattern, its FETCH_SIZE against the known byte count, its power without the FP64 pipe.
+    st.A[0] += x;
+    return;
+#endif
     if constexpr (SERVO) {
         // 26 operations: the Butterworth stage is the Yule output (butter b0 folded into K.b) minus a double integrator,
         // t = (v1, v2).  Three groups of independent instructions:
@@ -471,7 +478,6 @@ __global__ void __launch_bounds__(MULTI ? RG_TM_BLOCK_WIDE_MULTI : RG_TM_BLOCK_W
 rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restrict__ tracks, uint32_t n_tracks,
                   double *__restrict__ rec, uint32_t total_recs, double *__restrict__ win_energy /* [channels][total_windows], m > 1 */,
                   uint32_t total_windows, uint32_t *__restrict__ nonfinite, uint32_t lds_tables,
-                  uint32_t windows_here /* m > 1: windows of its segment a lane runs in THIS kernel: m, or 1 when rg_tm_plain_kernel runs the rest */,
                   uint32_t *__restrict__ zero_words, uint64_t zero_count /* batch accumulators to clear, or nullptr */,
                   unsigned long long *__restrict__ dbg /* nullptr, or 6 words per wave: start, end, hw id, path, cycle counter start, end */) {
     typedef Fmt<FMT> F;
@@ -587,7 +593,7 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
                     for (int j = 0; j < RG_TM_DIM; ++j) r[(size_t)(1 + j) * total_recs] = st.B[0][j];
                 }
 #pragma unroll 1
-                for (uint32_t w = 1; w < windows_here; ++w) {
+                for (uint32_t w = 1; w < m; ++w) {
                     const uint64_t wstart = start + (uint64_t)w * L;
                     uint32_t lenw = 0;
                     if (active && wstart < tr.frames) {
@@ -671,88 +677,6 @@ rg_tm_main_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restric
         r[(size_t)23 * total_recs] = st.t[0][0];
         r[(size_t)24 * total_recs] = st.t[0][1];
         r[(size_t)25 * total_recs] = F::peak_norm(pk);  // max |x| of this segment, normalised (replaygain.rs:967)
-    }
-}
-
-// =================================================================================================
-// Windows 2..m of multi-window segments as a kernel of their own (tuning key 9).  The loop without the transient moments
-// needs no response tables and fewer registers than the first window's: 128 VGPRs = four waves per SIMD where the main
-// kernel has three, 256-thread blocks with nothing in LDS but the waves' PCM tiles.  A lane picks its cascade up where
-// rg_tm_main_kernel (windows_here = 1) left it -- the twelve state words and the peak it stored in the segment's record --
-// runs the remaining windows exactly as the main kernel's own loop would (same tm_fast_path instantiations, same order),
-// and puts the final state back.
-template <int FMT, bool SERVO>
-__global__ void __launch_bounds__(RG_TM_BLOCK) __attribute__((amdgpu_waves_per_eu(4)))
-rg_tm_plain_kernel(const RgTmCoef K, const RgTmGeom G, const RgTmTrack *__restrict__ tracks, uint32_t n_tracks,
-                   double *__restrict__ rec, uint32_t total_recs, double *__restrict__ win_energy, uint32_t total_windows,
-                   uint32_t *__restrict__ nonfinite) {
-    typedef Fmt<FMT> F;
-    typedef typename F::elem elem;
-    typedef __attribute__((address_space(1))) const elem gelem;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t gl = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t t = find_track(tracks, n_tracks, gl, &RgTmTrack::lane_base);
-    struct { const void *ch0, *ch1; uint64_t frames; uint32_t nseg; } tr;
-    {
-        const RgTmTrack &q = tracks[t];
-        tr.ch0 = q.ch0; tr.ch1 = q.ch1; tr.frames = q.frames; tr.nseg = q.nseg;
-    }
-    const uint32_t rel = gl - tracks[t].lane_base;
-    const int chan = (tr.ch1 != nullptr && rel >= tr.nseg) ? 1 : 0;
-    const uint32_t seg = rel - (chan ? tr.nseg : 0u);
-    const uint32_t L = G.L, m = G.m;
-    const bool active = seg < tr.nseg;
-    const uint64_t start = (uint64_t)seg * L * m;
-    gelem *const chp = (gelem *)(chan == 0 ? tr.ch0 : tr.ch1);
-    auto rec_ptr = [&]() -> double * { return rec + (size_t)chan * RG_TM_REC * total_recs + ((size_t)tracks[t].rec_base + (active ? seg : 0)); };
-    TmLane<1> st;
-    typename F::peak_t pk = 0;
-#pragma unroll
-    for (int j = 0; j < RG_TM_DIM; ++j) st.B[0][j] = 0.0;
-    st.A[0] = 0.0;
-    {
-        const double *__restrict__ const r = rec_ptr();
-#pragma unroll
-        for (int j = 0; j < 10; ++j) st.s[0][j] = active ? r[(size_t)(13 + j) * total_recs] : 0.0;
-        st.t[0][0] = active ? r[(size_t)23 * total_recs] : 0.0;
-        st.t[0][1] = active ? r[(size_t)24 * total_recs] : 0.0;
-        if (active) pk = F::peak_denorm(r[(size_t)25 * total_recs]);
-    }
-    char *const wtile = smem + (threadIdx.x >> 6) * (RG_TM_WAVE_TILE_BYTES * 2);
-    auto note_nonfinite = [&](const double energy, const uint32_t unit, const bool counts) {
-        const bool bad = counts && !(fabs(energy) <= 1.7976931348623157e308);
-        if (__any(bad) && bad) atomicMax(&nonfinite[tracks[t].track_index], 0xFFFFFFFFu - unit);
-    };
-#pragma unroll 1
-    for (uint32_t w = 1; w < m; ++w) {
-        const uint64_t wstart = start + (uint64_t)w * L;
-        uint32_t lenw = 0;
-        if (active && wstart < tr.frames) {
-            const uint64_t rem = tr.frames - wstart;
-            lenw = rem < L ? (uint32_t)rem : L;
-        }
-        if (!__any(lenw != 0)) break;  // the track ended in an earlier window for every row of this wave
-        st.A[0] = 0.0;
-        const double v2_start = st.t[0][1];
-        const bool idle = lenw == 0 && tr.frames >= (uint64_t)((L + 3u) & ~3u);  // see rg_tm_main_kernel
-        const bool plainw = idle || (lenw == L && wstart + ((L + 3u) & ~3u) <= tr.frames);
-        gelem *const rowp = idle ? chp : chp + wstart;
-        if (__all(plainw))
-            tm_fast_path<FMT, false, false, SERVO>(st, pk, K, L, G.H10, rowp, lenw, nullptr, nullptr, wtile);
-        else
-            tm_fast_path<FMT, true, false, SERVO>(st, pk, K, L, G.H10, rowp, lenw, nullptr, nullptr, wtile);
-        note_nonfinite(st.A[0], seg * m + w, lenw != 0);
-        double energy = st.A[0];
-        if constexpr (SERVO) energy = fabs(energy) <= 1.7976931348623157e308 ? energy + fma(K.aff_lin, st.t[0][1] - v2_start, K.aff_n * (double)lenw) : energy;
-        if (lenw != 0) win_energy[(size_t)chan * total_windows + tracks[t].win_base + (size_t)seg * m + w] = energy;
-    }
-    if (active) {
-        double *__restrict__ const r = rec_ptr();
-#pragma unroll
-        for (int j = 0; j < 10; ++j) r[(size_t)(13 + j) * total_recs] = st.s[0][j];
-        r[(size_t)23 * total_recs] = st.t[0][0];
-        r[(size_t)24 * total_recs] = st.t[0][1];
-        r[(size_t)25 * total_recs] = F::peak_norm(pk);
     }
 }
 
@@ -1154,6 +1078,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
                 }
                 if (NCH == 1) { total *= 2.0; e *= 2.0; }
                 if (nf != 0 && widx > 0xFFFFFFFFu - nf) total = __longlong_as_double(0x7FF8000000000000ll);  // == : its own class
+                if (total < 0.0) total = 0.0;  // servo form: the signed affine terms can leave a rounding error below zero (as above)
                 const int wb = rg_window_bin(total, 0.0, n);
                 if (w == 1 && e > 1.0e-13 * total) {
                     const double lo = total - e;
@@ -1207,11 +1132,17 @@ template <int FMT, bool SERVO>
 static hipError_t launch_main_fmt(int nch, const RgTmCoef &K, const RgTmGeom &G, const RgTmTrack *d_tracks,
                                   uint32_t n_tracks, uint32_t grid, double *d_rec, uint32_t total_recs, double *d_win,
                                   uint32_t total_windows, uint32_t *d_nonfinite, uint32_t *d_zero, uint64_t zero_count,
-                                  int split, hipStream_t s) {
+                                  hipStream_t s) {
     // LDS: T12 (H10 x 12 doubles) + T2 ((L - H10) x 2 doubles) + one 4 KiB PCM tile per wave
     size_t lds = rg_tm_lds_bytes(G.L, G.H10, G.block, G.m);
     uint32_t lds_tables = lds <= RG_TM_LDS_BYTES ? 1u : 0u;
     if (!lds_tables) lds = 0;
+#ifdef RG_TM_LDS_PAD_EXPERIMENT  // experiment: blocks of 256 lanes ask for more LDS than they use -> two of them per CU instead of three
+    {
+        static const long pad_kib = getenv("RG_TM_LDS_MIN_KIB") ? atol(getenv("RG_TM_LDS_MIN_KIB")) : 0;
+        if (lds_tables && G.block == RG_TM_BLOCK && G.m == 1 && (long)lds < pad_kib * 1024) lds = (size_t)pad_kib * 1024;
+    }
+#endif
     // the attribute belongs to the function ON THE CURRENT DEVICE: a node drives several devices from one process
     // (rg_node.hip), each from its own host thread
     static std::atomic<unsigned long long> attr_set{0};
@@ -1226,16 +1157,10 @@ static hipError_t launch_main_fmt(int nch, const RgTmCoef &K, const RgTmGeom &G,
     if (G.m > 1) {
         if (!lds_tables) return hipErrorInvalidValue;  // multi-window segments exist on the LDS path only
         hipLaunchKernelGGL((rg_tm_main_kernel<FMT, true, SERVO>), dim3(grid), dim3(G.block), lds, s, K, G, d_tracks, n_tracks,
-                           d_rec, total_recs, d_win, total_windows, d_nonfinite, lds_tables, split ? 1u : G.m, d_zero, zero_count, g_tm_debug);
-        if (split) {  // windows 2..m at four waves per SIMD; the same lanes, in blocks of 256
-            const uint64_t lanes = (uint64_t)grid * G.block;
-            const uint32_t pgrid = (uint32_t)((lanes + RG_TM_BLOCK - 1) / RG_TM_BLOCK);
-            hipLaunchKernelGGL((rg_tm_plain_kernel<FMT, SERVO>), dim3(pgrid), dim3(RG_TM_BLOCK), (RG_TM_BLOCK / 64) * RG_TM_WAVE_TILE_BYTES * 2, s, K, G,
-                               d_tracks, n_tracks, d_rec, total_recs, d_win, total_windows, d_nonfinite);
-        }
+                           d_rec, total_recs, d_win, total_windows, d_nonfinite, lds_tables, d_zero, zero_count, g_tm_debug);
     } else {
         hipLaunchKernelGGL((rg_tm_main_kernel<FMT, false, SERVO>), dim3(grid), dim3(G.block), lds, s, K, G, d_tracks, n_tracks,
-                           d_rec, total_recs, d_win, total_windows, d_nonfinite, lds_tables, 1u, d_zero, zero_count, g_tm_debug);
+                           d_rec, total_recs, d_win, total_windows, d_nonfinite, lds_tables, d_zero, zero_count, g_tm_debug);
     }
     return hipGetLastError();
 }
@@ -1243,9 +1168,9 @@ static hipError_t launch_main_fmt(int nch, const RgTmCoef &K, const RgTmGeom &G,
 extern "C" hipError_t rg_launch_tm_main(int fmt, int nch, const RgTmCoef *K, const RgTmGeom *G,
                                         const RgTmTrack *d_tracks, uint32_t n_tracks, uint32_t grid, double *d_rec,
                                         uint32_t total_recs, double *d_win, uint32_t total_windows, uint32_t *d_nonfinite,
-                                        uint32_t *d_zero, uint64_t zero_count, int split, hipStream_t s) {
+                                        uint32_t *d_zero, uint64_t zero_count, hipStream_t s) {
     if (grid == 0) return hipSuccess;
-#define RG_TM_LAUNCH(F, SV) launch_main_fmt<F, SV>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_win, total_windows, d_nonfinite, d_zero, zero_count, split, s)
+#define RG_TM_LAUNCH(F, SV) launch_main_fmt<F, SV>(nch, *K, *G, d_tracks, n_tracks, grid, d_rec, total_recs, d_win, total_windows, d_nonfinite, d_zero, zero_count, s)
     if (G->servo) {
         switch (fmt) {
             case RG_FMT_F32_PLANAR: return RG_TM_LAUNCH(RG_FMT_F32_PLANAR, true);

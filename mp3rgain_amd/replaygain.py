@@ -420,7 +420,8 @@ class Analyzer:
             raise ReplayGainError(-7, "ncclGetUniqueId failed on rank 0 (librccl.so not found?)")
         err = None
         if explicit and lib_rc != 0:  # a library that was asked for by name and cannot be loaded: agreed on below, like any other failure
-            err = ReplayGainError(int(lib_rc), f"cannot load {lib}")
+            err = ReplayGainError(int(lib_rc), f"refused {lib}: not a librccl.so[.N] (a stand-in transport needs MP3RGAIN_AMD_TEST_SEAMS=1)"
+                                  if int(lib_rc) == -10 else f"cannot load {lib}")
         else:
             try:
                 self.comm_init(box[0], world, rank)

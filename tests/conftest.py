@@ -58,11 +58,10 @@ def _ctx(capi):
 #   (2, -2)   transient-moment kernels, one segment per window
 #   (2, -3)   transient-moment kernels, four windows per segment (moments over the first, plain energies for the rest)
 #   (2, -4)   transient-moment kernels, sixteen windows per segment
-#   (2, -5)   four windows per segment, windows 2..4 in the kernel of their own (tuning key 9: rg_tm_plain_kernel)
 #   (2, -6)   thirty-seven windows per segment (round 4: what a 1000-track batch runs at, one round of blocks; rows whose
 #             track ends inside a lane's run re-read the track's first window)
-@pytest.fixture(params=[(1, 0), (2, 0), (2, -1), (2, -2), (2, -3), (2, -4), (2, -5), (2, -6)],
-                ids=["halo", "tm-auto", "tm-short", "tm-window", "tm-multi4", "tm-multi16", "tm-multi4-split", "tm-multi37"])
+@pytest.fixture(params=[(1, 0), (2, 0), (2, -1), (2, -2), (2, -3), (2, -4), (2, -6)],
+                ids=["halo", "tm-auto", "tm-short", "tm-window", "tm-multi4", "tm-multi16", "tm-multi37"])
 def analyzer(_ctx, request):
     variant, seg = request.param
     _ctx.set_kernel(variant)
@@ -80,15 +79,10 @@ def analyzer(_ctx, request):
     elif seg == -4:
         _ctx.set_tuning(2, 1)
         _ctx.set_tuning(4, 16)
-    elif seg == -5:
-        _ctx.set_tuning(2, 1)
-        _ctx.set_tuning(4, 4)
-        _ctx.set_tuning(9, 1)
     elif seg == -6:
         _ctx.set_tuning(2, 1)
         _ctx.set_tuning(4, 37)
     yield _ctx
-    _ctx.set_tuning(9, 0)
     _ctx.set_kernel(0)
     _ctx.set_tuning(1, 0)
     _ctx.set_tuning(2, 0)
