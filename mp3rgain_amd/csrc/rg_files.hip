@@ -820,7 +820,9 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
                     PipeChunk &ch = R.chunks[(size_t)R.open];
                     Mp3Stage &st = P.stage[ch.stage];
                     const size_t with = ch.used + need + rg_mp3dev_track_bytes(ch.files.size() + 1) + 64;
-                    if (with <= st.cap && ch.units + units <= kPipeChunkUnits) break;
+                    // (the call's first chunks are smaller: the device has nothing to do until the first one is complete)
+                    const uint64_t unit_cap = R.open < 3 ? kPipeChunkUnits >> (3 - R.open) : kPipeChunkUnits;  // 1/8, 1/4, 1/2, then whole chunks
+                    if (with <= st.cap && ch.units + units <= unit_cap) break;
                     if (ch.files.empty()) {  // a stream larger than a block: the block grows (nothing is in flight from it)
                         if (!grow_stage(st, with)) { hip_fail("hipHostMalloc of a staging block failed"); (*rcs)[i] = RG_ERR_DEVICE; err = "out of pinned memory"; la.staged = false; return; }
                         break;

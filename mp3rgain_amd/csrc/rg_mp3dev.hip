@@ -850,7 +850,7 @@ constexpr int kHuffThreads = 512;  // 1024 (eight waves per SIMD instead of six)
 
 // The bit reader.  Under SIMT whatever ONE lane of a wave has to do now and then -- take the next word of its stream, ask
 // for the next bytes, follow a long code into a second table -- the wave does every time, so the reader has no state to keep
-// in step with the position: a lane's stream passes through a ring of eight words in LDS (column `tid` of ring[8][threads],
+// in step with the position: a lane's stream passes through a ring of eight or sixteen words in LDS (column `tid` of ring[words][threads],
 // big-endian words with everything at or past `limit` -- the end of the frame's own main data -- already zero, which is what
 // the host decoder's private copy of the frame's data reads there), and a look at the stream is three words from the ring and
 // two 64-bit shifts by the position's low five bits, whatever the position.  The ring is fed sixteen bytes at a time -- one
@@ -858,11 +858,15 @@ constexpr int kHuffThreads = 512;  // 1024 (eight waves per SIMD instead of six)
 // length from anywhere in the chunk and every request is a DRAM page of its own -- at points of the loops where the whole
 // wave feeds together.  Positions are 32-bit bit counts from the 16-byte group the granule starts in (a granule is at most
 // 4095 bits long).
+#ifndef RG_HF_RING
+#define RG_HF_RING 16  // words of a lane's ring: 8 (fed 16 bytes at a time) or 16 (fed 32 bytes at a time)
+#endif
 struct BitRing {
-    uint32_t *__restrict__ ring;     // the thread's column: word i of the stream at ring[(i & 7) * kHuffThreads]
+    static constexpr uint32_t kWords = RG_HF_RING, kMask = RG_HF_RING - 1, kFeed = RG_HF_RING / 2;  // words per feed
+    uint32_t *__restrict__ ring;     // the thread's column: word i of the stream at ring[(i & kMask) * kHuffThreads]
     const uint4 *__restrict__ g;     // the next group to ask for (the track's main data is 16-byte aligned)
-    uint4 c;                         // the group in flight: words filled .. filled + 3
-    uint32_t filled;                 // words in the ring (a multiple of 4)
+    uint4 c[kFeed / 4];              // the groups in flight: words filled .. filled + kFeed - 1
+    uint32_t filled;                 // words in the ring (a multiple of kFeed)
     uint32_t pos, end;               // read position, end of the granule's bits
     int32_t limit;                   // end of the frame's own data; may lie before `pos` in damaged streams
     __device__ __forceinline__ uint32_t masked(uint32_t raw, uint32_t i) const {
@@ -871,7 +875,7 @@ struct BitRing {
         return __builtin_bswap32(raw) & (uint32_t)(0xFFFFFFFF00000000ull >> v);
     }
     __device__ __forceinline__ void commit(const uint4 &q) {
-        uint32_t *const at = ring + (filled & 4u) * kHuffThreads;
+        uint32_t *const at = ring + (filled & kMask) * kHuffThreads;  // filled is a multiple of 4: no wrap inside a group
         if ((int32_t)((filled + 4u) << 5) <= limit) {  // far from the end of the frame's data: nothing to mask
             at[0 * kHuffThreads] = __builtin_bswap32(q.x);
             at[1 * kHuffThreads] = __builtin_bswap32(q.y);
@@ -885,40 +889,48 @@ struct BitRing {
         }
         filled += 4u;
     }
-    // The group in flight goes into the ring if half of the ring is free, and the next one is asked for.  Called once per
+    // The groups in flight go into the ring if half of the ring is free, and the next ones are asked for.  Called once per
     // step of at most three words (two big_values pairs: 94 bits; four quadruples: 40 bits), this keeps at least five words
     // ahead of the position at the top of every step: a look needs three, and the step's second pair may be two words on.
+    // (Half a ring per feed: with sixteen words a lane asks for 32 bytes of a line at a time -- the chunk's lanes hold more
+    // lines than the L2 does, and a line is often gone before the lane comes back for more of it.)
     __device__ __forceinline__ void feed() {
-        if (filled - (pos >> 5) <= 4u) {
-            commit(c);
-            c = *g++;
+        if (filled - (pos >> 5) <= kWords - kFeed) {
+#pragma unroll
+            for (uint32_t k = 0; k < kFeed / 4; ++k) commit(c[k]);
+#pragma unroll
+            for (uint32_t k = 0; k < kFeed / 4; ++k) c[k] = g[k];
+            g += kFeed / 4;
         }
     }
     // granule at absolute bit `bit_off` of the stream `base`, `length` bits long, frame data ending at `frame_end_bit`
     __device__ __forceinline__ void open(const uint8_t *base, uint64_t bit_off, uint32_t length, uint64_t frame_end_bit) {
-        const uint64_t group0 = bit_off >> 7;
+        const uint64_t group0 = (bit_off >> 7) & ~(uint64_t)(kFeed / 4 - 1);  // feeds are aligned to their own size
         g = reinterpret_cast<const uint4 *>(base) + group0;
         pos = (uint32_t)(bit_off - (group0 << 7));
         end = pos + length;
         const int64_t lim = (int64_t)frame_end_bit - (int64_t)(group0 << 7);
         limit = lim < -(1 << 30) ? -(1 << 30) : (lim > (1 << 30) ? (1 << 30) : (int32_t)lim);
-        const uint4 p0 = g[0], p1 = g[1];
-        c = g[2];
-        g += 3;
+        uint4 p[kWords / 4];
+#pragma unroll
+        for (uint32_t k = 0; k < kWords / 4; ++k) p[k] = g[k];
+#pragma unroll
+        for (uint32_t k = 0; k < kFeed / 4; ++k) c[k] = g[kWords / 4 + k];
+        g += kWords / 4 + kFeed / 4;
         filled = 0u;
-        commit(p0);
-        commit(p1);
+#pragma unroll
+        for (uint32_t k = 0; k < kWords / 4; ++k) commit(p[k]);
     }
     // the 64 bits at the read position
     __device__ __forceinline__ void window64(uint32_t &hi, uint32_t &lo) const {
         const uint32_t wi = pos >> 5, sh = pos & 31u;
-        const uint32_t w0 = ring[(wi & 7u) * kHuffThreads], w1 = ring[((wi + 1u) & 7u) * kHuffThreads], w2 = ring[((wi + 2u) & 7u) * kHuffThreads];
+        const uint32_t w0 = ring[(wi & kMask) * kHuffThreads], w1 = ring[((wi + 1u) & kMask) * kHuffThreads], w2 = ring[((wi + 2u) & kMask) * kHuffThreads];
         hi = (uint32_t)(((((uint64_t)w0 << 32) | w1) << sh) >> 32);
         lo = (uint32_t)(((((uint64_t)w1 << 32) | w2) << sh) >> 32);
     }
     __device__ __forceinline__ uint32_t window() const {  // the 32 bits at the read position
         const uint32_t wi = pos >> 5, sh = pos & 31u;
-        const uint32_t w0 = ring[(wi & 7u) * kHuffThreads], w1 = ring[((wi + 1u) & 7u) * kHuffThreads];
+        const uint32_t w0 = ring[(wi & kMask) * kHuffThreads], w1 = ring[((wi + 1u) & kMask) * kHuffThreads];
         return (uint32_t)(((((uint64_t)w0 << 32) | w1) << sh) >> 32);
     }
     // scalefactors (at most five bits at a time; lanes on different paths): a lane feeds when it has to
@@ -1000,7 +1012,7 @@ extern "C" int rg_hf_dbg_read(void *out) { return (int)hipMemcpyFromSymbol(out, 
 #define RG_HF_STAMP(e) do { } while (0)
 #endif
 #ifndef RG_HF_WAVES
-#define RG_HF_WAVES 4
+#define RG_HF_WAVES (RG_HF_RING == 8 ? 6 : 4)  // per SIMD: three blocks per CU with the 8-word ring (51.6 KB of LDS), two with the 16-word one (67.6 KB)
 #endif
 __global__ void __launch_bounds__(kHuffThreads) __attribute__((amdgpu_waves_per_eu(RG_HF_WAVES, RG_HF_WAVES)))
 rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *__restrict__ H,
@@ -1010,9 +1022,13 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
     __shared__ uint16_t E_all[RG_MP3_HUFF_LDS_ENTRIES];
     __shared__ uint32_t t_rp[32];
     __shared__ uint8_t quadA[64];
-    __shared__ uint8_t sf_all[40 * kHuffThreads];
-    __shared__ uint32_t stg_all[8 * kHuffThreads];
-    __shared__ uint32_t ring_all[8 * kHuffThreads];
+    // the scalefactors' columns (40 bytes per thread) and, once every thread of the block has taken its scalefactors into
+    // registers, the columns in which the spectrum's sectors are put together (8 words per thread): 20 KB instead of 36, and with
+    // the tables and the bit ring 51.6 KB -- three blocks per CU
+    __shared__ __attribute__((aligned(16))) uint8_t sf_all[40 * kHuffThreads];
+    uint32_t *const stg_all = reinterpret_cast<uint32_t *>(sf_all);
+    static_assert(8 * 4 <= 40, "the sector columns fit where the scalefactor columns were");
+    __shared__ uint32_t ring_all[RG_HF_RING * kHuffThreads];
     const int tid = threadIdx.x;
     RG_HF_STAMP(0);
     const uint32_t n_e = H->n_entries;  // + 2 <= RG_MP3_HUFF_LDS_ENTRIES: checked when the tables are uploaded; e16[n_e], [n_e + 1] = 0
@@ -1062,6 +1078,25 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
     }
     b.open(main + tr.main_base, r.bit_off, r.part2_3_length, r.frame_end_bit);
     huff_scalefactors(b, r, tr.lsf != 0, reuse, sf, &illegal, &preflag);
+    // the unit's scalefactors, out of LDS for good
+    uint32_t sfw[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+    {
+        sfw[i] = (uint32_t)sf[(4 * i) * kHuffThreads] | ((uint32_t)sf[(4 * i + 1) * kHuffThreads] << 8) | ((uint32_t)sf[(4 * i + 2) * kHuffThreads] << 16) |
+                 ((uint32_t)sf[(4 * i + 3) * kHuffThreads] << 24);
+        if (i & 1) __builtin_amdgcn_sched_barrier(0);  // eight reads in flight, not forty: their registers set the kernel's count
+    }
+    // ... and into the unit at once (its first 48 bytes; the last 16 -- nz is among them -- follow when the spectrum is done): ten
+    // registers less through the loops below
+    {
+        uint4 *const up = reinterpret_cast<uint4 *>(units + u);
+        up[0] = make_uint4(sfw[0], sfw[1], sfw[2], sfw[3]);
+        up[1] = make_uint4(sfw[4], sfw[5], sfw[6], sfw[7]);
+        up[2] = make_uint4(sfw[8], sfw[9], (uint32_t)illegal, (uint32_t)(illegal >> 32));
+    }
+    // (waves that lie wholly behind the last unit have ended above: the hardware's barrier counts the waves still there)
+    __syncthreads();
     RG_HF_STAMP(2);
     // ---- band layout and big_values regions (rg_mp3dec.cpp: parse_side_info, derived part) ----
     int long_end, short_start;
@@ -1225,25 +1260,15 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
         if (!done) nz = line > 576 ? 576 : line;
     }
     RG_HF_STAMP(4);
-    // ---- the unit ----
-    rg_mp3_unit o;
-#pragma unroll
-    for (int i = 0; i < 40; ++i) o.sf[i] = sf[i * kHuffThreads];
-    o.illegal = illegal;
-    o.nz = (uint16_t)nz;
-    o.global_gain = r.global_gain;
-    o.block_type = r.block_type;
-    o.mixed = r.mixed;
-    o.subblock_gain[0] = r.subblock_gain[0]; o.subblock_gain[1] = r.subblock_gain[1]; o.subblock_gain[2] = r.subblock_gain[2];
-    o.scalefac_scale = r.scalefac_scale;
-    o.preflag = (uint8_t)preflag;
-    o.long_end = (uint8_t)long_end;
-    o.short_start = (uint8_t)short_start;
-    o.mode_ext = r.mode_ext;
-    o.intensity_scale = r.intensity_scale;
-    o.reserved[0] = (uint8_t)hi_found;  // words of the row's second plane worth reading (device spectra only)
-    o.reserved[1] = 0;
-    units[u] = o;
+    // ---- the unit's last 16 bytes ----
+    static_assert(offsetof(rg_mp3_unit, nz) == 48 && sizeof(rg_mp3_unit) == 64, "unit layout");
+    {
+        const uint32_t w0 = (uint32_t)nz | ((uint32_t)r.global_gain << 16) | ((uint32_t)r.block_type << 24);
+        const uint32_t w1 = (uint32_t)r.mixed | ((uint32_t)r.subblock_gain[0] << 8) | ((uint32_t)r.subblock_gain[1] << 16) | ((uint32_t)r.subblock_gain[2] << 24);
+        const uint32_t w2 = (uint32_t)r.scalefac_scale | ((uint32_t)(preflag & 0xFF) << 8) | ((uint32_t)long_end << 16) | ((uint32_t)short_start << 24);
+        const uint32_t w3 = (uint32_t)r.mode_ext | ((uint32_t)r.intensity_scale << 8) | ((uint32_t)(hi_found & 0xFF) << 16);  // reserved[0]: words of the second plane worth reading
+        reinterpret_cast<uint4 *>(units + u)[3] = make_uint4(w0, w1, w2, w3);
+    }
     RG_HF_STAMP(5);
 }
 
