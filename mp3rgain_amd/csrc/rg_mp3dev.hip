@@ -92,9 +92,9 @@ __device__ __forceinline__ void rg_lds_barrier() {
 // Instrument (tools/build_variant.sh NAME -DRG_BH_TIMING=<block>; tools/bh_timing.py): shader-clock stamps of one block's
 // waves around their work of every pipeline step, and inside the requantisation wave
 __device__ unsigned long long rg_bh_dbg[4][40][2];
-__device__ unsigned long long rg_bh_dbg2[40][4];
+__device__ unsigned long long rg_bh_dbg2[40][6];
 extern "C" int rg_bh_dbg_read(void *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rg_bh_dbg), sizeof(unsigned long long) * 4 * 40 * 2); }
-extern "C" int rg_bh_dbg2_read(void *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rg_bh_dbg2), sizeof(unsigned long long) * 40 * 4); }
+extern "C" int rg_bh_dbg2_read(void *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rg_bh_dbg2), sizeof(unsigned long long) * 40 * 6); }
 #define RG_BH_STAMP(w, k, e) do { if (blockIdx.x == RG_BH_TIMING && (threadIdx.x & 63) == 0 && (k) < 40) rg_bh_dbg[w][k][e] = __builtin_amdgcn_s_memtime(); } while (0)
 #define RG_BH_STAMP2(k, e) do { if (blockIdx.x == RG_BH_TIMING && (threadIdx.x & 63) == 0 && (k) < 40) rg_bh_dbg2[k][e] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -287,6 +287,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                 // (past the run's last granule the same units and spectra are asked for again and never used)
                 if (uq) reinterpret_cast<uint4 *>(&Ub[(k + 1) % 3][0])[uq_t] = u_reg;
                 header_of(u_reg, h_next);
+                RG_BH_STAMP2(k, 4);
                 // ---- stage B: requantisation (rg_mp3dec.cpp: requantize)
                 uint2 raw[kRounds][2];
 #pragma unroll
@@ -302,6 +303,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                     for (int r = 0; r < kRounds; ++r)
                         if (nz8 < 256 * (r + 1) && 4 * (lane + 64 * r) >= nz8) raw[r][c] = make_uint2(0u, 0u);  // the first test is the wave's
                 }
+                RG_BH_STAMP2(k, 5);
                 // Two planes of a byte per line.  Past the longest second plane of the step's units (hi_q words of four lines: as far
                 // as a magnitude above 127 was actually found, usually nowhere, else in the first few dozen lines) a byte is its
                 // line's index into the LDS part of the x^(4/3) table -- no absolute value, no clamp, no large-value pass.  A round
@@ -401,7 +403,12 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                     }
                 }
                 RG_BH_STAMP2(k, 3);
+                // (asked for at the top of the step instead -- 2000 cycles earlier -- the units change nothing: 0.358 against 0.354 ms)
+#ifdef RG_BH_SAMEUNIT  // experiment (wrong results): every step reads the run's first unit again -- what the units' latency costs the step
+                if (uq) u_reg = reinterpret_cast<const uint4 *>(units + ubase + (uint64_t)(k & 0) * nch)[uq_t];
+#else
                 if (uq) u_reg = reinterpret_cast<const uint4 *>(units + ubase + (uint64_t)(k + 2 < nsteps ? k + 2 : nsteps - 1) * nch)[uq_t];
+#endif
                 fetch_spectra(k + 1 < nsteps ? k + 1 : nsteps - 1, h_next);
                 int bt_s[2] = {0, 0}, ll_s[2] = {0, 0}, so_s[2] = {0, 0};
                 int gq_idx[2] = {0, 0};

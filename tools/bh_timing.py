@@ -57,9 +57,13 @@ for label, src in (("dense320_synthetic", ROOT / "tests/golden/mp3/v1_44k_stereo
     for w in (1, 0, 2, 3):
         busy = (t[w, :, 1] - t[w, :, 0])[steps]
         print(f"   wave {w} {names[w]:8s}: busy mean {busy.mean():7.0f}  min {busy.min():6d}  max {busy.max():6d}   = {busy.mean() / period.mean() * 100:4.0f} % of the step")
-    d2 = np.zeros((40, 4), dtype=np.uint64)
+    d2 = np.zeros((40, 6), dtype=np.uint64)
     assert lib.rg_bh_dbg2_read(C.c_void_p(d2.ctypes.data)) == 0
     d2 = d2.astype(np.int64)
+    u0 = (d2[:, 4] - t[1, :, 0])[steps]
+    u1 = (d2[:, 5] - d2[:, 4])[steps]
+    u2 = (d2[:, 2] - d2[:, 5])[steps]
+    print(f"   requant wave, arrivals: the step's units in hand {u0.mean():.0f}, its spectra in hand and zeroed {u1.mean():.0f}, second-plane work {u2.mean():.0f} cycles")
     a0 = (d2[:, 2] - t[1, :, 0])[steps]
     a1 = (d2[:, 3] - d2[:, 2])[steps]
     a2 = (d2[:, 0] - d2[:, 3])[steps]

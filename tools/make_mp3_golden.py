@@ -36,7 +36,7 @@ def legal_is_positions(g, lsf, rng):
 # decoders may, and ffmpeg's does, use that a short block's predecessor leaves zeros in the last third of its overlap.
 def build_case(name, rate, mode, mode_ext, nframes, seed, *, block_types=(0,), mixed_prob=0.0, bitrate=None, crc=False,
                gg=(150, 165), big=12, lines=(200, 520), huge_every=0, is_cut=None, sfc_lsf=None, stuffing=True,
-               padding_every=0, sbg=False, return_specs=False):
+               padding_every=0, sbg=False, return_specs=False, spikes=None):
     rng = random.Random(seed)
     lsf = rate < 32000
     nch = 1 if mode == 3 else 2
@@ -58,6 +58,9 @@ def build_case(name, rate, mode, mode_ext, nframes, seed, *, block_types=(0,), m
                     nlines = min(nlines, is_cut)
                 vals = B.random_spectrum(rng, nlines, big, tail_ones=0 if (is_cut is not None and ch == 1) else rng.choice([0, 16, 40]),
                                          huge_every=huge_every)
+                if spikes:  # (count, lo, hi): large magnitudes anywhere below the last nonzero line, high lines included
+                    for _ in range(spikes[0]):
+                        vals[rng.randrange(max(2, nlines - (nlines & 1)))] = rng.choice([-1, 1]) * rng.randint(spikes[1], spikes[2])
                 g = B.GranuleSpec(values=vals, global_gain=rng.randint(*gg), block_type=bt,
                                   mixed=mixed,
                                   scalefac_scale=rng.randrange(2), count1table=rng.randrange(2))
@@ -130,6 +133,10 @@ CASES = [
     # name, rate, mode, mode_ext, frames, seed, options
     ("v1_44k_stereo_long", 44100, 0, 0, 8, 101, dict(bitrate=320, huge_every=0)),
     ("v1_44k_stereo_linbits", 44100, 0, 0, 6, 102, dict(bitrate=320, huge_every=7, gg=(120, 135), lines=(60, 200))),
+    # large values (above 127, above the 704 of the back half's LDS power table, up to the escape limit) at every height of the
+    # spectrum, above line 256 and 512 too: the device format's second byte plane at its full length
+    ("v1_44k_ms_spikes_high", 44100, 1, 2, 8, 110, dict(bitrate=320, gg=(114, 126), big=3, lines=(300, 576), spikes=(14, 128, 2500),
+                                                        block_types=(0, 0, 1, 2, 3, 0))),
     ("v1_48k_ms_blocktypes", 48000, 1, 2, 10, 103, dict(bitrate=320, block_types=(0, 1, 2, 2, 3, 0, 0, 1, 2, 3), sbg=True)),
     ("v1_44k_ms_mixed", 44100, 1, 2, 8, 104, dict(bitrate=320, block_types=(1, 2, 2, 3), mixed_prob=1.0, sbg=True)),
     ("v1_32k_intensity", 32000, 1, 1, 8, 105, dict(bitrate=256, is_cut=120)),
