@@ -853,7 +853,10 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
 // thread then parses granule 0's scalefactors first, which is cheaper than chaining the two granules in one thread.
 namespace {
 
-constexpr int kHuffThreads = 512;  // 1024 (eight waves per SIMD instead of six) is slower: 0.44 against 0.38 ms on the dense stream
+#ifndef RG_HF_THREADS
+#define RG_HF_THREADS 512
+#endif
+constexpr int kHuffThreads = RG_HF_THREADS;
 
 // The bit reader.  Under SIMT whatever ONE lane of a wave has to do now and then -- take the next word of its stream, ask
 // for the next bytes, follow a long code into a second table -- the wave does every time, so the reader has no state to keep
@@ -1053,13 +1056,16 @@ rg_mp3_huffman_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevHuff *
     // Lane i takes the i-th unit of the chunk's units ordered by big_values (rg_mp3_sort_*): a wave lasts as long as its
     // longest lane, and in stream order a wave holds mid and side channels, loud and quiet granules side by side -- 2 to 3
     // times the iterations its units need on average.
-#ifdef RG_HF_NOSTRIPE
+#ifndef RG_HF_STRIPE
+    // Blocks in the order of the sort, heaviest first: a chunk is several generations of blocks (rg_files.hip: 768 K units
+    // against 262 144 resident lanes), the long blocks start first and the short ones fill in behind them.
     const uint32_t slot = blockIdx.x * kHuffThreads + (uint32_t)tid;
 #else
-    // The sorted order is dealt to the blocks in stripes: wave w of a block takes the block's share of the w-th eighth of the
-    // order (waves w and w + 4, which share a SIMD, the eighths w and 7 - w), so that every block, every CU and every SIMD gets
-    // the same mix of long and short waves whatever the dispatcher does: a chunk is one generation of blocks, and the launch
-    // lasts as long as its most loaded SIMD.
+    // Tried, and better only when a chunk is a single generation of blocks (0.158 / 0.142 / 0.060 ms per 256 K units without,
+    // 0.171 / 0.154 / 0.082 with, in 768 K-unit chunks): the sorted order dealt to the blocks in stripes -- wave w of a block takes
+    // the block's share of the w-th eighth of the order (waves w and w + 4, which share a SIMD, the eighths w and 7 - w) -- so
+    // that every SIMD gets the same mix of long and short waves.  But then every block lasts as long as the longest waves, and
+    // its slots are free only when it has ended.
     const uint32_t wv = (uint32_t)tid >> 6;
     const uint32_t slot = (((wv < 4u ? wv : 11u - wv) * gridDim.x + blockIdx.x) << 6) + ((uint32_t)tid & 63u);
 #endif
