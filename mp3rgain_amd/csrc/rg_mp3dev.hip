@@ -230,6 +230,9 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         // values above line 256: rare) is read at the top of the step that needs it.  `hd`: the unit headers of the step asked
         // for (its nz and hi_q are the wave's).
         auto fetch_spectra = [&](const int step, const uint32_t (&hd)[2][4]) {
+#ifdef RG_BH_NOFETCH  // experiment (wrong results): the spectra are asked for once per run -- what issuing the loads costs the step
+            if (step > 0) return;
+#endif
 #pragma unroll
             for (int c = 0; c < nch; ++c) {
 #ifdef RG_BH_SAMEROW  // experiment (wrong results): every step reads the run's first rows again -- what memory latency costs the step
@@ -422,7 +425,11 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                     const int rel = gq_kk - (short_start == 0 ? 0 : (short_start == 3 ? 9 : 39));  // 3 short_start: it is 0, 3 or 13
                     const bool short_sf = lane >= 22 && gq_band < 12 && rel >= 0;
                     gq_idx[c] = lane < 22 ? lane : (short_sf ? long_end + rel : -1);
+#ifdef RG_BH_NOGAINS  // experiment (wrong results): no scalefactor, no gain look-up -- what the gains cost the step
+                    gq_sf[c] = 0;
+#else
                     gq_sf[c] = UP[c].sf[gq_idx[c] < 0 ? 0 : gq_idx[c]];
+#endif
                 }
                 float gq_g[2] = {0.0f, 0.0f};
 #pragma unroll
@@ -437,7 +444,11 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                     if (lane < 22) q = base4 - m4 * (sv + (preflag ? gq_pt : 0));
                     else q = base4 - 8 * (int)((h[c][1] >> gq_sh) & 0xFFu) - m4 * sv;
                     q = q < RG_MP3_GAIN_Q_MIN ? RG_MP3_GAIN_Q_MIN : (q > RG_MP3_GAIN_Q_MAX ? RG_MP3_GAIN_Q_MAX : q);
+#ifdef RG_BH_NOGAINS
+                    gq_g[c] = __int_as_float(0x3f800000 + (q << 10));
+#else
                     gq_g[c] = gain_l[q - RG_MP3_GAIN_Q_MIN];
+#endif
                     bt_s[c] = (int)(h[c][0] >> 24);
                     ll_s[c] = long_end == 22 ? ll22 : (long_end == 8 ? ll8 : (long_end == 6 ? ll6 : (long_end == 0 ? 0 : (int)sfbl_l[long_end])));
                     so_s[c] = short_start >= 13 ? so13 : (short_start == 3 ? so3 : (short_start == 0 ? 0 : 3 * (int)sfbs_l[short_start]));
