@@ -292,10 +292,18 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
         }
         // FP64 issue efficiency by waves per SIMD (tools/ubench/frame.hip: 188 / 160 / 147 cycles per frame)
         const double wps = std::min(blocks_cu, std::max(1.0, c->one_shot ? rounds : waves / 1024.0));
-        const double eff = wps >= 3.0 ? 1.0 : (wps >= 2.0 ? 1.09 + (3.0 - wps) * 0.0 : 1.28 - (wps - 1.0) * 0.19);
+        double eff = wps >= 3.0 ? 1.0 : (wps >= 2.0 ? 1.09 + (3.0 - wps) * 0.0 : 1.28 - (wps - 1.0) * 0.19);
+        // Where the response tables, not the batch, keep a CU at one or two waves per SIMD (96 kHz: H10 = 1212 frames, 135 KB of
+        // tables at L = 2400) the kernel loses less than the frame-only microbenchmark: fitted on the 96 kHz sweep of round 5
+        // (L = 2400 / 1600 / 1200 at one wave per SIMD against L = 960 / 800 / 600 / 480 at three), 1.10 at one wave.
+        if (blocks_cu < 3.0 && (c->one_shot ? rounds : waves / 1024.0) >= 3.0) eff = blocks_cu >= 2.0 ? 1.04 : 1.10;
         // tables that do not fit a CU's LDS (160 KiB) send the whole launch down the generic path
         // rounds * cost covers every lane of the batch whatever the segment stride is, so candidates compare on it directly
         score[i] = rounds * cost * eff * (lds > (double)RG_TM_LDS_BYTES ? 8.0 : 1.0);
+        if (const char *e = getenv("RG_TRACE_TM"))
+            if (e[0] == '2')
+                fprintf(stderr, "[tm]   L %u m %u: H10 %u block %u lds %.0f blocks/CU %.0f waves %.0f rounds %.2f wps %.2f eff %.2f cost/frame %.2f score %.4g\n", L, m, H10,
+                        block, lds, blocks_cu, waves, rounds, wps, eff, cost / (double)stride, score[i]);
         if (score[i] < best) { best = score[i]; best_i = i; }
     }
     // try the candidates from the best score on (tiny L can need too many scan rounds)

@@ -14,8 +14,14 @@ from mp3rgain_amd import _capi  # noqa: E402
 ntr = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 minutes = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
 an = rg.Analyzer(0)
-for rate in (96000, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000):
-    for ch in (2, 1):
+import os  # noqa: E402
+rates = [int(x) for x in os.environ["RATES"].split(",")] if os.environ.get("RATES") else (96000, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000)
+if os.environ.get("TM_SEGMENT"):  # tuning key 1: segment length; key 4: most windows per lane
+    an.set_tuning(1, int(os.environ["TM_SEGMENT"]))
+if os.environ.get("TM_WINDOWS"):
+    an.set_tuning(4, int(os.environ["TM_WINDOWS"]))
+for rate in rates:
+    for ch in ((2,) if os.environ.get("STEREO_ONLY") else (2, 1)):
         frames = int(rate * 60 * minutes)
         pcm = torch.empty((ntr, ch, frames), dtype=torch.float32, device="cuda")
         d = (_capi.TrackDesc * ntr)()
