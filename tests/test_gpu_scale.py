@@ -70,6 +70,27 @@ def test_config3_shape_batch_properties(analyzer, oracle):
         assert np.array_equal(h[t], wh) and got[t].peak == want["peak"]
 
 
+@pytest.mark.parametrize("rate,n,seconds", [(96000, 20, 150), (64000, 72, 170)])
+def test_high_rate_batches_large_enough_for_the_long_segments(analyzer, oracle, rate, n, seconds):
+    """Batches at 96 / 64 kHz large enough that the segment chooser takes what it takes for production-size batches there --
+    the longest segment whose response tables still fit the LDS (96 kHz: L = 2400, one wave per SIMD) and several windows per
+    lane (64 kHz) -- against the oracle on a sample of tracks, and the album as the sum of its tracks."""
+    frames = seconds * rate + 977  # not a whole number of windows
+    seeds = [0x5EED9000 + 16 * (rate // 1000) + t for t in range(n)]
+    buf, descs = _device_batch(analyzer, seeds, [frames] * n, rate=rate)
+    analyzer.enqueue_device(descs, n, buf.data_ptr(), buf.numel() * 4, album=True)
+    got, h = analyzer.collect(n, want_hist=True)
+    alb, ah = analyzer.album_finish(want_hist=True)
+    assert np.array_equal(ah, h.sum(axis=0, dtype=np.uint64).astype(np.uint32))
+    assert alb.album_loudness_db == oracle.hist_loudness(ah)
+    for t in (0, n // 2, n - 1):
+        l, r = oracle.synth_f32(seeds[t], 0, rate, frames), oracle.synth_f32(seeds[t], 1, rate, frames)
+        want, wh = oracle.analyze_pcm(l, r, rate)
+        diff = np.nonzero(h[t] != wh)[0]
+        assert diff.size == 0, f"track {t}: {diff.size} bins differ, first {diff[:5]}"
+        assert got[t].loudness_db == want["loudness_db"] and got[t].peak == want["peak"]
+
+
 def test_pipelined_enqueues_are_idempotent(analyzer, oracle):
     """Back-to-back enqueues rotate through the pipeline slots and overlap on the GPU; every one of them
     must produce the same bits (no cross-slot interference), including the in-kernel clearing of accumulators."""
