@@ -258,7 +258,9 @@ def mp3_end_to_end(an, nfiles: int) -> dict:
                                       "h2d_GBps_assumed": pcie_gbps,
                                       "stereo_samples_per_s": pcie_gbps * 1e9 / (len(stream) / si.frames)},
             "note": "HIP events around each kernel on the stream it runs on; one chunk of `units_per_launch` granule-channels, 30 repetitions "
-                    "back to back; the compressed bytes are copied H2D per repetition on the copy stream, beside the kernels"}
+                    "back to back; the compressed bytes are copied H2D per repetition on the copy stream, beside the kernels; `chain` has the "
+                    "frame parser and lane sort in line between the events, `chain_pipelined` is per chunk the way the file route enqueues "
+                    "chunks (parser and sort on the copy stream, beside the Huffman / back-half kernels of the chunk before)"}
     except Exception as ex:  # noqa: BLE001
         leg["roofline"] = {"error": str(ex)}
     return leg

@@ -327,7 +327,8 @@ int rg_mp3_decode_device(rg_ctx *ctx, const void *data, size_t len, float *ch0, 
 
 /* Measurement hook: the device decode chain alone on `copies` copies of one stream (one chunk of the default route), each of
  * its three stages bracketed with HIP events on their own stream: ms_out[0..2] = frame parser, Huffman, back half (average of
- * `reps` repetitions), ms_out[3] = the chain.  units = granule-channels, frames = PCM frames per channel decoded
+ * `reps` repetitions), ms_out[3] = the chain, ms_out[4] = per chunk in the file route's own arrangement (the frame parser on the
+ * copy stream, beside the kernels of the chunk before); ms_out holds five values.  units = granule-channels, frames = PCM frames per channel decoded
  * per repetition, compressed_bytes = main data + slots the chain reads. */
 int rg_mp3_decode_bench(rg_ctx *ctx, const void *data, size_t len, uint32_t copies, uint32_t reps, double *ms_out,
                         uint64_t *units_out, uint64_t *compressed_bytes_out, uint64_t *frames_out);

@@ -326,11 +326,12 @@ class Analyzer:
 
     def decode_mp3_bench(self, data: bytes, copies: int, reps: int = 5) -> dict:
         """rg_mp3_decode_bench: per-kernel HIP-event times of the device decode chain on `copies` copies of one stream."""
-        ms = (C.c_double * 4)()
+        ms = (C.c_double * 5)()
         units, cbytes, frames = C.c_uint64(), C.c_uint64(), C.c_uint64()
         buf = (C.c_char * len(data)).from_buffer_copy(data)
         self._check(self._lib.rg_mp3_decode_bench(self._ctx, buf, len(data), copies, reps, ms, C.byref(units), C.byref(cbytes), C.byref(frames)))
-        return {"ms": {"frames": ms[0], "huffman": ms[1], "backhalf": ms[2], "chain": ms[3]},
+        # chain_pipelined: per chunk in the file route's arrangement (frame parser and lane sort beside the chunk before)
+        return {"ms": {"frames": ms[0], "huffman": ms[1], "backhalf": ms[2], "chain": ms[3], "chain_pipelined": ms[4]},
                 "units": units.value, "compressed_bytes": cbytes.value, "frames": frames.value}
 
     def analyze_wav_bytes(self, wavs: Sequence[bytes], album: bool = False):

@@ -474,7 +474,8 @@ def test_the_decode_bench_hook_counts_what_it_decodes(_ctx):
     assert r["frames"] == si.frames * copies
     assert 0.8 * len(data) * copies < r["compressed_bytes"] < 1.1 * len(data) * copies  # main data + a 40-byte slot per frame
     ms = r["ms"]
-    assert set(ms) == {"frames", "huffman", "backhalf", "chain"}
+    assert set(ms) == {"frames", "huffman", "backhalf", "chain", "chain_pipelined"}
+    assert 0.0 < ms["chain_pipelined"] <= 1.25 * ms["chain"] + 0.05
     assert all(v > 0.0 for v in ms.values())
     assert ms["chain"] >= max(ms["frames"], ms["huffman"], ms["backhalf"])
     assert ms["chain"] <= 1.5 * (ms["frames"] + ms["huffman"] + ms["backhalf"]) + 0.05
