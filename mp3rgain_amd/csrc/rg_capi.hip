@@ -273,6 +273,8 @@ extern "C" void rg_destroy(rg_ctx *c) {
         c->d_mp3_sortw_set[k].release();
     }
     c->h_mp3_results.release();
+    c->h_mp3_part_counts.release();
+    c->h_part_results.release();
     if (c->mp3_copy_stream) (void)hipStreamDestroy(c->mp3_copy_stream);
     for (int k = 0; k < 2; ++k)
         if (c->mp3_set_free[k]) (void)hipEventDestroy(c->mp3_set_free[k]);

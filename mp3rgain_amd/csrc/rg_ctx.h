@@ -164,6 +164,12 @@ struct rg_ctx {
     DevBuf<uint32_t> d_mp3_perm_set[2];
     DevBuf<uint32_t> d_mp3_sortw_set[2];
     PinnedBuf<uint32_t> h_mp3_results;
+    // An album of MPEG streams is analysed chunk by chunk while later chunks are still being copied and decoded (rg_files.hip:
+    // album parts): the batch enqueued next waits for `enqueue_wait_ev` (the chunk's decode) on its own stream; per chunk a copy
+    // of the frame parser's counts, and every part's per-track results, land in pinned memory without a host synchronise
+    hipEvent_t enqueue_wait_ev = nullptr;
+    PinnedBuf<uint32_t> h_mp3_part_counts;
+    PinnedBuf<rg_track_result> h_part_results;
     hipEvent_t *mp3_bench_ev = nullptr;      // rg_mp3_decode_bench: four events recorded around the three decode stages of a chunk
     void *mp3_pipe = nullptr;                // rg_files.hip: pinned staging blocks of the loader pipeline
     void (*mp3_pipe_free)(void *) = nullptr;

@@ -384,6 +384,7 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
         for (int k = 0; k < RG_MAX_SLOTS; ++k) RG_HIP(c, hipStreamWaitEvent(c->slots[k].stream, c->user_ev, 0));
         c->user_dirty = false;
     }
+    if (c->enqueue_wait_ev) RG_HIP(c, hipStreamWaitEvent(s, c->enqueue_wait_ev, 0));  // the batch's PCM is still being produced (rg_ctx.h)
     if (S.album_pending) {  // the previous album tail that used this slot's buffers ran on another stream
         RG_HIP(c, hipStreamWaitEvent(s, S.album_done, 0));
         S.album_pending = false;

@@ -637,14 +637,41 @@ struct Mp3Pipe {
     static constexpr int NSTAGE = 3;
     Mp3Stage stage[NSTAGE];
     std::vector<Mp3Scratch> scratch;  // one per loader thread
+    std::vector<hipEvent_t> part_ev;  // album parts: per chunk [2k] its decode is done, [2k + 1] its frame counts are on the host
     ~Mp3Pipe() {
         for (Mp3Stage &st : stage) {
             if (st.p) (void)hipHostFree(st.p);
             if (st.staged) (void)hipEventDestroy(st.staged);
         }
         for (Mp3Scratch &sc : scratch) free(sc.p);
+        for (hipEvent_t e : part_ev) (void)hipEventDestroy(e);
     }
 };
+// Album parts.  The decode of an album's files is a pipeline of chunks (below); with `PartsRun` the tracks of chunk k are
+// analysed -- one enqueue on a pipeline stream that waits for the chunk's decode, album mode -- while chunk k + 1 is copied and
+// decoded, instead of all together at the end: where the H2D copy is the longest stage (anything from 128 kb/s up) the analysis
+// disappears behind it, and elsewhere it fills the decode kernels' tails.  Each part leaves its [histogram | peak] pack in
+// c->d_album_packs and its per-track results in c->h_part_results; u32 adds commute, so the album is the fold of the packs
+// (the streamed host ingest and albums larger than the device do the same).  Anything out of the ordinary -- a file that is not
+// an MPEG stream or failed, an unsupported rate, a track the fast kernels flag -- drops the parts and the album is analysed the
+// plain way from the PCM, which is in the arena either way.
+constexpr size_t kMaxParts = 64;
+struct PartsRun {
+    int album = 1;  // 0: track mode (rg_analyze_tracks) -- the same parts without the packs
+    bool broken = false;
+    size_t n_parts = 0;
+    std::vector<size_t> file_of;  // position in c->h_part_results -> file of the call
+    std::vector<size_t> pending;  // files of decoded chunks not yet in a part (chunks the device, not the copy, was the longer stage of)
+};
+// A chunk whose H2D copy takes longer than its decode leaves the device idle: its tracks (and what is pending) become a part
+// right away.  Where the decode is the longer stage a part only splits the analysis into smaller, less efficient launches
+// (measured: 256 VBR files 20.6 -> 21.6 ms, 256 files of 320 kb/s 50.7 -> 38.4 ms), so such chunks wait -- for a later chunk
+// that is copy-bound, or for the end of the album, where an album without a single part goes the plain way.
+// Copy: ~50 GB/s; decode: ~0.5 ms per 256 K units = 1.9 ns per unit = 95 bytes' worth of copy.
+double parts_min_bytes_per_unit() {  // (read per call: tests flip it)
+    const char *e = getenv("RG_PARTS_MIN_BYTES_PER_UNIT");
+    return e ? atof(e) : 95.0;
+}
 Mp3Pipe &mp3_pipe(rg_ctx *c) {
     if (!c->mp3_pipe) {
         c->mp3_pipe = new Mp3Pipe();
@@ -716,8 +743,41 @@ bool read_whole_file(const char *path, Mp3Scratch *sc, size_t *len) {
 // Loads `paths` into `out` (entry i <- file i) with the pipeline: MPEG streams are on their way through the device when
 // this returns and their PCM sits in c->d_arena (LoadedAudio::staged), other inputs are loaded as load_audio_for loads
 // them.  rcs / errs: per-file outcome.
+// What one file of a list comes to before any analysis, in the order the reference meets its errors
+// (src/replaygain.rs:804-873): open / read, track selection, probe, sample rate.  RG_OK, or the code with `msg` set.
+int file_outcome(const LoadedAudio &la, int load_rc, const std::string &load_err, const char *path, int32_t track_index,
+                        std::string *msg) {
+    if (load_rc != RG_OK) {
+        *msg = load_err;
+        return load_rc;
+    }
+    if (track_index >= 0 && (uint32_t)track_index >= la.n_audio_tracks) {
+        char m[128];
+        snprintf(m, sizeof m, "Track index %d out of range (file has %u audio track(s))", track_index, la.n_audio_tracks);
+        *msg = m;
+        return RG_ERR_INVALID_ARG;
+    }
+    uint32_t rate = la.sample_rate;
+    if (!la.decoded && !la.split && !la.staged) {
+        rg_wav_info wi;
+        rate = rg_wav_parse(la.wav.data(), la.wav.size(), &wi) == RG_OK ? wi.sample_rate : 0;
+        if (rate == 0) {
+            *msg = std::string("Failed to probe format: ") + path;
+            return RG_ERR_FORMAT;
+        }
+    }
+    if (!rg_supported_rate(rate)) {
+        char m[256];
+        snprintf(m, sizeof m, "Unsupported sample rate: %u Hz. Supported rates: 96000, 88200, 64000, 48000, 44100, 32000, 24000, "
+                              "22050, 16000, 12000, 11025, 8000", rate);
+        *msg = m;
+        return RG_ERR_UNSUPPORTED_RATE;
+    }
+    return RG_OK;
+}
+
 int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedAudio> *out, std::vector<int> *rcs,
-                        std::vector<std::string> *errs) {
+                        std::vector<std::string> *errs, PartsRun *parts) {
     int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
     Mp3Pipe &P = mp3_pipe(c);
@@ -729,6 +789,18 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
     // earlier batches may still read the arena and the chunk buffers
     for (int s = 0; s < c->n_slots; ++s) RG_HIP(c, hipStreamSynchronize(c->slots[s].stream));
     hipStream_t fs = c->user_attached ? c->user_stream : c->slot().stream;
+    if (parts) {  // decode and parts share ONE pipeline stream (the caller has cut n_slots to 1): see PartsRun
+        fs = c->slots[0].stream;
+        RG_HIP(c, hipStreamSynchronize(fs));
+        if (P.part_ev.size() < 2 * kMaxParts) {
+            const size_t have = P.part_ev.size();
+            P.part_ev.resize(2 * kMaxParts, nullptr);
+            for (size_t k = have; k < P.part_ev.size(); ++k) RG_HIP(c, hipEventCreateWithFlags(&P.part_ev[k], hipEventDisableTiming));
+        }
+        RG_HIP(c, c->h_mp3_part_counts.reserve(n * kMaxParts));
+        RG_HIP(c, c->h_part_results.reserve(n));
+        if (parts->album) RG_HIP(c, c->d_album_packs.reserve(kMaxParts * (size_t)RG_ALBUM_PACK_WORDS));
+    }
     rc = rg_mp3dev_reserve_results(c, n, fs);
     if (rc != RG_OK) return rc;
 
@@ -934,12 +1006,72 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         }
         Mp3Stage &st = P.stage[ch.stage];
         const size_t tracks_off = (ch.used + 7) & ~(size_t)7;
-        return rg_mp3dev_enqueue_chunk(c, (int)(index & 1), st.p, tracks_off + rg_mp3dev_track_bytes(items.size()), tracks_off, st.staged,
-                                       items.data(), items.size(), fs);
+        if (parts && index >= kMaxParts) parts->broken = true;
+        const bool part = parts && !parts->broken;
+        r = rg_mp3dev_enqueue_chunk(c, (int)(index & 1), st.p, tracks_off + rg_mp3dev_track_bytes(items.size()), tracks_off, st.staged,
+                                    items.data(), items.size(), fs, part ? c->h_mp3_part_counts.p + index * n : nullptr, n,
+                                    part ? P.part_ev[2 * index + 1] : nullptr);
+        if (r == RG_OK && part) RG_HIP(c, hipEventRecord(P.part_ev[2 * index], fs));
+        return r;
+    };
+    // the tracks of chunk `index` (decode enqueued, the chunk after it too) as one part of the album
+    const double copy_bound_at = parts ? parts_min_bytes_per_unit() : 0.0;
+    // `ch` (may be null: nothing new) joins what is pending; `index`: the newest chunk whose files are pending or were
+    auto analyze_part = [&](const PipeChunk *ch, size_t index, bool last) -> int {
+        if (!parts || parts->broken) return RG_OK;
+        bool copy_bound = false;
+        if (ch) {
+            parts->pending.insert(parts->pending.end(), ch->files.begin(), ch->files.end());
+            copy_bound = ch->units && (double)ch->used / (double)ch->units >= copy_bound_at;
+        }
+        if (!copy_bound && !(last && parts->n_parts)) {
+            if (last) parts->broken = true;  // no chunk of the album was copy-bound: the plain route, one launch over all of it
+            return RG_OK;
+        }
+        if (parts->pending.empty()) return RG_OK;
+        std::vector<size_t> files;
+        files.swap(parts->pending);
+        RG_HIP(c, hipEventSynchronize(P.part_ev[2 * index + 1]));  // the frame parser ran at the head of the chunk's work: long done
+        const uint32_t *counts = c->h_mp3_part_counts.p + index * n;  // (the counts of every earlier chunk are in this copy as well)
+        std::vector<rg_track_desc> descs(files.size());
+        for (size_t k = 0; k < files.size(); ++k) {
+            const size_t i = files[k];
+            LoadedAudio &la = (*out)[i];
+            std::string msg;
+            if (!la.staged || file_outcome(la, (*rcs)[i], (*errs)[i], paths[i], track_index, &msg) != RG_OK) {
+                parts->broken = true;  // the plain route reports it, in input order
+                return RG_OK;
+            }
+            rg_track_desc &d = descs[k];
+            d = rg_track_desc{};
+            d.offset_bytes = la.arena_off;
+            d.frames = (uint64_t)counts[la.result_index] * 576;
+            d.sample_rate = la.sample_rate;
+            d.channels = (uint16_t)la.channels;
+            d.format = RG_FMT_F32_PLANAR;
+        }
+        c->enqueue_wait_ev = P.part_ev[2 * index];
+        const int r = rg_enqueue_impl(c, descs.data(), descs.size(), c->d_arena.p, arena_used, parts->album);
+        c->enqueue_wait_ev = nullptr;
+        if (r != RG_OK) {
+            parts->broken = true;
+            return RG_OK;
+        }
+        RgSlot &S = c->slot();
+        if (parts->album)
+            RG_HIP(c, hipMemcpyAsync(c->d_album_packs.p + parts->n_parts * (size_t)RG_ALBUM_PACK_WORDS, S.d_album_hist.p,
+                                     (size_t)RG_ALBUM_PACK_WORDS * sizeof(uint32_t), hipMemcpyDeviceToDevice, S.stream));
+        RG_HIP(c, hipMemcpyAsync(c->h_part_results.p + parts->file_of.size(), S.d_results.p, descs.size() * sizeof(rg_track_result),
+                                 hipMemcpyDeviceToHost, S.stream));
+        parts->n_parts++;
+        parts->file_of.insert(parts->file_of.end(), files.begin(), files.end());
+        return RG_OK;
     };
     auto drive = [&]() -> int {
         int result = RG_OK;
         size_t next = 0;
+        const PipeChunk *prev = nullptr;  // issued, not yet analysed as a part
+        size_t prev_index = 0;
         std::unique_lock<std::mutex> lk(R.m);
         for (;;) {
             R.cv.wait(lk, [&] { return (next < R.chunks.size() && R.chunks[next].closed && R.chunks[next].pending == 0) || R.files_done == n; });
@@ -949,7 +1081,16 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
                     R.open = -1;
                     continue;
                 }
-                if (next >= R.chunks.size()) break;
+                if (next >= R.chunks.size()) {
+                    if (result == RG_OK && parts) {
+                        lk.unlock();
+                        const int r = analyze_part(prev, prev_index, true);
+                        lk.lock();
+                        if (r != RG_OK) result = r;
+                        prev = nullptr;
+                    }
+                    break;
+                }
                 continue;
             }
             PipeChunk &ch = R.chunks[next];
@@ -957,6 +1098,14 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
             lk.unlock();
             const double t_i = now();
             int r = (result == RG_OK && !ch.files.empty()) ? issue(ch, next) : RG_OK;
+            if (r == RG_OK && result == RG_OK && prev) {  // the device has this chunk's decode to go on with
+                r = analyze_part(prev, prev_index, false);
+                prev = nullptr;
+            }
+            if (r == RG_OK && result == RG_OK && !ch.files.empty()) {
+                prev = &ch;
+                prev_index = next;
+            }
             if (trace)
                 fprintf(stderr, "[pipeline] chunk %zu: %zu files, %.1f MB, %llu units, ready at %.1f ms (files done %zu), enqueue took %.2f ms\n", next,
                         ch.files.size(), ch.used / 1e6, (unsigned long long)ch.units, (t_i - t_start) * 1e3, done_now, (now() - t_i) * 1e3);
@@ -1001,7 +1150,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
 }
 
 int load_many(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedAudio> *out, std::vector<int> *rcs_out = nullptr,
-              std::vector<std::string> *errs_out = nullptr);
+              std::vector<std::string> *errs_out = nullptr, PartsRun *parts = nullptr);
 
 // `out` is entry 0 of the context's pool
 int load_one(rg_ctx *c, const char *path, std::vector<LoadedAudio> *pool) { return load_many(c, &path, 1, pool); }
@@ -1010,11 +1159,11 @@ int load_one(rg_ctx *c, const char *path, std::vector<LoadedAudio> *pool) { retu
 // about 200 s of stereo audio into PCM per second, the GPU analyses 8 million).  Errors keep the reference's order: the
 // first failing file in input order is the one reported (src/replaygain.rs:1055).
 int load_many(rg_ctx *c, const char *const *paths, size_t n, std::vector<LoadedAudio> *out, std::vector<int> *rcs_out,
-              std::vector<std::string> *errs_out) {
+              std::vector<std::string> *errs_out, PartsRun *parts) {
     std::vector<int> rcs(n, RG_OK);
     std::vector<std::string> errs(n);
     if (c->gpu_mp3_decode >= 3 && n) {
-        const int prc = load_many_pipelined(c, paths, n, out, &rcs, &errs);
+        const int prc = load_many_pipelined(c, paths, n, out, &rcs, &errs, parts);
         if (prc != RG_OK) return prc;
     } else {
         unsigned workers = c->loader_threads ? c->loader_threads : usable_cores();
@@ -1124,39 +1273,6 @@ static void file_groups(rg_ctx *c, const char *const *paths, size_t n, std::vect
     }
 }
 
-// What one file of a list comes to before any analysis, in the order the reference meets its errors
-// (src/replaygain.rs:804-873): open / read, track selection, probe, sample rate.  RG_OK, or the code with `msg` set.
-static int file_outcome(const LoadedAudio &la, int load_rc, const std::string &load_err, const char *path, int32_t track_index,
-                        std::string *msg) {
-    if (load_rc != RG_OK) {
-        *msg = load_err;
-        return load_rc;
-    }
-    if (track_index >= 0 && (uint32_t)track_index >= la.n_audio_tracks) {
-        char m[128];
-        snprintf(m, sizeof m, "Track index %d out of range (file has %u audio track(s))", track_index, la.n_audio_tracks);
-        *msg = m;
-        return RG_ERR_INVALID_ARG;
-    }
-    uint32_t rate = la.sample_rate;
-    if (!la.decoded && !la.split && !la.staged) {
-        rg_wav_info wi;
-        rate = rg_wav_parse(la.wav.data(), la.wav.size(), &wi) == RG_OK ? wi.sample_rate : 0;
-        if (rate == 0) {
-            *msg = std::string("Failed to probe format: ") + path;
-            return RG_ERR_FORMAT;
-        }
-    }
-    if (!rg_supported_rate(rate)) {
-        char m[256];
-        snprintf(m, sizeof m, "Unsupported sample rate: %u Hz. Supported rates: 96000, 88200, 64000, 48000, 44100, 32000, 24000, "
-                              "22050, 16000, 12000, 11025, 8000", rate);
-        *msg = m;
-        return RG_ERR_UNSUPPORTED_RATE;
-    }
-    return RG_OK;
-}
-
 // analyze_album_with_index (src/replaygain.rs:1044-1074) up to, not including, the album percentile: per-file results in
 // input order on the host, the album's [histogram | peak] pack ready on the device (rg_album_finish reads it out; on a
 // node with several GPUs rg_album_exchange comes first, rg_node.cpp).  The first failing file IN INPUT ORDER aborts
@@ -1184,9 +1300,20 @@ extern "C" int rg_analyze_album_begin(rg_ctx *c, const char *const *paths, size_
         const double t0 = now();
         std::vector<int> rcs;
         std::vector<std::string> errs;
+        // album parts (PartsRun): one album that fits the device, decoded by the loader pipeline, nobody else's stream involved
+        const char *parts_env = getenv("RG_ALBUM_PARTS");  // "0": never (tests, measurements)
+        const bool parts_on = !(parts_env && parts_env[0] == '0');
+        PartsRun parts;
+        const bool use_parts = parts_on && groups.size() <= 1 && cnt > 0 && c->gpu_mp3_decode >= 3 && !c->user_attached;
+        const int slots_before = c->n_slots;
+        if (use_parts) {
+            for (int k = 0; k < RG_SLOT_STREAMS; ++k) RG_HIP(c, hipStreamSynchronize(c->slots[k].stream));
+            c->n_slots = 1;  // every part on slot 0, whose stream the decode runs on as well
+        }
         c->file_track_index = track_index;
-        rc = load_many(c, paths + first, cnt, &in, &rcs, &errs);
+        rc = load_many(c, paths + first, cnt, &in, &rcs, &errs, use_parts ? &parts : nullptr);
         c->file_track_index = -1;
+        c->n_slots = slots_before;
         if (rc != RG_OK) return rc;  // not a file's failure: *failed_index stays (size_t)-1, so that a node prefers real file errors of other shares
         for (size_t i = 0; i < cnt; ++i) {
             std::string msg;
@@ -1194,6 +1321,23 @@ extern "C" int rg_analyze_album_begin(rg_ctx *c, const char *const *paths, size_
             if (frc != RG_OK) return fail_at(first + i, rg_set_err(c, frc, "%s", msg.c_str()));
         }
         const double t1 = now();
+        if (use_parts && !parts.broken && parts.file_of.size() == cnt) {
+            // every file was analysed as a part of its chunk: the results are on their way to the host, the packs are on the device
+            for (int k = 0; k < RG_SLOT_STREAMS; ++k) RG_HIP(c, hipStreamSynchronize(c->slots[k].stream));
+            bool flagged = false;
+            for (size_t j = 0; j < cnt; ++j) {
+                const rg_track_result &r = c->h_part_results.p[j];
+                flagged = flagged || (c->kernel_variant == 0 && (r.flags & RG_TRACK_FLAG_IMPRECISE));
+                tracks_out[first + parts.file_of[j]] = r;
+            }
+            if (!flagged) {  // (a flagged track: the plain route below repeats it on the order-faithful kernel)
+                rc = rg_album_parts_fold(c, parts.n_parts);
+                if (rc != RG_OK) return rc;
+                for (size_t i = 0; i < cnt; ++i) tracks_out[first + i].file_type = in[i].is_mp4 ? RG_FILE_AAC : RG_FILE_MP3;
+                if (trace) fprintf(stderr, "[rg_analyze_album] load + decode + analysis in %zu parts %.1f ms, results %.1f ms\n", parts.n_parts, (t1 - t0) * 1e3, (now() - t1) * 1e3);
+                return RG_OK;
+            }
+        }
         std::vector<rg_track_desc> descs;
         size_t arena_bytes = 0;
         rc = stage_loaded(c, in, cnt, &descs, &arena_bytes);
@@ -1232,10 +1376,36 @@ static int analyze_tracks_group(rg_ctx *c, const char *const *paths, size_t firs
     std::vector<LoadedAudio> &in = file_pool(c, n);
     std::vector<int> rcs;
     std::vector<std::string> errs;
+    // parts (PartsRun), track mode: every file of the group has to come through the loader pipeline for them to count
+    const char *parts_env = getenv("RG_ALBUM_PARTS");
+    PartsRun parts;
+    parts.album = 0;
+    const bool use_parts = !(parts_env && parts_env[0] == '0') && n > 0 && c->gpu_mp3_decode >= 3 && !c->user_attached;
+    const int slots_before = c->n_slots;
+    if (use_parts) {
+        for (int k = 0; k < RG_SLOT_STREAMS; ++k) RG_HIP(c, hipStreamSynchronize(c->slots[k].stream));
+        c->n_slots = 1;
+    }
     c->file_track_index = track_index;
-    int rc = load_many(c, paths, n, &in, &rcs, &errs);
+    int rc = load_many(c, paths, n, &in, &rcs, &errs, use_parts ? &parts : nullptr);
     c->file_track_index = -1;
+    c->n_slots = slots_before;
     if (rc != RG_OK) return rc;
+    if (use_parts && !parts.broken && parts.file_of.size() == n) {
+        for (int k = 0; k < RG_SLOT_STREAMS; ++k) RG_HIP(c, hipStreamSynchronize(c->slots[k].stream));
+        bool flagged = false;
+        for (size_t j = 0; j < n; ++j) flagged = flagged || (c->kernel_variant == 0 && (c->h_part_results.p[j].flags & RG_TRACK_FLAG_IMPRECISE));
+        if (!flagged) {  // (else: the plain route below, which repeats flagged tracks on the order-faithful kernel)
+            for (size_t j = 0; j < n; ++j) {
+                const size_t i = parts.file_of[j];
+                out[i] = c->h_part_results.p[j];
+                out[i].file_type = in[i].is_mp4 ? RG_FILE_AAC : RG_FILE_MP3;
+                status_out[i] = RG_OK;
+                c->file_errors[first + i].clear();
+            }
+            return RG_OK;
+        }
+    }
     // the batch holds the files that loaded and whose rate the analysis knows; `slot` maps them back
     std::vector<size_t> slot;
     for (size_t i = 0; i < n; ++i) {

@@ -42,9 +42,11 @@ struct RgMp3StreamItem {
 size_t rg_mp3dev_track_bytes(size_t n_items);
 // One chunk: H2D of staging[0, bytes) on the context's copy stream into device set `set` (0 / 1), then frame parser,
 // Huffman and back-half kernels on `s`.  `staged` is recorded on the copy stream behind the H2D: the staging block
-// may be refilled once it has completed.  Nothing is synchronised.
+// may be refilled once it has completed.  Nothing is synchronised.  `counts_out` (pinned, n_counts words; may be null): a copy
+// of the per-file granule counts as they stand behind this chunk's frame parser, `counts_ev` recorded behind it.
 int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, size_t tracks_off, hipEvent_t staged,
-                            const RgMp3StreamItem *items, size_t n, hipStream_t s);
+                            const RgMp3StreamItem *items, size_t n, hipStream_t s, uint32_t *counts_out = nullptr, size_t n_counts = 0,
+                            hipEvent_t counts_ev = nullptr);
 // granules decoded per result_index: rg_mp3dev_fetch_results enqueues the D2H on `s`; read after synchronising `s`
 int rg_mp3dev_reserve_results(rg_ctx *c, size_t n, hipStream_t s);  // zeroed on `s`, which the chunks' kernels must follow
 int rg_mp3dev_fetch_results(rg_ctx *c, size_t n, hipStream_t s);

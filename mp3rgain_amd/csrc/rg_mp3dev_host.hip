@@ -169,7 +169,7 @@ int rg_mp3dev_fetch_results(rg_ctx *c, size_t n, hipStream_t s) {
 const uint32_t *rg_mp3dev_results(rg_ctx *c) { return c->h_mp3_results.p; }
 
 int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, size_t tracks_off, hipEvent_t staged,
-                            const RgMp3StreamItem *items, size_t n, hipStream_t s) {
+                            const RgMp3StreamItem *items, size_t n, hipStream_t s, uint32_t *counts_out, size_t n_counts, hipEvent_t counts_ev) {
     int rc = rg_bind_device(c);
     if (rc != RG_OK) return rc;
     rc = ensure_tables(c);
@@ -233,6 +233,10 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
     if (ub && !ev) {
         RG_HIP(c, rg_launch_mp3_frames(d_tr, (uint32_t)n, tb, d_chunk, c->d_mp3_tiles_set[set].p, d_recs, c->d_mp3_results.p, cs));
         RG_HIP(c, rg_launch_mp3_sort(d_tr, (uint32_t)n, d_recs, ub, c->d_mp3_sortw_set[set].p, c->d_mp3_perm_set[set].p, cs));
+    }
+    if (counts_out && !ev) {  // (the counts of every stream parsed so far: the frame parser runs on this stream, chunk after chunk)
+        RG_HIP(c, hipMemcpyAsync(counts_out, c->d_mp3_results.p, n_counts * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+        RG_HIP(c, hipEventRecord(counts_ev, cs));
     }
     RG_HIP(c, hipEventRecord(staged, cs));
     RG_HIP(c, hipStreamWaitEvent(s, staged, 0));

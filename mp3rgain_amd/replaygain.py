@@ -289,14 +289,18 @@ class Analyzer:
         return AlbumGainResult([_to_result(out[i], out[i].file_type) for i in range(n)], alb.album_loudness_db,
                                alb.album_gain_db, alb.album_peak)
 
-    def analyze_track_files(self, files, track_index: Optional[int] = None) -> list:
+    def analyze_track_files(self, files, track_index: Optional[int] = None, timing: Optional[dict] = None) -> list:
         """analyze_track for every file, as ONE GPU batch (files loaded on all host cores).  -> per file a
-        ReplayGainResult, or the ReplayGainError analyze_track_file would have raised for it."""
+        ReplayGainResult, or the ReplayGainError analyze_track_file would have raised for it.  `timing`: as analyze_album_files."""
         n = len(files)
         paths = (C.c_char_p * max(1, n))(*[os.fsencode(os.fspath(f)) for f in files])
         out = (_capi.TrackResult * max(1, n))()
         status = (C.c_int32 * max(1, n))()
-        self._check(self._lib.rg_analyze_tracks(self._ctx, paths, n, -1 if track_index is None else int(track_index), out, status))
+        t0 = time.perf_counter()
+        rc = self._lib.rg_analyze_tracks(self._ctx, paths, n, -1 if track_index is None else int(track_index), out, status)
+        if timing is not None:
+            timing["c_call_seconds"] = time.perf_counter() - t0
+        self._check(rc)
         res = []
         for i in range(n):
             if status[i] == 0:

@@ -374,6 +374,67 @@ def test_loader_pipeline_with_tiny_staging_blocks(oracle, tmp_path, monkeypatch)
         assert (a.loudness_db, a.peak) == (ref["loudness_db"], ref["peak"]), f.name
 
 
+def test_album_parts_give_the_plain_route_results(tmp_path, monkeypatch):
+    """Album parts (rg_files.hip: PartsRun): the tracks of a decoded chunk are analysed while later chunks are copied and decoded,
+    and the album is the fold of the parts' packs.  With tiny staging blocks (dozens of chunks) and every chunk made a part, only
+    copy-bound chunks (the default rule: the rest waits and joins a later part), and no parts at all, an album of 45 files --
+    mono and stereo, 8 to 48 kHz, one file longer than a block -- must come out the same, field by field; a WAV file among
+    them (not the pipeline's) sends the whole album down the plain route."""
+    import mp3rgain_amd as rg
+    import wave
+
+    monkeypatch.setenv("RG_MP3_STAGE_BYTES", "65536")
+    srcs = [p for p in STREAMS if p.stat().st_size < 60000]
+    big = (GOLD / "v1_44k_ms_mixed.mp3").read_bytes()
+    one = mp3dec.scan(big)
+    files = []
+    for k in range(44):
+        f = tmp_path / f"p{k:02d}.mp3"
+        f.write_bytes(srcs[(5 * k) % len(srcs)].read_bytes())
+        files.append(f)
+    long_file = tmp_path / "long.mp3"
+    long_file.write_bytes(big * (int(25 * one.sample_rate / one.frames) + 1))
+    files.insert(9, long_file)
+    wav = tmp_path / "tone.wav"
+    with wave.open(str(wav), "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(44100)
+        t = np.arange(44100 * 2)
+        x = (8000 * np.sin(2 * np.pi * 997 * t / 44100)).astype("<i2")
+        w.writeframes(np.stack([x, x], axis=1).tobytes())
+
+    def key(r):
+        return [(t.loudness_db, t.gain_db, t.peak, t.sample_rate, t.windows, t.file_type) for t in r.tracks] + [(r.album_loudness_db, r.album_gain_db, r.album_peak)]
+
+    with rg.Analyzer(0) as an:
+        an.set_kernel(0)
+        monkeypatch.setenv("RG_ALBUM_PARTS", "0")
+        plain = key(an.analyze_album_files(files))
+        plain_wav = key(an.analyze_album_files(files[:20] + [wav] + files[20:]))
+        monkeypatch.setenv("RG_ALBUM_PARTS", "1")
+        for rule in ("0", "95", "400", "1e9"):
+            monkeypatch.setenv("RG_PARTS_MIN_BYTES_PER_UNIT", rule)
+            assert key(an.analyze_album_files(files)) == plain, rule
+            assert key(an.analyze_album_files(files)) == plain, rule  # (buffers in place now)
+        monkeypatch.setenv("RG_PARTS_MIN_BYTES_PER_UNIT", "0")
+        assert key(an.analyze_album_files(files[:20] + [wav] + files[20:])) == plain_wav
+        assert key(an.analyze_album_files(files[:1])) == key(an.analyze_album_files(files[:1]))
+        with pytest.raises(rg.ReplayGainError):
+            an.analyze_album_files(files[:7] + [tmp_path / "missing.mp3"] + files[7:])
+        assert key(an.analyze_album_files(files)) == plain  # and the context is fine afterwards
+        # track mode (rg_analyze_tracks): the same parts without the album packs; a missing file is that file's error only
+        def tkey(rs):
+            return [(r.code, str(r)) if isinstance(r, rg.ReplayGainError) else (r.loudness_db, r.gain_db, r.peak, r.sample_rate, r.windows, r.file_type) for r in rs]
+        with_missing = files[:7] + [tmp_path / "missing.mp3"] + files[7:]
+        monkeypatch.setenv("RG_ALBUM_PARTS", "0")
+        t_plain, t_plain_missing = tkey(an.analyze_track_files(files)), tkey(an.analyze_track_files(with_missing))
+        assert t_plain == [k for k in plain[:-1]]
+        monkeypatch.setenv("RG_ALBUM_PARTS", "1")
+        for rule in ("0", "95", "1e9"):
+            monkeypatch.setenv("RG_PARTS_MIN_BYTES_PER_UNIT", rule)
+            assert tkey(an.analyze_track_files(files)) == t_plain, rule
+            assert tkey(an.analyze_track_files(with_missing)) == t_plain_missing, rule
+
+
 def test_analyze_tracks_in_groups_bounded_by_memory(_ctx, tmp_path, monkeypatch):
     """`-r` over a whole library is taken in groups whose PCM fits the device (rg_analyze_tracks): with the group size forced
     down to a few files, results and per-file errors are those of the single batch."""

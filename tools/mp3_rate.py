@@ -25,7 +25,10 @@ nfiles = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 minutes = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
 an = rg.Analyzer(0)
 for label, src in (("dense 320k synthetic", ROOT / "tests/golden/mp3/v1_44k_stereo_long.mp3"),
+                   ("dense 128k joint stereo, music-like", ROOT / "tests/golden/mp3/dense_44k_joint_128.mp3"),
                    ("VBR fixture (440 Hz sine)", ROOT / "tests/golden/fixtures/test_vbr.mp3")):
+    if os.environ.get("MP3_RATE_STREAM") and os.environ["MP3_RATE_STREAM"] not in label:
+        continue
     data = src.read_bytes()
     info = mp3dec.scan(data)
     body = data[int(info.first_frame_offset):]
@@ -73,3 +76,9 @@ for label, src in (("dense 320k synthetic", ROOT / "tests/golden/mp3/v1_44k_ster
               f"{nfiles * si.frames / dt / 1e6:8.1f} M stereo samples/s, album loudness {res.album_loudness_db:.2f} dB"
               f"   (+ {1e3 * (dt_py - dt):.2f} ms in the Python wrapper)")
     an.set_tuning(6, 3)
+    for _ in range(2):  # track mode (rg_analyze_tracks: `-r` over many files), default route
+        tm = {}
+        an.analyze_track_files(files, timing=tm)
+    dt = tm["c_call_seconds"]
+    print(f"   rg_analyze_tracks, device: host strips headers, piped: {dt:8.4f} s = {nfiles * audio_s / dt:9.0f}x real time, "
+          f"{nfiles * si.frames / dt / 1e6:8.1f} M stereo samples/s")
