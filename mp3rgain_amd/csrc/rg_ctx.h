@@ -168,6 +168,7 @@ struct rg_ctx {
     // album parts): the batch enqueued next waits for `enqueue_wait_ev` (the chunk's decode) on its own stream; per chunk a copy
     // of the frame parser's counts, and every part's per-track results, land in pinned memory without a host synchronise
     hipEvent_t enqueue_wait_ev = nullptr;
+    hipStream_t enqueue_stream = nullptr;    // the next enqueue's launches go here instead of its slot's stream (the slot's BUFFERS are used)
     PinnedBuf<uint32_t> h_mp3_part_counts;
     PinnedBuf<rg_track_result> h_part_results;
     hipEvent_t *mp3_bench_ev = nullptr;      // rg_mp3_decode_bench: four events recorded around the three decode stages of a chunk

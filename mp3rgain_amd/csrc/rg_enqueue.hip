@@ -378,7 +378,7 @@ int rg_enqueue_impl(rg_ctx *c, const rg_track_desc *tracks, size_t n, const void
     // next pipeline slot: its stream orders this batch behind the batch that used the slot before
     c->cur = (c->cur + 1) % c->n_slots;
     RgSlot &S = c->slot();
-    hipStream_t s = S.stream;
+    hipStream_t s = c->enqueue_stream ? c->enqueue_stream : S.stream;
     if (c->user_dirty) {  // inputs produced on the caller's stream (or by rg_synth_fill_device) must be complete first
         if (c->user_attached) RG_HIP(c, hipEventRecord(c->user_ev, c->user_stream));
         for (int k = 0; k < RG_MAX_SLOTS; ++k) RG_HIP(c, hipStreamWaitEvent(c->slots[k].stream, c->user_ev, 0));

@@ -667,10 +667,12 @@ struct PartsRun {
 // right away.  Where the decode is the longer stage a part only splits the analysis into smaller, less efficient launches
 // (measured: 256 VBR files 20.6 -> 21.6 ms, 256 files of 320 kb/s 50.7 -> 38.4 ms), so such chunks wait -- for a later chunk
 // that is copy-bound, or for the end of the album, where an album without a single part goes the plain way.
-// Copy: ~50 GB/s; decode: ~0.5 ms per 256 K units = 1.9 ns per unit = 95 bytes' worth of copy.
+// Copy: ~50 GB/s; decode: ~0.5 ms per 256 K units = 1.9 ns per unit = 95 bytes' worth of copy.  At 104 bytes per unit (128 kb/s
+// stereo) the two routes measure the same within their noise (album 24.9 -> 23.4 ms, track mode 21.6 -> 22.5), so the line is
+// drawn at 120: 160 kb/s and up.
 double parts_min_bytes_per_unit() {  // (read per call: tests flip it)
     const char *e = getenv("RG_PARTS_MIN_BYTES_PER_UNIT");
-    return e ? atof(e) : 95.0;
+    return e ? atof(e) : 120.0;
 }
 Mp3Pipe &mp3_pipe(rg_ctx *c) {
     if (!c->mp3_pipe) {
@@ -788,9 +790,11 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         if (!st.staged) RG_HIP(c, hipEventCreateWithFlags(&st.staged, hipEventDisableTiming));
     // earlier batches may still read the arena and the chunk buffers
     for (int s = 0; s < c->n_slots; ++s) RG_HIP(c, hipStreamSynchronize(c->slots[s].stream));
-    hipStream_t fs = c->user_attached ? c->user_stream : c->slot().stream;
-    if (parts) {  // decode and parts share ONE pipeline stream (the caller has cut n_slots to 1): see PartsRun
-        fs = c->slots[0].stream;
+    // The decode runs on the FIRST pipeline stream, whichever slot the last batch used: the runtime maps streams onto four
+    // hardware queues and this context has five streams once the copy stream exists -- with the decode on "the current slot's
+    // stream" every fourth call landed on the queue the copy stream shares and took 25 instead of 20 ms (tools/seq_album.py).
+    hipStream_t fs = c->user_attached ? c->user_stream : c->slots[0].stream;
+    if (parts) {  // decode and parts share that stream: see PartsRun
         RG_HIP(c, hipStreamSynchronize(fs));
         if (P.part_ev.size() < 2 * kMaxParts) {
             const size_t have = P.part_ev.size();
@@ -1050,8 +1054,15 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
             d.channels = (uint16_t)la.channels;
             d.format = RG_FMT_F32_PLANAR;
         }
+        // on the decode's stream (behind the decode of the chunk after this part's), with the buffers of the next pipeline slot:
+        // one batch in flight at a time (cost model: one_shot), and no slot's pinned descriptors are waited for
         c->enqueue_wait_ev = P.part_ev[2 * index];
+        c->enqueue_stream = fs;
+        const bool one_shot_before = c->one_shot;
+        c->one_shot = true;
         const int r = rg_enqueue_impl(c, descs.data(), descs.size(), c->d_arena.p, arena_used, parts->album);
+        c->one_shot = one_shot_before;
+        c->enqueue_stream = nullptr;
         c->enqueue_wait_ev = nullptr;
         if (r != RG_OK) {
             parts->broken = true;
@@ -1060,9 +1071,9 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         RgSlot &S = c->slot();
         if (parts->album)
             RG_HIP(c, hipMemcpyAsync(c->d_album_packs.p + parts->n_parts * (size_t)RG_ALBUM_PACK_WORDS, S.d_album_hist.p,
-                                     (size_t)RG_ALBUM_PACK_WORDS * sizeof(uint32_t), hipMemcpyDeviceToDevice, S.stream));
+                                     (size_t)RG_ALBUM_PACK_WORDS * sizeof(uint32_t), hipMemcpyDeviceToDevice, fs));
         RG_HIP(c, hipMemcpyAsync(c->h_part_results.p + parts->file_of.size(), S.d_results.p, descs.size() * sizeof(rg_track_result),
-                                 hipMemcpyDeviceToHost, S.stream));
+                                 hipMemcpyDeviceToHost, fs));
         parts->n_parts++;
         parts->file_of.insert(parts->file_of.end(), files.begin(), files.end());
         return RG_OK;
@@ -1305,15 +1316,11 @@ extern "C" int rg_analyze_album_begin(rg_ctx *c, const char *const *paths, size_
         const bool parts_on = !(parts_env && parts_env[0] == '0');
         PartsRun parts;
         const bool use_parts = parts_on && groups.size() <= 1 && cnt > 0 && c->gpu_mp3_decode >= 3 && !c->user_attached;
-        const int slots_before = c->n_slots;
-        if (use_parts) {
+        if (use_parts)  // the parts use every slot's buffers on the decode's stream: nothing of an earlier batch may be in flight
             for (int k = 0; k < RG_SLOT_STREAMS; ++k) RG_HIP(c, hipStreamSynchronize(c->slots[k].stream));
-            c->n_slots = 1;  // every part on slot 0, whose stream the decode runs on as well
-        }
         c->file_track_index = track_index;
         rc = load_many(c, paths + first, cnt, &in, &rcs, &errs, use_parts ? &parts : nullptr);
         c->file_track_index = -1;
-        c->n_slots = slots_before;
         if (rc != RG_OK) return rc;  // not a file's failure: *failed_index stays (size_t)-1, so that a node prefers real file errors of other shares
         for (size_t i = 0; i < cnt; ++i) {
             std::string msg;
@@ -1381,15 +1388,11 @@ static int analyze_tracks_group(rg_ctx *c, const char *const *paths, size_t firs
     PartsRun parts;
     parts.album = 0;
     const bool use_parts = !(parts_env && parts_env[0] == '0') && n > 0 && c->gpu_mp3_decode >= 3 && !c->user_attached;
-    const int slots_before = c->n_slots;
-    if (use_parts) {
+    if (use_parts)
         for (int k = 0; k < RG_SLOT_STREAMS; ++k) RG_HIP(c, hipStreamSynchronize(c->slots[k].stream));
-        c->n_slots = 1;
-    }
     c->file_track_index = track_index;
     int rc = load_many(c, paths, n, &in, &rcs, &errs, use_parts ? &parts : nullptr);
     c->file_track_index = -1;
-    c->n_slots = slots_before;
     if (rc != RG_OK) return rc;
     if (use_parts && !parts.broken && parts.file_of.size() == n) {
         for (int k = 0; k < RG_SLOT_STREAMS; ++k) RG_HIP(c, hipStreamSynchronize(c->slots[k].stream));

@@ -411,7 +411,7 @@ def test_album_parts_give_the_plain_route_results(tmp_path, monkeypatch):
         plain = key(an.analyze_album_files(files))
         plain_wav = key(an.analyze_album_files(files[:20] + [wav] + files[20:]))
         monkeypatch.setenv("RG_ALBUM_PARTS", "1")
-        for rule in ("0", "95", "400", "1e9"):
+        for rule in ("0", "120", "400", "1e9"):
             monkeypatch.setenv("RG_PARTS_MIN_BYTES_PER_UNIT", rule)
             assert key(an.analyze_album_files(files)) == plain, rule
             assert key(an.analyze_album_files(files)) == plain, rule  # (buffers in place now)
@@ -429,7 +429,7 @@ def test_album_parts_give_the_plain_route_results(tmp_path, monkeypatch):
         t_plain, t_plain_missing = tkey(an.analyze_track_files(files)), tkey(an.analyze_track_files(with_missing))
         assert t_plain == [k for k in plain[:-1]]
         monkeypatch.setenv("RG_ALBUM_PARTS", "1")
-        for rule in ("0", "95", "1e9"):
+        for rule in ("0", "120", "1e9"):
             monkeypatch.setenv("RG_PARTS_MIN_BYTES_PER_UNIT", rule)
             assert tkey(an.analyze_track_files(files)) == t_plain, rule
             assert tkey(an.analyze_track_files(with_missing)) == t_plain_missing, rule
