@@ -275,7 +275,6 @@ extern "C" void rg_destroy(rg_ctx *c) {
     c->h_mp3_results.release();
     c->h_mp3_part_counts.release();
     c->h_part_results.release();
-    if (c->mp3_copy_stream) (void)hipStreamDestroy(c->mp3_copy_stream);
     for (int k = 0; k < 2; ++k)
         if (c->mp3_set_free[k]) (void)hipEventDestroy(c->mp3_set_free[k]);
     c->d_ingest[0].release();

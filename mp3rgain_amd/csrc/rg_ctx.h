@@ -150,7 +150,7 @@ struct rg_ctx {
     bool mp3_tab_ready = false;
     // tuning key 6 = 3 (rg_mp3dev_enqueue_chunk): two device copies of staging blocks, the per-file results
     DevBuf<unsigned char> d_mp3_stage[2];
-    hipStream_t mp3_copy_stream = nullptr;   // H2D of staging blocks, beside the kernels of the chunk before
+    hipStream_t mp3_copy_stream = nullptr;   // H2D of staging blocks, beside the kernels of the chunk before: the second pipeline stream (not owned)
     hipEvent_t mp3_set_free[2] = {nullptr, nullptr};
     bool mp3_set_used[2] = {false, false};
     DevBuf<uint32_t> d_mp3_results;

@@ -790,9 +790,10 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         if (!st.staged) RG_HIP(c, hipEventCreateWithFlags(&st.staged, hipEventDisableTiming));
     // earlier batches may still read the arena and the chunk buffers
     for (int s = 0; s < c->n_slots; ++s) RG_HIP(c, hipStreamSynchronize(c->slots[s].stream));
-    // The decode runs on the FIRST pipeline stream, whichever slot the last batch used: the runtime maps streams onto four
-    // hardware queues and this context has five streams once the copy stream exists -- with the decode on "the current slot's
-    // stream" every fourth call landed on the queue the copy stream shares and took 25 instead of 20 ms (tools/seq_album.py).
+    // The decode runs on the FIRST pipeline stream, whichever slot the last batch used, and the copies on the second
+    // (rg_mp3dev_enqueue_chunk): the runtime maps streams onto four hardware queues, and with a fifth stream for the copies and
+    // the decode on "the current slot's stream" every fourth call landed on the queue the copy stream shared and took 25 instead
+    // of 20 ms (tools/seq_album.py).
     hipStream_t fs = c->user_attached ? c->user_stream : c->slots[0].stream;
     if (parts) {  // decode and parts share that stream: see PartsRun
         RG_HIP(c, hipStreamSynchronize(fs));
@@ -1546,7 +1547,7 @@ extern "C" int rg_mp3_decode_bench(rg_ctx *c, const void *data, size_t len, uint
         it.result_index = k;
         it.d_ch0 = reinterpret_cast<float *>(c->d_arena.p + per_stream * k);
     }
-    hipStream_t fs = c->slot().stream;
+    hipStream_t fs = c->slots[0].stream;  // as the file route: never the stream the copies run on (rg_mp3dev_enqueue_chunk)
     // one set of events per repetition: the repetitions are enqueued back to back (a synchronise after each would let the
     // clocks fall between them) and read out at the end
     if (reps > 256) reps = 256;
@@ -1649,7 +1650,7 @@ extern "C" int rg_mp3_decode_device(rg_ctx *c, const void *data, size_t len, flo
         it.lsf = out->mpeg_version == 1 ? 0u : 1u;
         it.result_index = 0;
         it.d_ch0 = reinterpret_cast<float *>(c->d_arena.p);
-        hipStream_t fs = c->slot().stream;
+        hipStream_t fs = c->slots[0].stream;
         rc = rg_mp3dev_reserve_results(c, 1, fs);
         if (rc != RG_OK) return rc;
         rc = rg_mp3dev_enqueue_chunk(c, 0, st.p, total, tracks_off, st.staged, &it, 1, fs);

@@ -174,7 +174,12 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
     if (rc != RG_OK) return rc;
     rc = ensure_tables(c);
     if (rc != RG_OK) return rc;
-    if (!c->mp3_copy_stream) RG_HIP(c, hipStreamCreateWithFlags(&c->mp3_copy_stream, hipStreamNonBlocking));
+    // The copies (and the frame parser and lane sort behind them) run on the SECOND pipeline stream, the decode on the first (the
+    // callers pass it): the context's four pipeline streams are the runtime's four hardware queues, a fifth stream would share
+    // one of them -- with whichever stream happens to sit there (rg_files.hip).  Nothing else is in flight on the pipeline
+    // streams while files are loaded; what the caller enqueues afterwards on this stream is ordered behind the copies.
+    c->mp3_copy_stream = c->slots[1].stream;
+    if (s == c->mp3_copy_stream) return rg_set_err(c, RG_ERR_STATE, "the MP3 decode may not run on the copies' stream");
     for (int k = 0; k < 2; ++k)
         if (!c->mp3_set_free[k]) RG_HIP(c, hipEventCreateWithFlags(&c->mp3_set_free[k], hipEventDisableTiming));
     // the descriptors are written into the staging block itself: check that they fit BEFORE writing them
