@@ -10,7 +10,7 @@ import mp3rgain_amd as rg
 from mp3rgain_amd import mp3dec
 calls = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 an = rg.Analyzer(0)
-for label, src in (("128k", "tests/golden/mp3/dense_44k_joint_128.mp3"), ("vbr", "tests/golden/fixtures/test_vbr.mp3")):
+for label, src in (("128k", "tests/golden/mp3/dense_44k_joint_128.mp3"), ("vbr", "tests/golden/fixtures/test_vbr.mp3"), ("320k", "tests/golden/mp3/v1_44k_stereo_long.mp3")):
     data = (ROOT / src).read_bytes()
     info = mp3dec.scan(data)
     body = data[int(info.first_frame_offset):]
@@ -18,7 +18,7 @@ for label, src in (("128k", "tests/golden/mp3/dense_44k_joint_128.mp3"), ("vbr",
     stream = body * max(1, int(180 / (one.frames / one.sample_rate)))
     tmp = Path(tempfile.mkdtemp())
     files = []
-    for k in range(256):
+    for k in range(int(os.environ.get("NFILES", "256"))):
         p = tmp / f"t{k:04d}.mp3"; p.write_bytes(stream); files.append(p)
     for mode in ("album", "tracks"):
         f = an.analyze_album_files if mode == "album" else an.analyze_track_files
