@@ -199,6 +199,49 @@ def mp3_end_to_end(an, nfiles: int) -> dict:
         tmp.rmdir()
     loud = {r["album_loudness_db"] for r in leg["routes"].values()}
     leg["routes_agree"] = len(loud) == 1
+    # ---- the same call on the two other kinds of stream the round's end-to-end claims are made on (default route only): an
+    # encoder-made 128 kb/s joint-stereo stream and the reference's own VBR fixture, both repeated to three minutes.  The
+    # 320 kb/s album above is bound by the host-to-device copy of its compressed bytes; these two are not.  Album loudness
+    # is checked against the host decoder's route on 8 of the files (all files of a stream are equal, so the album's
+    # percentile does not depend on how many there are).
+    leg["streams"] = {}
+    for label, src in (("vbr_fixture", ROOT / "tests" / "golden" / "fixtures" / "test_vbr.mp3"),
+                       ("dense128_joint", ROOT / "tests" / "golden" / "mp3" / "dense_44k_joint_128.mp3")):
+        try:
+            data = src.read_bytes()
+            body2 = data[int(mp3dec.scan(data).first_frame_offset):]
+            one2 = mp3dec.scan(body2)
+            stream2 = body2 * max(1, int(180.0 / (one2.frames / one2.sample_rate)))
+            si2 = mp3dec.scan(stream2)
+            tmp2 = Path(tempfile.mkdtemp(prefix="rg_bench_mp3_"))
+            files2 = []
+            for k in range(nfiles):
+                p2 = tmp2 / f"t{k:04d}.mp3"
+                p2.write_bytes(stream2)
+                files2.append(p2)
+            try:
+                for _ in range(3):
+                    an.analyze_album_files(files2)
+                dt2, res2 = 1e9, None
+                for _ in range(3):
+                    tm = {}
+                    res2 = an.analyze_album_files(files2, timing=tm)
+                    dt2 = min(dt2, tm["c_call_seconds"])
+                an.set_tuning(6, 0)
+                host = an.analyze_album_files(files2[:min(nfiles, 8)])
+                an.set_tuning(6, 3)
+                leg["streams"][label] = {
+                    "files": nfiles, "seconds": dt2, "value": nfiles * si2.frames / dt2, "x_real_time": nfiles * si2.frames / si2.sample_rate / dt2,
+                    "bytes_per_file": len(stream2), "kbps": len(stream2) * 8 / (si2.frames / si2.sample_rate) / 1e3,
+                    "album_loudness_db": res2.album_loudness_db, "album_loudness_db_host_decoder_route": host.album_loudness_db,
+                    "agrees_with_host_decoder_route": res2.album_loudness_db == host.album_loudness_db}
+            finally:
+                an.set_tuning(6, 3)
+                for p2 in files2:
+                    p2.unlink()
+                tmp2.rmdir()
+        except Exception as ex:  # noqa: BLE001
+            leg["streams"][label] = {"error": str(ex)}
     # ---- how many of these decoded tracks does the fast kernel flag (RG_TRACK_FLAG_IMPRECISE), and what does the exact
     # repeat of the synchronous entry points cost then?  The file-level calls above return the repeated (exact) results, whose
     # flag is gone; here the decoded PCM of one file, 16 copies, goes through the asynchronous pair (hands the flag over)

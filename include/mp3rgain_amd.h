@@ -188,7 +188,13 @@ int rg_set_kernel(rg_ctx *ctx, int variant);
  * the host's cores, the rest on the GPU; 0 = the host decoder.  (An album of 64 three-minute 320 kb/s files:
  * 0.96 s / 0.25 s / 0.04 s / 0.017 s for 0 / 1 / 2 / 3.),
  * key 7 = host threads the file-level entry points load files with (0 = every core this process may use; a node of
- * several contexts gives each its share, mp3rgain_amd_node.h).
+ * several contexts gives each its share, mp3rgain_amd_node.h),
+ * keys 10-13 = routing of the file-level entry points, per context (their defaults come from the environment as it was when
+ * the context was created -- RG_ALBUM_PARTS, RG_PARTS_MIN_BYTES_PER_UNIT, RG_MP3_STAGE_BYTES, RG_TRACKS_GROUP_BYTES,
+ * INTEGRATION.md -- and the library never calls getenv after rg_create): key 10 = album parts: 1 =
+ * never, 2 = on; key 11 = the copy-bound rule of the parts, compressed bytes per granule-channel from which a chunk
+ * becomes a part, PLUS ONE (1 = every chunk); key 12 = bytes of a pinned staging block (>= 4096); key 13 = estimated PCM
+ * bytes per group of files of rg_analyze_tracks / rg_analyze_album.
  * (Key 9 of ABI 4 -- windows 2..m in a kernel of their own -- is gone with that kernel: it spilled and was never faster.) */
 int rg_set_tuning(rg_ctx *ctx, int key, int64_t value);
 /* diagnostic (host only): variant 2's design for one rate and segment length.  T_out: [L][12],

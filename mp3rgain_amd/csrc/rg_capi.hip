@@ -6,6 +6,8 @@
 //   memset(hist, peak) -> K1 IIR+RMS+histogram+peak -> per-track percentile/result
 //   [album] -> merge -> (caller's all-reduce) -> album percentile
 // There is no CPU compute path in this file by design.
+#include <atomic>
+#include <chrono>
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
@@ -148,6 +150,66 @@ extern "C" int rg_rate_design_info(uint32_t sr, int *stable, uint32_t *halo, dou
 // ================================ context ==========================================================
 extern "C" const char *rg_last_error(const rg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+// The environment's routing / tracing knobs (INTEGRATION.md lists them), read once per context: the file layer used to call
+// getenv per call, which races with a host application's setenv; a value that does not parse keeps the default and says so
+// on stderr (a silent "nan" used to switch the album parts off).
+static void read_env_defaults(rg_ctx *c) {
+    auto number = [](const char *name, double lo, double *out) {
+        const char *e = getenv(name);
+        if (!e || !*e) return;
+        char *end = nullptr;
+        const double v = strtod(e, &end);
+        if (end == e || *end != '\0' || !(v >= lo) || !(v < 1e18)) {
+            fprintf(stderr, "mp3rgain_amd: %s=\"%s\" is not a number >= %g: ignored\n", name, e, lo);
+            return;
+        }
+        *out = v;
+    };
+    if (const char *e = getenv("RG_ALBUM_PARTS")) c->env_parts_on = !(e[0] == '0');
+    number("RG_PARTS_MIN_BYTES_PER_UNIT", 0.0, &c->env_parts_min_bpu);
+    double v = 0.0;
+    number("RG_MP3_STAGE_BYTES", 4096.0, &v);
+    c->env_stage_bytes = (size_t)v;
+    v = 0.0;
+    number("RG_TRACKS_GROUP_BYTES", 1.0, &v);
+    c->env_group_bytes = (size_t)v;
+    c->trace_files = getenv("RG_TRACE_FILES") != nullptr;
+    if (const char *e = getenv("RG_TRACE_TM")) c->trace_tm = e[0] == '2' ? 2 : 1;
+}
+
+extern "C" hipError_t rg_launch_spin(uint64_t ticks, hipStream_t s);
+// Do the context's pipeline streams own a hardware queue each?  (a batch's fix-up runs under the next batch's
+// main kernel only then; the runtime has GPU_MAX_HW_QUEUES = 4 queues per process by default and hands them to streams in the
+// order of their creation.)  A wave that spins for 100 us goes to every stream at once: four queues finish together, shared ones
+// one after the other.  Costs 0.4 ms per context; the finding is a line on stderr (once per process) and the text of
+// rg_last_error until a real error replaces it -- results do not depend on it.
+static void check_hw_queues(rg_ctx *c) {
+    auto run = [&](int n_streams) -> double {
+        for (int k = 0; k < n_streams; ++k)
+            if (rg_launch_spin(1, c->slots[k].stream) != hipSuccess) return -1.0;
+        for (int k = 0; k < n_streams; ++k)
+            if (hipStreamSynchronize(c->slots[k].stream) != hipSuccess) return -1.0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < n_streams; ++k)
+            if (rg_launch_spin(10000, c->slots[k].stream) != hipSuccess) return -1.0;
+        for (int k = 0; k < n_streams; ++k)
+            if (hipStreamSynchronize(c->slots[k].stream) != hipSuccess) return -1.0;
+        return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    };
+    const double one = run(1), all = run(RG_SLOT_STREAMS);
+    if (one <= 0.0 || all <= 0.0) return;
+    c->hw_queue_serial = all / one;
+    if (all > 1.6 * one) {
+        char buf[400];
+        snprintf(buf, sizeof buf, "mp3rgain_amd: the context's %d pipeline streams share hardware queues (%.0f us for one spinning kernel, %.0f us for one on "
+                 "each stream): create the context before other HIP streams and keep GPU_MAX_HW_QUEUES >= 4 (INTEGRATION.md); results are "
+                 "unaffected, pipelined batches overlap less", RG_SLOT_STREAMS, one, all);
+        c->err = buf;
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true)) fprintf(stderr, "%s\n", buf);
+    }
+}
+
 extern "C" rg_ctx *rg_create(int device) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -172,6 +234,7 @@ extern "C" rg_ctx *rg_create(int device) {
     }
     rg_ctx *c = new rg_ctx();
     c->device = device;
+    read_env_defaults(c);
     e = hipSetDevice(device);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->user_ev, hipEventDisableTiming);
     for (int k = 0; k < RG_MAX_SLOTS && e == hipSuccess; ++k) {
@@ -212,6 +275,7 @@ extern "C" rg_ctx *rg_create(int device) {
         rg_destroy(c);
         return nullptr;
     }
+    check_hw_queues(c);
     return c;
 }
 
@@ -327,6 +391,16 @@ extern "C" int rg_set_tuning(rg_ctx *c, int key, int64_t value) {
         case RG_TUNE_INGEST_CHUNK_KIB: c->tune_ingest_chunk_kib = (uint64_t)value; return RG_OK;
         case RG_TUNE_GPU_MP3_DECODE: c->gpu_mp3_decode = value > 3 ? 3 : (int)value; return RG_OK;
         case RG_TUNE_LOADER_THREADS: c->loader_threads = (unsigned)(value > 1024 ? 1024 : value); return RG_OK;
+        case RG_TUNE_ALBUM_PARTS:
+            if (value > 2) return rg_set_err(c, RG_ERR_INVALID_ARG, "tuning key 10 takes 0 (default), 1 (never) or 2 (on)");
+            c->tune_album_parts = (int)value;
+            return RG_OK;
+        case RG_TUNE_PARTS_MIN_BPU: c->tune_parts_min_bpu = value; return RG_OK;
+        case RG_TUNE_STAGE_BYTES:
+            if (value != 0 && value < 4096) return rg_set_err(c, RG_ERR_INVALID_ARG, "a staging block holds at least 4096 bytes");
+            c->tune_stage_bytes = (size_t)value;
+            return RG_OK;
+        case RG_TUNE_GROUP_BYTES: c->tune_group_bytes = (size_t)value; return RG_OK;
         case RG_TUNE_PIPELINE_SLOTS: {
             if (sync_all(c) != RG_OK) return RG_ERR_DEVICE;
             c->n_slots = value == 0 ? RG_DEFAULT_SLOTS : (value > RG_MAX_SLOTS ? RG_MAX_SLOTS : (int)value);

@@ -200,3 +200,14 @@ extern "C" hipError_t rg_launch_synth_fill(float *d_dst, uint64_t seed, uint32_t
                        sample_rate, first_frame, frames);
     return hipGetLastError();
 }
+
+// One wave that keeps its queue busy for `ticks` of the 100 MHz wall clock: rg_create launches it on all pipeline streams at once
+// to see whether they run beside each other (rg_capi.hip: check_hw_queues).
+__global__ void __launch_bounds__(64) rg_spin_kernel(uint64_t ticks) {
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+extern "C" hipError_t rg_launch_spin(uint64_t ticks, hipStream_t s) {
+    hipLaunchKernelGGL(rg_spin_kernel, dim3(1), dim3(64), 0, s, ticks);
+    return hipGetLastError();
+}

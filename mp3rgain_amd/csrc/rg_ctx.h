@@ -63,7 +63,8 @@ struct RgTmDeviceTables {
 };
 
 enum { RG_TUNE_TM_SEGMENT = 1, RG_TUNE_TM_TARGET_LANES = 2, RG_TUNE_PIPELINE_SLOTS = 3, RG_TUNE_TM_WINDOWS = 4, RG_TUNE_INGEST_CHUNK_KIB = 5,
-       RG_TUNE_GPU_MP3_DECODE = 6, RG_TUNE_LOADER_THREADS = 7 };
+       RG_TUNE_GPU_MP3_DECODE = 6, RG_TUNE_LOADER_THREADS = 7, RG_TUNE_ALBUM_PARTS = 10, RG_TUNE_PARTS_MIN_BPU = 11,
+       RG_TUNE_STAGE_BYTES = 12, RG_TUNE_GROUP_BYTES = 13 };
 
 #define RG_MAX_SLOTS 8
 #define RG_SLOT_STREAMS 4   // HIP streams the slots are spread over (the runtime has 4 hardware queues by default)
@@ -184,6 +185,24 @@ struct rg_ctx {
                                              // only finds the frames and strips their headers (loader pipeline, rg_files.hip)
     int32_t file_track_index = -1;           // Some(idx) of the file-level call in progress (src/replaygain.rs:838-851); -1 = None
     unsigned loader_threads = 0;             // tuning key 7: host threads of the file loaders; 0 = every core this process may use
+    // Routing knobs of the file layer.  The environment is read ONCE, at rg_create (rg_capi.hip: read_env_defaults; getenv is
+    // not safe against a host application's setenv, and a value that does not parse is ignored with a message in
+    // rg_last_error's place); tuning keys 10-13 override per context, 0 = the default read then.
+    bool env_parts_on = true;                // RG_ALBUM_PARTS != "0"
+    double env_parts_min_bpu = 120.0;        // RG_PARTS_MIN_BYTES_PER_UNIT: compressed bytes per unit from which a chunk is copy-bound
+    size_t env_stage_bytes = 0;              // RG_MP3_STAGE_BYTES (>= 4096), 0 = the album's size, at most 128 MB
+    size_t env_group_bytes = 0;              // RG_TRACKS_GROUP_BYTES, 0 = a third of the free device memory
+    double hw_queue_serial = 0.0;            // rg_create's finding: time of a spinning kernel on every pipeline stream / on one (1 = own queues, 4 = one queue)
+    bool trace_files = false;                // RG_TRACE_FILES
+    int trace_tm = 0;                        // RG_TRACE_TM: 1 = the segment chooser's decision, 2 = every candidate
+    int tune_album_parts = 0;                // key 10: 0 = default, 1 = never, 2 = whenever the rule allows
+    int64_t tune_parts_min_bpu = 0;          // key 11: threshold + 1 (1 = every chunk is a part), 0 = default
+    size_t tune_stage_bytes = 0;             // key 12
+    size_t tune_group_bytes = 0;             // key 13
+    bool parts_on() const { return tune_album_parts ? tune_album_parts == 2 : env_parts_on; }
+    double parts_min_bpu() const { return tune_parts_min_bpu ? (double)(tune_parts_min_bpu - 1) : env_parts_min_bpu; }
+    size_t stage_bytes() const { return tune_stage_bytes ? tune_stage_bytes : env_stage_bytes; }
+    size_t group_bytes() const { return tune_group_bytes ? tune_group_bytes : env_group_bytes; }
     DevBuf<unsigned char> d_arena;           // staging for host PCM (synchronous API)
     DevBuf<unsigned char> d_ingest[2];       // streamed host ingest: two sub-batch arenas, one filling while the other is analysed
     DevBuf<uint32_t> d_album_packs;          // streamed album: one [histogram | peak] pack per sub-batch, folded at the end

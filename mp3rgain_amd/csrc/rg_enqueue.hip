@@ -300,8 +300,7 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
         // tables that do not fit a CU's LDS (160 KiB) send the whole launch down the generic path
         // rounds * cost covers every lane of the batch whatever the segment stride is, so candidates compare on it directly
         score[i] = rounds * cost * eff * (lds > (double)RG_TM_LDS_BYTES ? 8.0 : 1.0);
-        if (const char *e = getenv("RG_TRACE_TM"))
-            if (e[0] == '2')
+        if (c->trace_tm >= 2)
                 fprintf(stderr, "[tm]   L %u m %u: H10 %u block %u lds %.0f blocks/CU %.0f waves %.0f rounds %.2f wps %.2f eff %.2f cost/frame %.2f score %.4g\n", L, m, H10,
                         block, lds, blocks_cu, waves, rounds, wps, eff, cost / (double)stride, score[i]);
         if (score[i] < best) { best = score[i]; best_i = i; }
@@ -313,7 +312,7 @@ int choose_tm_tables(rg_ctx *c, const TmGroup &g, const rg_track_desc *tracks, R
     (void)best_i;
     for (size_t i : order)
         if (get_tm_tables(c, g.rate_idx, cand[i].L, out, cand[i].m) == RG_OK) {
-            if (getenv("RG_TRACE_TM"))
+            if (c->trace_tm)
                 fprintf(stderr, "[tm] %zu track(s) at %u Hz, %s: L = %u, m = %u (score %.3g; runner-up L = %u, m = %u: %.3g)\n", g.ids.size(),
                         RG_RATE_TABLE[g.rate_idx].sample_rate, c->one_shot ? "one batch in flight" : "pipelined", cand[i].L, cand[i].m, score[i],
                         cand[order.size() > 1 ? order[1] : i].L, cand[order.size() > 1 ? order[1] : i].m, score[order.size() > 1 ? order[1] : i]);

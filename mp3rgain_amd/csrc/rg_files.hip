@@ -670,10 +670,7 @@ struct PartsRun {
 // Copy: ~50 GB/s; decode: ~0.5 ms per 256 K units = 1.9 ns per unit = 95 bytes' worth of copy.  At 104 bytes per unit (128 kb/s
 // stereo) the two routes measure the same within their noise (album 24.9 -> 23.4 ms, track mode 21.6 -> 22.5), so the line is
 // drawn at 120: 160 kb/s and up.
-double parts_min_bytes_per_unit() {  // (read per call: tests flip it)
-    const char *e = getenv("RG_PARTS_MIN_BYTES_PER_UNIT");
-    return e ? atof(e) : 120.0;
-}
+// (rg_ctx::parts_min_bpu(): RG_PARTS_MIN_BYTES_PER_UNIT as read at rg_create, or tuning key 11)
 Mp3Pipe &mp3_pipe(rg_ctx *c) {
     if (!c->mp3_pipe) {
         c->mp3_pipe = new Mp3Pipe();
@@ -809,7 +806,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
     rc = rg_mp3dev_reserve_results(c, n, fs);
     if (rc != RG_OK) return rc;
 
-    const bool trace = getenv("RG_TRACE_FILES") != nullptr;
+    const bool trace = c->trace_files;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
     PipeRun R;
@@ -820,10 +817,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
             if (paths[i] && stat(paths[i], &st) == 0 && st.st_size > 0) total += (size_t)st.st_size;
         }
         size_t cap = kPipeStageBytes;
-        if (const char *e = getenv("RG_MP3_STAGE_BYTES")) {  // tests: tiny blocks, so that a handful of small files exercises the whole rotation
-            const long long v = atoll(e);
-            if (v >= 4096) cap = (size_t)v;
-        }
+        if (c->stage_bytes()) cap = c->stage_bytes();  // tests: tiny blocks, so that a handful of small files exercises the whole rotation
         R.stage_want = std::min(cap, total + total / 8 + ((size_t)1 << 16));
     }
     std::vector<PipeFile> pf(n);
@@ -1020,7 +1014,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         return r;
     };
     // the tracks of chunk `index` (decode enqueued, the chunk after it too) as one part of the album
-    const double copy_bound_at = parts ? parts_min_bytes_per_unit() : 0.0;
+    const double copy_bound_at = parts ? c->parts_min_bpu() : 0.0;
     // `ch` (may be null: nothing new) joins what is pending; `index`: the newest chunk whose files are pending or were
     auto analyze_part = [&](const PipeChunk *ch, size_t index, bool last) -> int {
         if (!parts || parts->broken) return RG_OK;
@@ -1266,10 +1260,7 @@ static void file_groups(rg_ctx *c, const char *const *paths, size_t n, std::vect
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)48 << 30;
     size_t budget = std::min((size_t)64 << 30, (free_b + c->d_arena.cap) / 3);
-    if (const char *e = getenv("RG_TRACKS_GROUP_BYTES")) {  // tests: small groups
-        const long long v = atoll(e);
-        if (v > 0) budget = (size_t)v;
-    }
+    if (c->group_bytes()) budget = c->group_bytes();  // tests: small groups
     groups->clear();
     for (size_t first = 0; first < n;) {
         size_t last = first, est = 0;
@@ -1300,7 +1291,7 @@ extern "C" int rg_analyze_album_begin(rg_ctx *c, const char *const *paths, size_
     if (rc != RG_OK) return rc;
     std::vector<std::pair<size_t, size_t>> groups;
     file_groups(c, paths, n, &groups);
-    const bool trace = getenv("RG_TRACE_FILES") != nullptr;
+    const bool trace = c->trace_files;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto fail_at = [&](size_t i, int code) {
         if (failed_index) *failed_index = i;
@@ -1313,8 +1304,7 @@ extern "C" int rg_analyze_album_begin(rg_ctx *c, const char *const *paths, size_
         std::vector<int> rcs;
         std::vector<std::string> errs;
         // album parts (PartsRun): one album that fits the device, decoded by the loader pipeline, nobody else's stream involved
-        const char *parts_env = getenv("RG_ALBUM_PARTS");  // "0": never (tests, measurements)
-        const bool parts_on = !(parts_env && parts_env[0] == '0');
+        const bool parts_on = c->parts_on();  // RG_ALBUM_PARTS=0 / tuning key 10 = 1: never (tests, measurements)
         PartsRun parts;
         const bool use_parts = parts_on && groups.size() <= 1 && cnt > 0 && c->gpu_mp3_decode >= 3 && !c->user_attached;
         if (use_parts)  // the parts use every slot's buffers on the decode's stream: nothing of an earlier batch may be in flight
@@ -1385,10 +1375,9 @@ static int analyze_tracks_group(rg_ctx *c, const char *const *paths, size_t firs
     std::vector<int> rcs;
     std::vector<std::string> errs;
     // parts (PartsRun), track mode: every file of the group has to come through the loader pipeline for them to count
-    const char *parts_env = getenv("RG_ALBUM_PARTS");
     PartsRun parts;
     parts.album = 0;
-    const bool use_parts = !(parts_env && parts_env[0] == '0') && n > 0 && c->gpu_mp3_decode >= 3 && !c->user_attached;
+    const bool use_parts = c->parts_on() && n > 0 && c->gpu_mp3_decode >= 3 && !c->user_attached;
     if (use_parts)
         for (int k = 0; k < RG_SLOT_STREAMS; ++k) RG_HIP(c, hipStreamSynchronize(c->slots[k].stream));
     c->file_track_index = track_index;

@@ -46,13 +46,51 @@ struct RgMp3Dct<1> {
     static RG_MP3_HD void run(const float *x, float *X, const float *) { X[0] = x[0]; }
 };
 
+// The same DCT as a dense product behind ONE even/odd split -- the form the device runs on its matrix cores
+// (rg_mp3dev.hip, wave 2: v_mfma_f32_16x16x4_f32), and therefore the form the host runs too:
+//   u[k] = x[k] + x[31-k],  v[k] = x[k] - x[31-k]                                      (k = 0..15)
+//   A[2i]   = sum_k u[k] cos(pi (2i)   (2k+1) / 64),   A[2i+1] = sum_k v[k] cos(pi (2i+1) (2k+1) / 64)   (i = 0..15)
+// every sum a chain of fused multiply-adds from +0.0f in ascending k -- the order in which the matrix instruction adds its
+// four products to the accumulator and in which the device chains four of them (tools/ubench/mfma_order.hip established
+// it on gfx950).  512 fused operations and 32 additions per time slot instead of Lee's 289 -- on the host's vector units
+// (sixteen independent chains per parity, the inner loop runs over i) no slower, and closer to the exact sum: no secants
+// up to 10.2 in front of the additions.  `c`: [parity][k][i], (float) of the cosines above (rg_mp3dec.cpp: tables()).
+RG_MP3_HD void rg_mp3_dct32_split(const float *x /* 32 */, float *A /* 32 */, const float (*c)[16][16]) {
+    float u[16], v[16], e[16], o[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        u[k] = x[k] + x[31 - k];
+        v[k] = x[k] - x[31 - k];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) e[i] = o[i] = 0.0f;
+    for (int k = 0; k < 16; ++k) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            e[i] = rg_mp3_mac(u[k], c[0][k][i], e[i]);
+            o[i] = rg_mp3_mac(v[k], c[1][k][i], o[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        A[2 * i] = e[i];
+        A[2 * i + 1] = o[i];
+    }
+}
+
 // The polyphase matrixing V[i] = sum_k S[k] cos((16 + i)(2k+1) pi / 64), i = 0..63, from the DCT above:
 //   V[i] = A[16+i] (i < 16),  V[16] = 0,  V[i] = -A[48-i] (17 <= i <= 47),  V[48] = -A[0],  V[i] = -A[i-48] (i >= 49)
 // `V` may be any random-access target with operator[] (a plain array, or the host's ring buffer view).
 template <typename Out>
-RG_MP3_HD void rg_mp3_matrixing(const float *S /* 32 */, Out &&V, const float *sec) {
+RG_MP3_HD void rg_mp3_matrixing(const float *S /* 32 */, Out &&V, const float *sec, const float (*dct16)[16][16]) {
     float A[32];
+#ifdef RG_MP3_DCT_LEE
+    (void)dct16;
     RgMp3Dct<32>::run(S, A, sec);
+#else
+    (void)sec;
+    rg_mp3_dct32_split(S, A, dct16);
+#endif
 #pragma unroll
     for (int i = 0; i < 16; ++i) V[i] = A[16 + i];
     V[16] = 0.0f;

@@ -173,7 +173,8 @@ struct Tables {
     float win[4][36];                     // IMDCT windows per block type (2 = short, 12 taps used)
     float imdct36[36][18];
     float imdct12[12][6];
-    float sec[32];                        // secants of the 32-point DCT behind the synthesis matrixing (rg_mp3_math.h)
+    float sec[32];                        // secants of the 32-point DCT behind the synthesis matrixing (rg_mp3_math.h: Lee's form)
+    float dct16[2][16][16];               // [parity][k][i]: the two 16 x 16 cosine matrices of its dense form (rg_mp3_dct32_split)
     float D[512];                         // synthesis window
 };
 
@@ -268,6 +269,11 @@ const Tables &tables() {
                 for (int k = 0; k < n / 2; ++k) t->sec[at++] = (float)(1.0 / (2.0 * cos(M_PI * (2.0 * k + 1.0) / (2.0 * n))));
             t->sec[31] = 0.0f;
         }
+        for (int k = 0; k < 16; ++k)
+            for (int i = 0; i < 16; ++i) {
+                t->dct16[0][k][i] = (float)cos(M_PI * (2.0 * i) * (2.0 * k + 1.0) / 64.0);
+                t->dct16[1][k][i] = (float)cos(M_PI * (2.0 * i + 1.0) * (2.0 * k + 1.0) / 64.0);
+            }
         for (int i = 0; i <= 256; ++i) t->D[i] = (float)((double)kMp3SynthWindowQ16[i] / 65536.0);
         for (int i = 1; i < 256; ++i) t->D[512 - i] = (i & 63) ? -t->D[i] : t->D[i];
         T = t;
@@ -733,7 +739,7 @@ void synth(const float S[18][32], ChannelState &cs, const Tables &T, float *pcm 
             int o;
             float &operator[](int i) { return V[(o + i) & 1023]; }
         } ring{V, o};
-        rg_mp3_matrixing(S[t], ring, T.sec);
+        rg_mp3_matrixing(S[t], ring, T.sec, T.dct16);
         float *dst = pcm + 32 * t;
         for (int j = 0; j < 32; ++j) {
             float s = 0.0f;
@@ -1008,6 +1014,7 @@ extern "C" void rg_mp3_fill_device_tables(RgMp3DevTables *o) {
     memcpy(o->imdct36, T.imdct36, sizeof o->imdct36);
     memcpy(o->imdct12, T.imdct12, sizeof o->imdct12);
     memcpy(o->sec, T.sec, sizeof o->sec);
+    memcpy(o->dct16, T.dct16, sizeof o->dct16);
     memcpy(o->D, T.D, sizeof o->D);
     for (int r = 0; r < 9; ++r) {
         for (int b = 0; b < 23; ++b) o->sfb_long[r][b] = T.sfb_long[r][b];

@@ -15,6 +15,11 @@
 // only for the first 4 * rg_mp3_unit::reserved[0] lines (no other line holds a value above 127).  (Spectra parsed on the
 // host -- rg_mp3_parse_units -- are rows of 576 int16 in the same RG_MP3_ROW_BYTES.)
 #define RG_MP3_ROW_BYTES 1152
+// The Huffman kernel's bit reader (rg_mp3dev.hip: BitRing) opens on a 32-byte-aligned group and stays up to a ring (16 words)
+// plus a feed (8 words) ahead of the position: behind the last stream of a buffer it reads up to 4 * (16 + 8) + 32 = 128 bytes
+// past the data.  What it finds there never reaches a decoded value (everything past a frame's data is masked), but the
+// bytes must be mapped: every buffer the reader walks is reserved with this much behind its payload.
+#define RG_MP3_READ_AHEAD_BYTES 256
 #define RG_MP3_SORT_BUCKETS 96    // lane sort of the Huffman stage: big_values >> 2, heaviest first (73 buckets in use)
 #define RG_MP3_SORT_WORDS 256     // per staging set: [0, 96) histogram (zero between uses), [96, 192) bucket cursors, [192] units that decode
 #define RG_MP3_SORT_NVALID 192
@@ -30,7 +35,8 @@ struct RgMp3DevTables {
     float win[4][36];
     float imdct36[36][18];
     float imdct12[12][6];
-    float sec[32];                     // secants of the 32-point DCT behind the matrixing (rg_mp3_math.h)
+    float sec[32];                     // secants of the 32-point DCT behind the matrixing (rg_mp3_math.h, Lee's form: measurement builds)
+    float dct16[2][16][16];            // [parity][k][i]: the cosine matrices of its dense form, the matrix cores' A operands
     float D[512];
     uint16_t sfb_long[9][24];
     uint16_t sfb_short[9][16];

@@ -53,32 +53,34 @@ typedef unsigned short rg_u16x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Stages B-E, one kernel.  One block = a run of RG_MP3_RUN consecutive granules of one track (both channels), four waves,
-// a four-stage pipeline over the run's granules with ONE barrier per granule; every hand-over goes through LDS:
-//   wave 1  granule k      units and quantised spectra in (fetched one granule ahead); requantisation -- a line's gain
-//                          2^((global_gain - 210)/4 - mult (sf + preflag pretab) [- 2 subblock_gain]) depends on its band
-//                          (and window) only, so the wave first writes the granule's 22 long-band and 39 (short band,
-//                          window) gains, from a table indexed by the exact integer exponent, and a line then costs one
-//                          look-up; what is the same for the whole granule sits in scalar registers --, mid/side,
-//                          intensity stereo, short-block reordering (wave-local steps, no block barrier inside)
-//   wave 0  granule k - 1  lane (channel, subband): alias butterflies folded into the load of its eighteen lines, the
-//                          fast 36-point IMDCT of rg_mp3_math.h (the code the host runs) or three 12-point ones, window,
-//                          overlap-add with the second half it kept from the granule before (an LDS column of its own),
-//                          frequency inversion -> 18 x 32 subband samples
-//   wave 2  granule k - 2  matrixing: lane (channel, time slot) runs the 32-point DCT of rg_mp3_math.h (one source
-//                          compiled into both decoders); the 32 DCT outputs are kept, the 64 matrixing values follow
-//                          from them by symmetry
-//   wave 3  granule k - 3  the 512-tap window: lane (channel, j) owns PCM sample j of the granule's eighteen time slots;
-//                          the two DCT columns it needs of the fifteen slots of history stay in its registers from one
-//                          granule to the next (2 LDS reads per output instead of 32), the symmetry's signs are folded
-//                          into its sixteen window coefficients; 576 PCM samples per granule straight into the arena
+// a pipeline over the run's granules with ONE barrier per step; every hand-over goes through LDS.  Granule k of the run:
+//   steps k, k + 1  wave 1 (k even) or wave 2 (k odd): requantisation, in two halves so that one wave's first half runs
+//                   beside the other's second.  First half: the granule's units and quantised spectra (asked for a granule
+//                   of this wave -- two steps -- ago) are taken in, the next ones asked for; a line's gain
+//                   2^((global_gain - 210)/4 - mult (sf + preflag pretab) [- 2 subblock_gain]) depends on its band (and
+//                   window) only, so the wave writes the granule's 22 long-band and 39 (short band, window) gains, from a
+//                   table indexed by the exact integer exponent.  Second half: three rounds of four lines per lane -- a
+//                   line costs one look-up of its gain and one of x^(4/3) --, mid/side, then the special cases: intensity
+//                   stereo, short-block reordering (wave-local steps, no block barrier inside)
+//   step k + 2      wave 0, lane (channel, subband): alias butterflies folded into the load of its eighteen lines, the
+//                   fast 36-point IMDCT of rg_mp3_math.h (the code the host runs) or three 12-point ones, window,
+//                   overlap-add with the second half it kept from the granule before (in its registers), frequency
+//                   inversion -> 18 x 32 subband samples
+//   step k + 3      wave 3: matrixing, the 32-point DCT of the granule's 36 columns (channel, time slot) as 24
+//                   v_mfma_f32_16x16x4_f32 (rg_mp3_math.h: rg_mp3_dct32_split is the same arithmetic on the host)
+//   step k + 4      wave 3 again, in the same instruction stream as the matrixing of granule k + 1: the 512-tap window,
+//                   lane (channel, j) owns PCM sample j of the granule's eighteen time slots; the two DCT columns it
+//                   needs of the fifteen slots of history stay in its registers from one granule to the next (2 LDS reads
+//                   per output instead of 32), the symmetry's signs are folded into its sixteen window coefficients; 576
+//                   PCM samples per granule and channel straight into the arena
 // A run that starts inside the track takes the two granules before it through the first stages (the second one's subband
 // samples need the first one's overlap, and its DCT rows are the filterbank's history).  Each wave runs its own loop, so
-// the register file is sized for the largest stage, not for their sum: 128 VGPRs, 40 KB of LDS, four blocks per CU.
-// (Rounds 2 and 3 had two kernels with the subband samples in memory between them -- 4.6 KB of traffic per granule and
-// channel, the fifteen slots of history transformed again by every block, 0.60 ms per 256 K units against 0.46 for the first version of this kernel and 0.35 now (what the per-wave
-// clock stamps of RG_BH_TIMING showed); a
-// first fused kernel in round 2, six waves stepping through barrier-separated phases together, had lost to them.)
-
+// the register file is sized for the largest stage, not for their sum: 128 VGPRs, 38 KB of LDS, four blocks per CU.
+// History: rounds 2 and 3 had two kernels with the subband samples in memory between them (0.60 ms per 256 K units); rounds
+// 3-5 this kernel with ONE requantisation wave, a matrixing wave (Lee's DCT on the vector pipe) and a window wave: 0.46,
+// then 0.35 ms; round 6 the arrangement above: 0.35-0.36 ms again -- DESIGN section 10 has the measurements that say why
+// (a block alone on its CU steps in 4000 cycles instead of 5000, four blocks together in 5400 either way: the CU's vector
+// pipe, which the f32 matrix instructions share, is three quarters busy).
 // The block's barrier between pipeline steps.  What the waves hand each other is in LDS, so only LDS traffic has to be
 // complete at the barrier: __syncthreads() would also wait for every global load and store in flight -- the next
 // granule's spectra and units, the PCM on its way out -- and make a step as long as a round trip to memory.
@@ -97,7 +99,11 @@ extern "C" int rg_bh_dbg_read(void *out) { return (int)hipMemcpyFromSymbol(out, 
 extern "C" int rg_bh_dbg2_read(void *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rg_bh_dbg2), sizeof(unsigned long long) * 40 * 6); }
 #define RG_BH_STAMP(w, k, e) do { if (blockIdx.x == RG_BH_TIMING && (threadIdx.x & 63) == 0 && (k) < 40) rg_bh_dbg[w][k][e] = __builtin_amdgcn_s_memtime(); } while (0)
 #define RG_BH_STAMP2(k, e) do { if (blockIdx.x == RG_BH_TIMING && (threadIdx.x & 63) == 0 && (k) < 40) rg_bh_dbg2[k][e] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long rg_bh_dbg3[40][6];  // inside wave 3: [step][matrixing done | rows in registers | sums done | stored]
+extern "C" int rg_bh_dbg3_read(void *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rg_bh_dbg3), sizeof(unsigned long long) * 40 * 6); }
+#define RG_BH_STAMP3(k, e) do { if (blockIdx.x == RG_BH_TIMING && (threadIdx.x & 63) == 0 && (k) < 40) rg_bh_dbg3[k][e] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define RG_BH_STAMP3(k, e) do { } while (0)
 #define RG_BH_STAMP(w, k, e) do { } while (0)
 #define RG_BH_STAMP2(k, e) do { } while (0)
 #endif
@@ -106,24 +112,31 @@ __global__ void __launch_bounds__(RG_MP3_BH_THREADS) __attribute__((amdgpu_waves
 rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks,
                        const rg_mp3_unit *__restrict__ units, const int16_t *__restrict__ is, const uint32_t planes) {
     constexpr int R = RG_MP3_RUN;
-    __shared__ float xrb[2][2][576];   // [buffer][channel][line]
-    __shared__ __attribute__((aligned(16))) rg_mp3_unit Ub[3][2];
-    __shared__ int band_nz[64];
+    __shared__ float xrb[2][2][576];   // [granule parity][channel][line]: written in the second step of its requantisation, read in the next
+    __shared__ __attribute__((aligned(16))) rg_mp3_unit Ub[4][2];  // [granule % 4]: in two steps before its requantisation starts, read until its IMDCT
+    __shared__ uint8_t band_nz[64];
     __shared__ short band_mode[64];
     __shared__ float c12[12][6], wn[4][36], cs_l[8], ca_l[8];
     __shared__ uint8_t ptab[24];
-    __shared__ float ovl[18][64];
     __shared__ float gain_l[RG_MP3_GAIN_Q_MAX - RG_MP3_GAIN_Q_MIN + 1];
-    constexpr int kPowLds = 704;       // x^(4/3) for the values that occur (what four blocks per CU leave room for); larger ones
+    constexpr int kPowLds = 1728;      // x^(4/3) for the values that occur (what four blocks per CU leave room for); larger ones
                                        // go to the table in memory: a wait the wave cannot hide, once per round that has one
     __shared__ float pow_l[kPowLds];
     __shared__ uint16_t sfbl_l[24], sfbs_l[16];
-    __shared__ float gtab[2][64];
+    __shared__ float gtab[2][2][64];   // [requantisation wave][channel][band | 22 + 3 * short band + window]
     __shared__ __attribute__((aligned(4))) uint8_t sidx_l[576];
-    __shared__ float Sin[2][2][18][33];  // [granule parity][channel][time slot][subband]: wave 0 -> wave 2
-    __shared__ float Ar[2][2][18][33];   // the DCT outputs of those slots (word 32 = 0.0f = V[16]): wave 2 -> wave 3
+    // rows of 34 words: a matrix-core operand access is (column j = lane & 15, k or row group g = lane >> 4) -> word 34 j + g + ..
+    // = bank 2 j + g of 32: the sixteen columns of a half-wave's two groups fall on different banks (33 made them collide)
+    constexpr int kRow = 34;
+    __shared__ float Sin[2][2][18][kRow];  // [granule parity][channel][time slot][subband]: wave 0 -> wave 3
+    __shared__ float cos_l[2][16][16];     // [parity][k][i]: the matrix cores' A operands (T->dct16), read by wave 3 as it goes
+    __shared__ float Ar[2][18][kRow];    // the DCT outputs of those slots (word 32 = 0.0f = V[16]): wave 3 to itself (matrix cores -> window)
     constexpr int NT = RG_MP3_BH_THREADS;
     const int tid = threadIdx.x;
+#ifdef RG_BH_LDS_PAD  // experiment: fewer blocks per CU (what the step costs with less company)
+    __shared__ volatile float lds_pad[RG_BH_LDS_PAD / 4];
+    lds_pad[tid] = 1.0f;
+#endif
     uint32_t ti = 0;
     {
         uint32_t lo = 0, hi = n_tracks - 1;
@@ -143,31 +156,34 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
     const int pd0 = g0 > 0 ? 1 : 0;    // first pipeline granule whose subband samples are right (the one before has no overlap)
     const uint64_t ubase = tr.unit_base + (uint64_t)((long long)g0 + gi0) * nch;
     const int nsteps = ng - gi0;       // granules through the pipeline
+    constexpr int kTail = 4;           // steps a granule spends in the pipeline behind its first: requantisation x 2, IMDCT, matrixing, window
     for (int e = tid; e < 144; e += NT) (&wn[0][0])[e] = (&T->win[0][0])[e];
     if (tid < 72) (&c12[0][0])[tid] = (&T->imdct12[0][0])[tid];
     if (tid < 8) { cs_l[tid] = T->cs[tid]; ca_l[tid] = T->ca[tid]; }
     if (tid < 24) ptab[tid] = T->pretab[tid];
     for (int e = tid; e < RG_MP3_GAIN_Q_MAX - RG_MP3_GAIN_Q_MIN + 1; e += NT) gain_l[e] = T->gain[e];
     for (int e = tid; e < kPowLds; e += NT) pow_l[e] = T->pow43[e];
+    for (int e = tid; e < 512; e += NT) (&cos_l[0][0][0])[e] = (&T->dct16[0][0][0])[e];
     if (tid >= 32 && tid < 56) sfbl_l[tid - 32] = T->sfb_long[rr][tid - 32];
     if (tid >= 64 && tid < 80) sfbs_l[tid - 64] = T->sfb_short[rr][tid - 64];
     for (int e = tid; e < 144; e += NT) reinterpret_cast<uint32_t *>(sidx_l)[e] = reinterpret_cast<const uint32_t *>(T->short_idx_of_line[rr])[e];
-    if (tid < 64) {
-#pragma unroll
-        for (int i = 0; i < 18; ++i) ovl[i][tid] = 0.0f;  // a granule without a predecessor adds 0.0f, as the host does
-    }
     static_assert(sizeof(rg_mp3_unit) == 64, "the unit prefetch assumes 64-byte units");
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // a scalar: each wave takes one branch whole
     const int lane = tid & 63;
 
-    if (wave == 1) {
-        // ================= wave 1: units and spectra in, requantised (and stereo-processed, reordered) spectrum out ===
-        // This wave is the pipeline's longest stage, and a wave issues at most one instruction in four cycles: its length is
-        // its instruction count.  The body is compiled once per channel count, so that nothing in it asks how many channels
-        // there are.
-        // the block's step is as long as this wave's: where it shares a SIMD with the other blocks' lighter waves it goes first
-        // (priorities for the other stages as well were slower)
-        __builtin_amdgcn_s_setprio(3);
+    if (wave == 1 || wave == 2) {
+        // ================= waves 1, 2: units and spectra in, requantised (and stereo-processed, reordered) spectrum out =
+        // Requantisation is the pipeline's longest stage by far (its length is a chain of LDS round trips and memory
+        // instructions, not arithmetic), so two waves share it: wave 1 takes the even granules of the pipeline, wave 2 the odd
+        // ones, each over TWO steps -- first half: units, clean-up of what arrived, large values, prefetch, gains; second half:
+        // the three rounds and the special cases -- so that one wave's first half runs beside the other's second.  The body
+        // is compiled once per channel count, so that nothing in it asks how many channels there are.
+        // (No wave of the block has a priority of its own any more: with the stages this even -- 2300 cycles a step each, wave
+        // 3 3800, for a block that has the CU to itself -- raising any one of them measured 1-3 % slower)
+#ifdef RG_BH_PRIO_RQ
+        __builtin_amdgcn_s_setprio(RG_BH_PRIO_RQ);
+#endif
+        const int par = wave - 1;  // the wave's granules: par, par + 2, ... (a scalar)
         // PLANES: the spectra come from the device Huffman stage, a byte per line in two planes (rg_mp3dev.h); else rows of int16
         auto requant_wave = [&](auto nch_c, auto planes_c) {
         constexpr int nch = decltype(nch_c)::value;
@@ -179,11 +195,13 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
             if (lane + 64 * r < 144) rq_lb[r] = *reinterpret_cast<const uint32_t *>(&T->long_band_of_line[rr][4 * (lane + 64 * r)]);
         const bool uq = lane >= 56 && lane < 56 + 4 * nch;  // lanes that carry the units: four 16-byte words each
         const int uq_t = lane - 56;
-        uint4 u_reg = make_uint4(0u, 0u, 0u, 0u), u_first = make_uint4(0u, 0u, 0u, 0u);
+        // the units of this wave's first granule go to LDS here; those of its second are on their way
+        const int q_first = par < nsteps ? par : nsteps - 1;
+        uint4 u_reg = make_uint4(0u, 0u, 0u, 0u), u_first = make_uint4(0u, 0u, 0u, 0u), u_keep = make_uint4(0u, 0u, 0u, 0u);
         if (uq) {
-            u_first = reinterpret_cast<const uint4 *>(units + ubase)[uq_t];
-            reinterpret_cast<uint4 *>(&Ub[0][0])[uq_t] = u_first;
-            if (nsteps > 1) u_reg = reinterpret_cast<const uint4 *>(units + ubase + nch)[uq_t];
+            u_first = reinterpret_cast<const uint4 *>(units + ubase + (uint64_t)q_first * nch)[uq_t];
+            if (par < nsteps) reinterpret_cast<uint4 *>(&Ub[par][0])[uq_t] = u_first;
+            u_reg = reinterpret_cast<const uint4 *>(units + ubase + (uint64_t)(par + 2 < nsteps ? par + 2 : nsteps - 1) * nch)[uq_t];
         }
         // A unit's last sixteen bytes -- nz, global_gain, block_type | mixed, subblock_gain | scalefac_scale, preflag,
         // long_end, short_start | mode_ext, ... -- are the same for the whole wave and sit in lane 59 + 4 c of the units' way
@@ -274,22 +292,25 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
         };
-        fetch_spectra(0, h_next);
+        fetch_spectra(q_first, h_next);
+        float (*const GT)[64] = gtab[par];
         rg_lds_barrier();
-        for (int k = 0; k <= nsteps + 2; ++k) {
-            RG_BH_STAMP(1, k, 0);
-            if (k < nsteps) {
+        int steps_done = 0;  // the block's barriers are counted: every wave passes kTail + nsteps of them
+        if (par == 1) {      // step 0 belongs to the even wave's first half alone
+            rg_lds_barrier();
+            steps_done = 1;
+        }
+        for (int k = par; k < nsteps; k += 2) {
+            RG_BH_STAMP(wave, k, 0);
+            {
+                // ---------------- first half: step k ----------------
                 float (*const XP)[576] = xrb[k & 1];
-                const rg_mp3_unit *const UP = Ub[k % 3];
-                // the units of step k + 1 become visible at this step's barrier; those of step k + 2 start travelling
+                const rg_mp3_unit *const UP = Ub[k & 3];
                 uint32_t h[2][4];
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) h[c][i] = h_next[c][i];
-                // (past the run's last granule the same units and spectra are asked for again and never used)
-                if (uq) reinterpret_cast<uint4 *>(&Ub[(k + 1) % 3][0])[uq_t] = u_reg;
-                header_of(u_reg, h_next);
                 RG_BH_STAMP2(k, 4);
                 // ---- stage B: requantisation (rg_mp3dec.cpp: requantize)
                 uint2 raw[kRounds][2];
@@ -351,13 +372,75 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                     }
                 }
                 RG_BH_STAMP2(k, 2);
-                // Order matters from here to the end of the step.  Everything this step needs from memory has arrived; the
-                // loads for the steps to come are issued below and nothing later in the step may wait for memory: the compiler
-                // cannot count loads across a branch and waits for ALL of them wherever a conditional load meets the code
-                // after it, i.e. it would sit out a round trip of the prefetch in every step.  The one conditional read of the
-                // step -- a quantised value beyond the LDS part of the x^(4/3) table takes its power from the full table in
-                // memory -- therefore happens HERE, before the prefetch, and the power waits in the line's own place in the
-                // output buffer (which nobody else touches before this step's barrier).
+                RG_BH_STAMP2(k, 3);
+                // (asked for at the top of the step instead -- 2000 cycles earlier -- the units change nothing: 0.358 against 0.354 ms)
+                // The units of this wave's next granule (k + 2; asked for a granule ago) are here: their headers say where its
+                // spectra end, and they go to LDS in the second half (their place still holds the units of granule k - 2 until
+                // this step's IMDCT is done with them).  Those of granule k + 4 start travelling.  (Past the run's last granule
+                // the same units and spectra are asked for again and never used.)
+                u_keep = u_reg;
+                header_of(u_keep, h_next);
+#ifdef RG_BH_SAMEUNIT  // experiment (wrong results): every step reads the run's first unit again -- what the units' latency costs the step
+                if (uq) u_reg = reinterpret_cast<const uint4 *>(units + ubase + (uint64_t)(k & 0) * nch)[uq_t];
+#else
+                if (uq) u_reg = reinterpret_cast<const uint4 *>(units + ubase + (uint64_t)(k + 4 < nsteps ? k + 4 : nsteps - 1) * nch)[uq_t];
+#endif
+                fetch_spectra(k + 2 < nsteps ? k + 2 : nsteps - 1, h_next);
+                int bt_s[2] = {0, 0}, ll_s[2] = {0, 0}, so_s[2] = {0, 0};
+                int gq_idx[2] = {0, 0};
+                uint32_t gq_sf[2] = {0u, 0u};
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {  // the scalefactor each lane's gain needs: one byte read per channel, asked for together
+                    if (c >= nch) continue;
+                    const int long_end = (int)((h[c][2] >> 16) & 0xFFu), short_start = (int)(h[c][2] >> 24);
+                    // (no multiplication: for gq_kk - 3 short_start the compiler takes v_mad_u64_u32, whose 64-bit addend's unused upper half
+                    // landed in a register of the prefetch just issued -- and the wave waited for memory right here, every step)
+                    const int rel = gq_kk - (short_start == 0 ? 0 : (short_start == 3 ? 9 : 39));  // 3 short_start: it is 0, 3 or 13
+                    const bool short_sf = lane >= 22 && gq_band < 12 && rel >= 0;
+                    gq_idx[c] = lane < 22 ? lane : (short_sf ? long_end + rel : -1);
+#ifdef RG_BH_NOGAINS  // experiment (wrong results): no scalefactor, no gain look-up -- what the gains cost the step
+                    gq_sf[c] = 0;
+#else
+                    gq_sf[c] = UP[c].sf[gq_idx[c] < 0 ? 0 : gq_idx[c]];
+#endif
+                }
+                float gq_g[2] = {0.0f, 0.0f};
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (c >= nch) continue;
+                    const int scalefac_scale = (int)(h[c][2] & 0xFFu), preflag = (int)((h[c][2] >> 8) & 0xFFu);
+                    const int long_end = (int)((h[c][2] >> 16) & 0xFFu), short_start = (int)(h[c][2] >> 24);
+                    const int m4 = scalefac_scale ? 4 : 2;  // 4 * mult
+                    const int base4 = (int)((h[c][0] >> 16) & 0xFFu) - 210;
+                    const int sv = gq_idx[c] < 0 ? 0 : (int)gq_sf[c];
+                    int q;
+                    if (lane < 22) q = base4 - m4 * (sv + (preflag ? gq_pt : 0));
+                    else q = base4 - 8 * (int)((h[c][1] >> gq_sh) & 0xFFu) - m4 * sv;
+                    q = q < RG_MP3_GAIN_Q_MIN ? RG_MP3_GAIN_Q_MIN : (q > RG_MP3_GAIN_Q_MAX ? RG_MP3_GAIN_Q_MAX : q);
+#ifdef RG_BH_NOGAINS
+                    gq_g[c] = __int_as_float(0x3f800000 + (q << 10));
+#else
+                    gq_g[c] = gain_l[q - RG_MP3_GAIN_Q_MIN];
+#endif
+                    bt_s[c] = (int)(h[c][0] >> 24);
+                    ll_s[c] = long_end == 22 ? ll22 : (long_end == 8 ? ll8 : (long_end == 6 ? ll6 : (long_end == 0 ? 0 : (int)sfbl_l[long_end])));
+                    so_s[c] = short_start >= 13 ? so13 : (short_start == 3 ? so3 : (short_start == 0 ? 0 : 3 * (int)sfbs_l[short_start]));
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    if (c < nch) GT[c][lane] = lane < 61 ? gq_g[c] : 0.0f;
+                const bool ms_all = nch == 2 && (h[0][3] & 3u) == 2u;  // plain mid/side (no intensity stereo in the frame)
+                RG_BH_STAMP2(k, 0);
+                RG_BH_STAMP(wave, k, 1);
+                // ---------------- second half: step k + 1 (the gains are visible behind the barrier) ----------------
+                rg_lds_barrier();
+                RG_BH_STAMP(wave, k + 1, 0);
+                if (uq && k + 2 < nsteps) reinterpret_cast<uint4 *>(&Ub[(k + 2) & 3][0])[uq_t] = u_keep;
+                // The one conditional read of a granule: a quantised value beyond the LDS part of the x^(4/3) table takes its
+                // power from the full table in memory and leaves it in the line's own place in the output buffer (free since
+                // the last step's IMDCT).  With 1728 entries in LDS that is one unit in a thousand of encoder-made music and
+                // none of the reference's VBR fixture; it happens here, at the top of the second half, where the only loads in
+                // flight are the prefetch of a step ago (rounds 3-5 had it in front of the prefetch, with 704 entries).
                 bool big_r[kRounds];  // the wave's: some lane of round r holds such a value
                 {
                     bool any_big = false;
@@ -405,60 +488,6 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                         }
                     }
                 }
-                RG_BH_STAMP2(k, 3);
-                // (asked for at the top of the step instead -- 2000 cycles earlier -- the units change nothing: 0.358 against 0.354 ms)
-#ifdef RG_BH_SAMEUNIT  // experiment (wrong results): every step reads the run's first unit again -- what the units' latency costs the step
-                if (uq) u_reg = reinterpret_cast<const uint4 *>(units + ubase + (uint64_t)(k & 0) * nch)[uq_t];
-#else
-                if (uq) u_reg = reinterpret_cast<const uint4 *>(units + ubase + (uint64_t)(k + 2 < nsteps ? k + 2 : nsteps - 1) * nch)[uq_t];
-#endif
-                fetch_spectra(k + 1 < nsteps ? k + 1 : nsteps - 1, h_next);
-                int bt_s[2] = {0, 0}, ll_s[2] = {0, 0}, so_s[2] = {0, 0};
-                int gq_idx[2] = {0, 0};
-                uint32_t gq_sf[2] = {0u, 0u};
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {  // the scalefactor each lane's gain needs: one byte read per channel, asked for together
-                    if (c >= nch) continue;
-                    const int long_end = (int)((h[c][2] >> 16) & 0xFFu), short_start = (int)(h[c][2] >> 24);
-                    // (no multiplication: for gq_kk - 3 short_start the compiler takes v_mad_u64_u32, whose 64-bit addend's unused upper half
-                    // landed in a register of the prefetch just issued -- and the wave waited for memory right here, every step)
-                    const int rel = gq_kk - (short_start == 0 ? 0 : (short_start == 3 ? 9 : 39));  // 3 short_start: it is 0, 3 or 13
-                    const bool short_sf = lane >= 22 && gq_band < 12 && rel >= 0;
-                    gq_idx[c] = lane < 22 ? lane : (short_sf ? long_end + rel : -1);
-#ifdef RG_BH_NOGAINS  // experiment (wrong results): no scalefactor, no gain look-up -- what the gains cost the step
-                    gq_sf[c] = 0;
-#else
-                    gq_sf[c] = UP[c].sf[gq_idx[c] < 0 ? 0 : gq_idx[c]];
-#endif
-                }
-                float gq_g[2] = {0.0f, 0.0f};
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    if (c >= nch) continue;
-                    const int scalefac_scale = (int)(h[c][2] & 0xFFu), preflag = (int)((h[c][2] >> 8) & 0xFFu);
-                    const int long_end = (int)((h[c][2] >> 16) & 0xFFu), short_start = (int)(h[c][2] >> 24);
-                    const int m4 = scalefac_scale ? 4 : 2;  // 4 * mult
-                    const int base4 = (int)((h[c][0] >> 16) & 0xFFu) - 210;
-                    const int sv = gq_idx[c] < 0 ? 0 : (int)gq_sf[c];
-                    int q;
-                    if (lane < 22) q = base4 - m4 * (sv + (preflag ? gq_pt : 0));
-                    else q = base4 - 8 * (int)((h[c][1] >> gq_sh) & 0xFFu) - m4 * sv;
-                    q = q < RG_MP3_GAIN_Q_MIN ? RG_MP3_GAIN_Q_MIN : (q > RG_MP3_GAIN_Q_MAX ? RG_MP3_GAIN_Q_MAX : q);
-#ifdef RG_BH_NOGAINS
-                    gq_g[c] = __int_as_float(0x3f800000 + (q << 10));
-#else
-                    gq_g[c] = gain_l[q - RG_MP3_GAIN_Q_MIN];
-#endif
-                    bt_s[c] = (int)(h[c][0] >> 24);
-                    ll_s[c] = long_end == 22 ? ll22 : (long_end == 8 ? ll8 : (long_end == 6 ? ll6 : (long_end == 0 ? 0 : (int)sfbl_l[long_end])));
-                    so_s[c] = short_start >= 13 ? so13 : (short_start == 3 ? so3 : (short_start == 0 ? 0 : 3 * (int)sfbs_l[short_start]));
-                }
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-                    if (c < nch) gtab[c][lane] = lane < 61 ? gq_g[c] : 0.0f;
-                const bool ms_all = nch == 2 && (h[0][3] & 3u) == 2u;  // plain mid/side (no intensity stereo in the frame)
-                wave_sync();
-                RG_BH_STAMP2(k, 0);
                 // This wave is the pipeline's longest stage and it runs alone on its data, so its length is the sum of its
                 // LDS round trips: the look-ups of a round (8 gains, 8 powers per lane, both channels) are all asked for
                 // before the first one is used, the rare value beyond the LDS part of the power table is dealt with once per
@@ -480,13 +509,13 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                         if (c >= nch) continue;
                         if (bt_s[c] != 2) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) gv[c][j] = gtab[c][(rq_lb[r] >> (8 * j)) & 0xFFu];
+                            for (int j = 0; j < 4; ++j) gv[c][j] = GT[c][(rq_lb[r] >> (8 * j)) & 0xFFu];
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const int line = rq_l0 + j;
                                 const int idx = line < ll_s[c] ? (int)((rq_lb[r] >> (8 * j)) & 0xFFu) : 22 + (int)sidx_l[line - ll_s[c] + so_s[c]];
-                                gv[c][j] = gtab[c][idx];
+                                gv[c][j] = GT[c][idx];
                             }
                         }
                         if (bytes_r[r]) {  // the byte is the index
@@ -667,9 +696,11 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                     }
                 }
             }
-            RG_BH_STAMP(1, k, 1);
+            RG_BH_STAMP(wave, k + 1, 1);
             rg_lds_barrier();
+            steps_done += 2;
         }
+        for (; steps_done < nsteps + kTail; ++steps_done) rg_lds_barrier();
         };
         if (planes) {
             if (nch == 2) requant_wave(std::integral_constant<int, 2>{}, std::true_type{});
@@ -685,16 +716,22 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         // ================= wave 0: lane (channel, subband): spectrum -> subband samples of eighteen time slots =========
         const bool active = lane < 32 * nch;
         const int my_c = lane >> 5, my_sb = lane & 31;
+        float ovl[18];  // the second half of the lane's subband from the granule before (rounds 3-5: an LDS column, 36 accesses a step)
+#pragma unroll
+        for (int i = 0; i < 18; ++i) ovl[i] = 0.0f;  // a granule without a predecessor adds 0.0f, as the host does
+#ifdef RG_BH_PRIO_IMDCT
+        __builtin_amdgcn_s_setprio(RG_BH_PRIO_IMDCT);
+#endif
         rg_lds_barrier();
-        for (int k = 0; k <= nsteps + 2; ++k) {
+        for (int k = 0; k < nsteps + kTail; ++k) {
             RG_BH_STAMP(0, k, 0);
-            if (k >= 1 && k <= nsteps && active) {
+            if (k >= 2 && k <= nsteps + 1 && active) {
                 // ---- stage D of granule k - 1 (rg_mp3dec.cpp: antialias, hybrid).  The butterflies between subbands
                 // sb - 1 | sb, sb = 1 .. nb: this lane evaluates its own half of the two it touches.  Windowed sample i:
                 // the first eighteen are added to the overlap and leave (frequency inversion: odd samples of odd subbands
                 // change sign), the second eighteen are the next granule's overlap.
-                const int q = k - 1;
-                const rg_mp3_unit &u = Ub[q % 3][my_c];
+                const int q = k - 2;
+                const rg_mp3_unit &u = Ub[q & 3][my_c];
                 const float *const X = xrb[q & 1][my_c];
                 const int bt = (u.block_type == 2 && u.mixed && my_sb < 2) ? 0 : (int)u.block_type;
                 const int nb = u.block_type == 2 ? (u.mixed ? 1 : 0) : 31;
@@ -720,11 +757,11 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                 const bool flip = (my_sb & 1) != 0;
                 auto emit = [&](const int i, const float val) {
                     if (i < 18) {
-                        float v = val + ovl[i][lane];
+                        float v = val + ovl[i];
                         if (flip && (i & 1)) v = -v;
-                        dst[i * 33] = v;
+                        dst[i * kRow] = v;
                     } else {
-                        ovl[i - 18][lane] = val;
+                        ovl[i - 18] = val;
                     }
                 };
                 if (bt != 2) {
@@ -739,7 +776,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                     } sink{emit};
                     rg_mp3_imdct36_windowed(xs, wn[bt], sink);
                 } else {
-#pragma unroll 1
+#pragma unroll  // (unrolled: the overlap is in registers, and of the three windows at most two reach a sample)
                     for (int i = 0; i < 36; ++i) {
                         float raw = 0.0f;
 #pragma unroll
@@ -752,13 +789,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                                 raw = rg_mp3_mac(s2, wn[2][ii], raw);
                             }
                         }
-                        if (i < 18) {
-                            float v = raw + ovl[i][lane];
-                            if (flip && (i & 1)) v = -v;
-                            dst[i * 33] = v;
-                        } else {
-                            ovl[i - 18][lane] = raw;
-                        }
+                        emit(i, raw);
                     }
                 }
             }
@@ -768,40 +799,37 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         return;
     }
 
-    if (wave == 2) {
-        // ================= wave 2: matrixing, lane (channel, time slot): the 32-point DCT (rg_mp3dec.cpp: synth) =======
-        const int c = lane >> 5, t = lane & 31;
-        const bool active = t < 18 && c < nch;
-        rg_lds_barrier();
-        for (int k = 0; k <= nsteps + 2; ++k) {
-            RG_BH_STAMP(2, k, 0);
-            const int p = k - 2;
-            if (p >= pd0 && p < nsteps && active) {
-                float x[32], A[32];
-                const float *src = &Sin[p & 1][c][t][0];
-#pragma unroll
-                for (int i = 0; i < 32; ++i) x[i] = src[i];
-                RgMp3Dct<32>::run(x, A, T->sec);
-                float *dstA = &Ar[p & 1][c][t][0];
-#pragma unroll
-                for (int i = 0; i < 32; ++i) dstA[i] = A[i];
-                dstA[32] = 0.0f;
-            }
-            RG_BH_STAMP(2, k, 1);
-            rg_lds_barrier();
-        }
-        return;
-    }
-
     {
-        // ================= wave 3: the 512-tap window, lane (channel, j) -> PCM sample j of every time slot ============
+        // ================= wave 3: matrixing on the matrix cores, then the 512-tap window -> PCM ========================
+        // Matrixing (rg_mp3dec.cpp: synth): the 36 (18) columns (channel, time slot) of a granule are three (two) tiles of
+        // sixteen; the 32-point DCT behind one even/odd split (rg_mp3_math.h: rg_mp3_dct32_split -- what the host runs) is
+        // two 16 x 16 matrices with K = 16, i.e. four v_mfma_f32_16x16x4_f32 per parity and tile chained through the
+        // accumulator: 24 matrix instructions (768 cycles of a pipe nothing else in this kernel uses), 24 additions and
+        // 24 + 24 LDS accesses per granule where Lee's form took 289 vector instructions on a wave of its own (rounds 3-5).
+        // The instruction adds its four products to the accumulator one after the other, each a fused multiply-add, in
+        // ascending k, subnormals kept (tools/ubench/mfma_order.hip; profiles/r06_mfma_order.txt): a chain of sixteen
+        // rg_mp3_mac from +0.0f, which is what the host's loop is.
+        // A operand (resident): lane (i = lane & 15, g = lane >> 4) holds cos[parity][k = 4 ks + g][i]; B operand: column
+        // j = lane & 15 of the tile, k = 4 ks + g: u or v of subbands k and 31 - k; D: lane holds rows 4 g .. 4 g + 3 of
+        // both parities = DCT outputs 8 g .. 8 g + 7 of its column.
+        // The window: lane (channel, j) owns PCM sample j of every time slot:
         // PCM sample j of time slot r is  sum_{i<8} V[r-2i][j] D[64i+j] + V[r-2i-1][32+j] D[64i+32+j]  in that order (the
         // host's); V[.][j] and V[.][32+j] are two fixed columns of the DCT rows with the signs folded into the window
         // coefficients: V[.][j] = A[.][16+j] (j < 16), 0 (j = 16), -A[.][48-j] (j > 16); V[.][32+j] = -A[.][16-j] (j < 16),
         // -A[.][0] (j = 16), -A[.][j-16] (j > 16) (fma(-a, d, s) and fma(a, -d, s) are the same bits).  cA / cB [q]: those
-        // columns of time slot q - 15 relative to the granule.
-        const int c = lane >> 5, wj = lane & 31;
-        const bool active = c < nch;
+        // columns of time slot q - 15 relative to the granule; the fifteen slots of history stay in registers from one
+        // granule to the next.
+        typedef float rg_f32x4 __attribute__((ext_vector_type(4)));
+#ifdef RG_BH_PRIO_W3
+        __builtin_amdgcn_s_setprio(RG_BH_PRIO_W3);
+#endif
+        const int mj = lane & 15, mg = lane >> 4;
+        const float *const cos_at = &cos_l[0][mg][mj];  // + 256 parity + 64 ks: the lane's element of an A operand (word = lane + ..: no bank twice)
+        const int ncols = 18 * nch;
+        if (lane < 36) (&Ar[0][0][0])[lane * kRow + 32] = 0.0f;  // word 32 of every row = V[16] = 0.0f, written once
+        // one channel: the upper half-wave repeats the lower one (same values to the same addresses) instead of sitting
+        // out under a mask -- the step's body is one straight line
+        const int c = nch == 2 ? lane >> 5 : 0, wj = lane & 31;
         float D1[8], D2[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -814,36 +842,134 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
         float cA[33], cB[33];
 #pragma unroll
         for (int q = 0; q < 33; ++q) cA[q] = cB[q] = 0.0f;  // the slots before the track are silence
-        float *const plane = c == 0 ? tr.ch0 : tr.ch1;
-        rg_lds_barrier();
-        for (int k = 0; k <= nsteps + 2; ++k) {
-            RG_BH_STAMP(3, k, 0);
-            const int p = k - 3;
-            if (p >= pd0 && p < nsteps && active) {
-                const float *rows = &Ar[p & 1][c][0][0];
+        // where a lane's PCM goes: a scalar base (the granule in the first channel's plane) + 32 bits of the lane's own (its
+        // channel's plane, its sample) -- a 64-bit address per lane cost two registers the sums need (and, spilled, a wait
+        // for every store in flight at the top of each step); the planes of a track lie less than 2^32 bytes apart (the host
+        // refuses a longer track for this route: rg_mp3dev_host.hip)
+        const uint32_t lane_off = (c == 0 ? 0u : (uint32_t)(tr.ch1 - tr.ch0)) + (uint32_t)wj;
+        // One step of this wave: the matrixing of granule pd = k - 3 on the matrix cores and, BESIDE it, the window sums
+        // of granule pw = k - 4 on the vector pipe -- the 24 matrix instructions (32 cycles each in their own pipe) are
+        // issued one every twelve fused multiply-adds (48 cycles), so the step is as long as the sums alone (one after the
+        // other the two took 1900 + 1600 cycles of a block that has the CU to itself, the longest stage of the pipeline).
+        // Order: the rows of pw (written by the step before) into registers, then pd's operands tile by tile, its results
+        // into the rows behind.  DV / WM (compile time): is there a granule to transform; 0 = none to window, 1 = its rows
+        // only become history (the granules before the run's first: nothing leaves), 2 = sums and PCM.
+        auto w3_step = [&](auto dv_c, auto wm_c, const int k) {
+#ifdef RG_BH_NO_MFMA  // experiments (wrong results): the step without its matrix instructions / without its sums
+            constexpr bool DV = false;
+#else
+            constexpr bool DV = decltype(dv_c)::value;
+#endif
+#ifdef RG_BH_NO_SUMS
+            constexpr int WM = decltype(wm_c)::value == 2 ? 1 : decltype(wm_c)::value;
+#else
+            constexpr int WM = decltype(wm_c)::value;
+#endif
+            const int pd = k - 3, pw = k - 4;
+            const float *const S = &Sin[pd & 1][0][0][0];  // [column = channel * 18 + time slot][kRow]
+            float *const wr = &Ar[0][0][0] + mj * kRow + 8 * mg;
+            if (WM >= 1) {
+                const float *rows = &Ar[c][0][0];
 #pragma unroll
                 for (int q = 0; q < 18; ++q) {
-                    cA[15 + q] = rows[q * 33 + col1];
-                    cB[15 + q] = rows[q * 33 + col2];
+                    cA[15 + q] = rows[q * kRow + col1];
+                    cB[15 + q] = rows[q * kRow + col2];
                 }
-                if (p + gi0 >= 0) {
-                    float *__restrict__ dst = plane + ((size_t)g0 + (size_t)(p + gi0)) * 576 + wj;
-                    // two time slots per instruction: the same sixteen fused multiply-adds per output, in the same order, as
-                    // packed operations (v_pk_fma_f32: both halves are the IEEE fma the host's rg_mp3_mac is)
+            }
+            // a tile's operands: subbands k = 4 ks + g and 31 - k of the lane's column; the pair of a k-step is asked for
+            // again, for the next tile, as soon as its two instructions have taken it (eight chunks before it is needed)
+            float xa[4], xb[4];
+            // (one base address, every tile and k-step a constant behind it; the last tile's idle columns read what lies
+            // behind the granule's rows -- whatever it is, their results are dropped)
+            const float *const rd_lo = S + mj * kRow + mg, *const rd_hi = S + mj * kRow + 31 - mg;
+            auto load_pair = [&](const int nt, const int ks) {
+                xa[ks] = rd_lo[16 * nt * kRow + 4 * ks];
+                xb[ks] = rd_hi[16 * nt * kRow - 4 * ks];
+            };
+            if (DV) {
 #pragma unroll
-                    for (int q = 0; q < 18; q += 2) {
-                        rg_f32x2 s2 = {0.0f, 0.0f};
+                for (int ks = 0; ks < 4; ++ks) load_pair(0, ks);
+            }
+            uint32_t lo = lane_off;
+            asm volatile("" : "+v"(lo));  // (or the sum is made once, outside the loop, and its two registers are spilled: a reload and a wait for every store in flight at the top of each step)
+            // (said to be global memory: behind the asm the compiler no longer knows, and a flat store also counts as an LDS access)
+            typedef __attribute__((address_space(1))) float rg_gf32;
+            rg_gf32 *__restrict__ const dst = (rg_gf32 *)(tr.ch0 + ((size_t)g0 + (size_t)(pw + gi0)) * 576) + lo;  // (the wave's) + the lane's
+            float sum[3] = {0.0f, 0.0f, 0.0f};
+            rg_f32x4 de = {0.0f, 0.0f, 0.0f, 0.0f}, dd = {0.0f, 0.0f, 0.0f, 0.0f};
+            // the A operands come from LDS two instructions ahead of their use (resident they were eight registers the sums need)
+            float ca[2] = {0.0f, 0.0f};
+            if (DV) {
+                ca[0] = cos_at[0];
+                ca[1] = cos_at[256];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            s2 = __builtin_elementwise_fma(rg_f32x2{cA[q + 15 - 2 * i], cA[q + 16 - 2 * i]}, rg_f32x2{D1[i], D1[i]}, s2);
-                            s2 = __builtin_elementwise_fma(rg_f32x2{cB[q + 14 - 2 * i], cB[q + 15 - 2 * i]}, rg_f32x2{D2[i], D2[i]}, s2);
+            for (int nt = 0; nt < 3; ++nt) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                    for (int par = 0; par < 2; ++par) {
+                        if (DV) {
+                            const rg_f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+                            if (par == 0) {
+                                de = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[0], xa[ks] + xb[ks], ks == 0 ? zero : de, 0, 0, 0);
+                                ca[0] = cos_at[64 * ((ks + 1) & 3)];
+                            } else {
+                                dd = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[1], xa[ks] - xb[ks], ks == 0 ? zero : dd, 0, 0, 0);
+                                ca[1] = cos_at[256 + 64 * ((ks + 1) & 3)];
+                                if (nt < 2) load_pair(nt + 1, ks);
+                            }
                         }
-                        dst[(size_t)q * 32] = s2.x;
-                        dst[(size_t)(q + 1) * 32] = s2.y;
+                        if (WM == 2) {
+                            // chunk m of 24: time slots 3 (m / 4) .. + 2, terms i = 2 (m % 4), 2 (m % 4) + 1 of their sixteen
+                            const int m = nt * 8 + ks * 2 + par, q0 = 3 * (m / 4), pp = m % 4;
+#pragma unroll
+                            for (int ii = 0; ii < 2; ++ii) {
+                                const int i = 2 * pp + ii;
+#pragma unroll
+                                for (int j = 0; j < 3; ++j) {
+                                    if (i == 0) sum[j] = 0.0f;
+                                    sum[j] = rg_mp3_mac(cA[q0 + j + 15 - 2 * i], D1[i], sum[j]);
+                                    sum[j] = rg_mp3_mac(cB[q0 + j + 14 - 2 * i], D2[i], sum[j]);
+                                }
+                            }
+                            if (pp == 3) {
+#pragma unroll
+                                for (int j = 0; j < 3; ++j) dst[(q0 + j) * 32] = sum[j];
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                if (DV) {  // the tile's results into the rows (its last instruction has had the twelve sums behind it to finish)
+                    if (16 * nt + mj < ncols) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) *reinterpret_cast<float2 *>(wr + 16 * nt * kRow + 2 * v) = make_float2(de[v], dd[v]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (WM >= 1) {
 #pragma unroll
                 for (int q = 0; q < 15; ++q) { cA[q] = cA[q + 18]; cB[q] = cB[q + 18]; }
+            }
+        };
+        rg_lds_barrier();
+        for (int k = 0; k < nsteps + kTail; ++k) {
+            RG_BH_STAMP(3, k, 0);
+            const int pd = k - 3, pw = k - 4;
+            const bool dv = pd >= pd0 && pd < nsteps;
+            const int wm = (pw >= pd0 && pw < nsteps) ? (pw + gi0 >= 0 ? 2 : 1) : 0;
+            using std::integral_constant;
+            if (dv) {
+                if (wm == 2) w3_step(std::true_type{}, integral_constant<int, 2>{}, k);
+                else if (wm == 1) w3_step(std::true_type{}, integral_constant<int, 1>{}, k);
+                else w3_step(std::true_type{}, integral_constant<int, 0>{}, k);
+            } else if (wm == 2) {
+                w3_step(std::false_type{}, integral_constant<int, 2>{}, k);
+            } else if (wm == 1) {
+                w3_step(std::false_type{}, integral_constant<int, 1>{}, k);
             }
             RG_BH_STAMP(3, k, 1);
             rg_lds_barrier();
@@ -884,6 +1010,7 @@ constexpr int kHuffThreads = RG_HF_THREADS;
 #endif
 struct BitRing {
     static constexpr uint32_t kWords = RG_HF_RING, kMask = RG_HF_RING - 1, kFeed = RG_HF_RING / 2;  // words per feed
+    static_assert(4 * (kWords + kFeed) + 32 <= RG_MP3_READ_AHEAD_BYTES, "the buffers are reserved with RG_MP3_READ_AHEAD_BYTES behind their payload");
     uint32_t *__restrict__ ring;     // the thread's column: word i of the stream at ring[(i & kMask) * kHuffThreads]
     const uint4 *__restrict__ g;     // the next group to ask for (the track's main data is 16-byte aligned)
     uint4 c[kFeed / 4];              // the groups in flight: words filled .. filled + kFeed - 1
@@ -1349,7 +1476,9 @@ rg_mp3_frames_kernel(const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks
     const uint32_t tile = blockIdx.x - tr.tile_base;
     const uint32_t f = tile * RG_MP3_FRAME_TILE + threadIdx.x;
     const bool live = f < tr.n_frames;
-    uint64_t raw[RG_MP3_SLOT_BYTES / 8];
+    // (the frame's forty bytes too: the side-information reader walks them with a running bit position)
+    __shared__ uint64_t raw_all[RG_MP3_FRAME_TILE][RG_MP3_SLOT_BYTES / 8];
+    uint64_t *const raw = raw_all[threadIdx.x];
     uint32_t main_bytes = 0;
     if (live) {
         const uint64_t *src = reinterpret_cast<const uint64_t *>(chunk + tr.slots_base + (size_t)f * RG_MP3_SLOT_BYTES);  // 8-byte aligned
@@ -1361,7 +1490,10 @@ rg_mp3_frames_kernel(const RgMp3DevTrack *__restrict__ tracks, uint32_t n_tracks
     uint32_t total;
     const uint32_t have_excl = block_scan256(main_bytes, &total, wave_sum);
     const uint64_t have = reinterpret_cast<const uint64_t *>(chunk + tr.tiles_base)[tile] + have_excl;
-    RgMp3HuffRec r[4];
+    // A frame's (up to four) records wait in LDS, a slice per thread: rg_mp3_frame_records -- the host's code -- fills them
+    // through a running index, which as a private array is 208 bytes of scratch memory per thread (rounds 4-5).
+    __shared__ RgMp3HuffRec r_all[RG_MP3_FRAME_TILE][4];
+    RgMp3HuffRec *const r = r_all[threadIdx.x];
     uint32_t n = 0;
     if (live) {
         uint32_t mb;

@@ -96,6 +96,9 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
             t.lsf = it.lsf;
             t.ch0 = it.d_ch0;
             t.ch1 = it.d_ch1;
+            // the back half addresses a lane's PCM as the first plane + 32 bits (rg_mp3dev.hip, wave 3)
+            if (t.ch1 && (uint64_t)(t.ch1 - t.ch0) >= (1ull << 30))
+                return rg_set_err(c, RG_ERR_INVALID_ARG, "a track of 2^30 frames or more per channel cannot take the device decoder (rg_set_tuning(ctx, 6, 0) selects the host decoder)");
             t.run_base = hb;
             hb += (t.n_granules + RG_MP3_RUN - 1) / RG_MP3_RUN;
             t.main_base = mainb;
@@ -109,8 +112,8 @@ int rg_mp3dev_decode(rg_ctx *c, const RgMp3SplitItem *items, size_t n, hipStream
             RG_HIP(c, c->d_mp3_tracks.reserve(tr.size() * sizeof(RgMp3DevTrack)));
             if (any_recs) {
                 RG_HIP(c, c->d_mp3_recs.reserve(units * sizeof(RgMp3HuffRec)));
-                RG_HIP(c, c->d_mp3_main.reserve(mainb + 64));
-                RG_HIP(c, hipMemsetAsync(c->d_mp3_main.p + mainb, 0, 64, s));  // the bit reader looks a few bytes ahead
+                RG_HIP(c, c->d_mp3_main.reserve(mainb + RG_MP3_READ_AHEAD_BYTES));
+                RG_HIP(c, hipMemsetAsync(c->d_mp3_main.p + mainb, 0, RG_MP3_READ_AHEAD_BYTES, s));  // the bit reader runs ahead (rg_mp3dev.h)
             }
             for (size_t i = first; i < last; ++i) {
                 const RgMp3SplitItem &it = items[i];
@@ -205,6 +208,8 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
         t.lsf = it.lsf;
         t.ch0 = it.d_ch0;
         t.ch1 = it.channels == 2 ? it.d_ch0 + (size_t)granules * 576 : nullptr;
+        if (t.ch1 && (uint64_t)granules * 576 >= (1ull << 30))  // (the planes lie 32 bits apart at most: rg_mp3dev.hip, wave 3)
+            return rg_set_err(c, RG_ERR_INVALID_ARG, "a track of 2^30 frames or more per channel cannot take the device decoder (rg_set_tuning(ctx, 6, 0) selects the host decoder)");
         t.main_base = it.main_off;
         t.run_base = hb;
         t.n_frames = it.n_frames;
@@ -215,7 +220,7 @@ int rg_mp3dev_enqueue_chunk(rg_ctx *c, int set, uint8_t *staging, size_t bytes, 
         hb += (granules + RG_MP3_RUN - 1) / RG_MP3_RUN;
     }
     // grow-only buffers; growing one frees the old allocation, which waits for the kernels still using it
-    RG_HIP(c, c->d_mp3_stage[set].reserve(bytes + 64));
+    RG_HIP(c, c->d_mp3_stage[set].reserve(bytes + RG_MP3_READ_AHEAD_BYTES));  // the main data is the block's first part: the reader runs ahead into the rest or past it
     if (ub) {
         RG_HIP(c, c->d_mp3_is.reserve(ub * (RG_MP3_ROW_BYTES / 2) + 64));
         RG_HIP(c, c->d_mp3_units.reserve(ub * sizeof(rg_mp3_unit)));

@@ -13,6 +13,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent))
 from wavutil import planar_for_oracle, test_signal, wav_bytes  # noqa: E402
 
 test_signal.__test__ = False
+ROOT = Path(__file__).resolve().parent.parent
 pytestmark = pytest.mark.gpu
 DB_TOL = 0.1
 
@@ -163,3 +164,26 @@ def test_large_stereo_files_fast_paths(an, oracle, tmp_path):
         got = an.analyze_wav_bytes([wav_bytes(chans, rate, kind, extra_chunks=False)])[0]
         same = an.analyze_track(rg.PcmTrack(planar_for_oracle(chans, kind), rate))
         assert (got.loudness_db, got.peak, got.windows) == (same.loudness_db, same.peak, same.windows)
+
+
+def test_rg_create_reports_pipeline_streams_that_share_a_hardware_queue(tmp_path):
+    """INTEGRATION.md 'Hardware queues': a context times a spinning kernel on one of its pipeline streams against one on each;
+    with GPU_MAX_HW_QUEUES=1 the four streams run one after the other and the context says so (stderr, and rg_last_error until a
+    real error replaces it) -- results are unaffected; with the default four queues it is silent."""
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import mp3rgain_amd as rg\n"
+            "from mp3rgain_amd import _capi\n"
+            "an = rg.Analyzer(0)\n"
+            "print('LAST_ERROR=' + _capi.load().rg_last_error(an._ctx).decode())\n") % str(ROOT)
+    env = dict(os.environ)
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    quiet = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert quiet.returncode == 0, quiet.stderr
+    assert "share hardware queues" not in quiet.stderr and "LAST_ERROR=\n" in quiet.stdout + "\n", (quiet.stdout, quiet.stderr)
+    env["GPU_MAX_HW_QUEUES"] = "1"
+    one = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr
+    assert "share hardware queues" in one.stderr and "share hardware queues" in one.stdout, (one.stdout, one.stderr)

@@ -407,15 +407,17 @@ def test_album_parts_give_the_plain_route_results(tmp_path, monkeypatch):
 
     with rg.Analyzer(0) as an:
         an.set_kernel(0)
-        monkeypatch.setenv("RG_ALBUM_PARTS", "0")
+        # (tuning keys 10 / 11: album parts never / on, and threshold + 1 of the copy-bound rule; the environment's
+        # RG_ALBUM_PARTS / RG_PARTS_MIN_BYTES_PER_UNIT are only the defaults a context reads when it is created)
+        an.set_tuning(10, 1)
         plain = key(an.analyze_album_files(files))
         plain_wav = key(an.analyze_album_files(files[:20] + [wav] + files[20:]))
-        monkeypatch.setenv("RG_ALBUM_PARTS", "1")
-        for rule in ("0", "120", "400", "1e9"):
-            monkeypatch.setenv("RG_PARTS_MIN_BYTES_PER_UNIT", rule)
+        an.set_tuning(10, 2)
+        for rule in (0, 120, 400, 10**9):
+            an.set_tuning(11, rule + 1)
             assert key(an.analyze_album_files(files)) == plain, rule
             assert key(an.analyze_album_files(files)) == plain, rule  # (buffers in place now)
-        monkeypatch.setenv("RG_PARTS_MIN_BYTES_PER_UNIT", "0")
+        an.set_tuning(11, 1)
         assert key(an.analyze_album_files(files[:20] + [wav] + files[20:])) == plain_wav
         assert key(an.analyze_album_files(files[:1])) == key(an.analyze_album_files(files[:1]))
         with pytest.raises(rg.ReplayGainError):
@@ -425,12 +427,12 @@ def test_album_parts_give_the_plain_route_results(tmp_path, monkeypatch):
         def tkey(rs):
             return [(r.code, str(r)) if isinstance(r, rg.ReplayGainError) else (r.loudness_db, r.gain_db, r.peak, r.sample_rate, r.windows, r.file_type) for r in rs]
         with_missing = files[:7] + [tmp_path / "missing.mp3"] + files[7:]
-        monkeypatch.setenv("RG_ALBUM_PARTS", "0")
+        an.set_tuning(10, 1)
         t_plain, t_plain_missing = tkey(an.analyze_track_files(files)), tkey(an.analyze_track_files(with_missing))
         assert t_plain == [k for k in plain[:-1]]
-        monkeypatch.setenv("RG_ALBUM_PARTS", "1")
-        for rule in ("0", "120", "1e9"):
-            monkeypatch.setenv("RG_PARTS_MIN_BYTES_PER_UNIT", rule)
+        an.set_tuning(10, 2)
+        for rule in (0, 120, 10**9):
+            an.set_tuning(11, rule + 1)
             assert tkey(an.analyze_track_files(files)) == t_plain, rule
             assert tkey(an.analyze_track_files(with_missing)) == t_plain_missing, rule
 
@@ -450,8 +452,11 @@ def test_analyze_tracks_in_groups_bounded_by_memory(_ctx, tmp_path, monkeypatch)
         files.append(f)
     files.insert(5, tmp_path / "nope.mp3")
     whole = an.analyze_track_files(files)
-    monkeypatch.setenv("RG_TRACKS_GROUP_BYTES", str(24 * 70000))  # two or three files per group
-    grouped = an.analyze_track_files(files)
+    an.set_tuning(13, 24 * 70000)  # two or three files per group (RG_TRACKS_GROUP_BYTES is the default a context reads at its creation)
+    try:
+        grouped = an.analyze_track_files(files)
+    finally:
+        an.set_tuning(13, 0)
     assert len(whole) == len(grouped) == len(files)
     for f, a, b in zip(files, whole, grouped):
         if isinstance(a, rg.ReplayGainError):
@@ -474,8 +479,11 @@ def test_album_larger_than_the_device_is_analysed_in_parts(_ctx, oracle, tmp_pat
         f.write_bytes(srcs[(3 * k) % len(srcs)].read_bytes())
         files.append(f)
     whole = an.analyze_album_files(files)
-    monkeypatch.setenv("RG_TRACKS_GROUP_BYTES", str(24 * 70000))
-    parts = an.analyze_album_files(files)
+    an.set_tuning(13, 24 * 70000)
+    try:
+        parts = an.analyze_album_files(files)
+    finally:
+        an.set_tuning(13, 0)
     assert (parts.album_loudness_db, parts.album_gain_db, parts.album_peak) == (whole.album_loudness_db, whole.album_gain_db, whole.album_peak)
     for a, b in zip(whole.tracks, parts.tracks):
         assert (a.loudness_db, a.gain_db, a.peak, a.sample_rate, a.windows, a.file_type) == (b.loudness_db, b.gain_db, b.peak, b.sample_rate, b.windows, b.file_type)

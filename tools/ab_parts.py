@@ -10,11 +10,13 @@ import torch  # noqa: F401
 import mp3rgain_amd as rg
 from mp3rgain_amd import mp3dec
 calls = int(sys.argv[1]) if len(sys.argv) > 1 else 9
-CONFIGS = {"plain": {"RG_ALBUM_PARTS": "0"}, "parts": {"RG_ALBUM_PARTS": "1"}}
-for extra in os.environ.get("AB_EXTRA", "").split(";"):  # e.g. AB_EXTRA="parts_b:RG_PARTS_ONE_SHOT=0"
+# per configuration: tuning keys of the context (10: album parts 1 = never / 2 = on, 11: threshold + 1 of the copy-bound rule;
+# the RG_ALBUM_PARTS / RG_PARTS_MIN_BYTES_PER_UNIT environment is only what a context reads when it is created)
+CONFIGS = {"plain": {10: 1}, "parts": {10: 2}}
+for extra in os.environ.get("AB_EXTRA", "").split(";"):  # e.g. AB_EXTRA="parts_all:11=1"
     if extra:
         name, kv = extra.split(":")
-        CONFIGS[name] = dict(CONFIGS["parts"], **dict(x.split("=") for x in kv.split(",")))
+        CONFIGS[name] = dict(CONFIGS["parts"], **{int(x.split("=")[0]): int(x.split("=")[1]) for x in kv.split(",")})
 keys = sorted({k for c in CONFIGS.values() for k in c})
 an = rg.Analyzer(0)
 only = os.environ.get("AB_STREAM", "")
@@ -36,8 +38,7 @@ for label, src in (("128k", "tests/golden/mp3/dense_44k_joint_128.mp3"), ("vbr",
         for rep in range(calls + 2):
             for name, env in CONFIGS.items():
                 for k in keys:
-                    os.environ.pop(k, None)
-                os.environ.update(env)
+                    an.set_tuning(k, env.get(k, 0))
                 tm = {}
                 f(files, timing=tm)
                 if rep >= 2: res[name].append(tm["c_call_seconds"] * 1e3)

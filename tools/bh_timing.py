@@ -51,24 +51,28 @@ for label, src in (("dense320_synthetic", ROOT / "tests/golden/mp3/v1_44k_stereo
     assert lib.rg_bh_dbg_read(C.c_void_p(buf.ctypes.data)) == 0
     t = buf.astype(np.int64)
     print(f"== {label}: backhalf {r['ms']['backhalf'] * (1 << 18) / r['units']:.3f} ms per 256K units")
-    steps = slice(4, 32)  # the pipeline's steady part
-    period = np.diff(t[1, :, 0])[steps]
+    steps = slice(6, 30)  # the pipeline's steady part
+    # Round 6: waves 1 and 2 requantise the even and the odd granules, two steps each (first half of granule k in step k,
+    # second half in step k + 1: entry [k] of an even k is wave 1's first half, of an odd k its second half); wave 0 the
+    # IMDCT, wave 3 matrixing + window.
+    period = np.diff(t[0, :, 0])[steps]
     print(f"   step period: mean {period.mean():.0f} cycles (min {period.min()}, max {period.max()})")
-    for w in (1, 0, 2, 3):
+    for w, name in ((1, "requant even"), (2, "requant odd"), (0, "imdct"), (3, "dct + window")):
         busy = (t[w, :, 1] - t[w, :, 0])[steps]
-        print(f"   wave {w} {names[w]:8s}: busy mean {busy.mean():7.0f}  min {busy.min():6d}  max {busy.max():6d}   = {busy.mean() / period.mean() * 100:4.0f} % of the step")
+        print(f"   wave {w} {name:12s}: busy mean {busy.mean():7.0f}  min {busy.min():6d}  max {busy.max():6d}   = {busy.mean() / period.mean() * 100:4.0f} % of the step")
+    ks = np.arange(40)
+    own = np.where(ks % 2 == 0, 1, 2)  # the wave whose granule k is
+    first = np.array([t[own[k], k, 1] - t[own[k], k, 0] for k in range(40)])[steps]
+    second = np.array([t[own[k], k + 1, 1] - t[own[k], k + 1, 0] if k + 1 < 40 else 0 for k in range(40)])[steps]
+    print(f"   a granule's requantisation: first half {first.mean():.0f}, second half {second.mean():.0f} cycles")
     d2 = np.zeros((40, 6), dtype=np.uint64)
     assert lib.rg_bh_dbg2_read(C.c_void_p(d2.ctypes.data)) == 0
     d2 = d2.astype(np.int64)
-    u0 = (d2[:, 4] - t[1, :, 0])[steps]
+    t0 = np.array([t[own[k], k, 0] for k in range(40)])
+    t1b = np.array([t[own[k], k + 1, 0] if k + 1 < 40 else 0 for k in range(40)])
+    u0 = (d2[:, 4] - t0)[steps]
     u1 = (d2[:, 5] - d2[:, 4])[steps]
     u2 = (d2[:, 2] - d2[:, 5])[steps]
-    print(f"   requant wave, arrivals: the step's units in hand {u0.mean():.0f}, its spectra in hand and zeroed {u1.mean():.0f}, second-plane work {u2.mean():.0f} cycles")
-    a0 = (d2[:, 2] - t[1, :, 0])[steps]
-    a1 = (d2[:, 3] - d2[:, 2])[steps]
-    a2 = (d2[:, 0] - d2[:, 3])[steps]
-    print(f"   requant wave, top of the step: arrivals + copies {a0.mean():.0f}, big-value pre-pass {a1.mean():.0f}, prefetch issue + gains {a2.mean():.0f} cycles")
-    a = (d2[:, 0] - t[1, :, 0])[steps]
-    b = (d2[:, 1] - d2[:, 0])[steps]
-    c = (t[1, :, 1] - d2[:, 1])[steps]
-    print(f"   requant wave: units + gains {a.mean():.0f}, three rounds {b.mean():.0f}, special cases {c.mean():.0f} cycles")
+    print(f"   first half: the step's units in hand {u0.mean():.0f}, its spectra in hand and zeroed {u1.mean():.0f}, second-plane work {u2.mean():.0f},"
+          f" big-value pre-pass {(d2[:, 3] - d2[:, 2])[steps].mean():.0f}, prefetch issue + gains {(d2[:, 0] - d2[:, 3])[steps].mean():.0f} cycles")
+    print(f"   second half: three rounds {(d2[:, 1] - t1b)[steps].mean():.0f} cycles, then the special cases")

@@ -52,15 +52,12 @@ for a in range(n_albums):
     if rnd.random() < 0.05:
         files.insert(rnd.randrange(len(files) + 1), tmp / "missing.mp3")
     stage = rnd.choice(["16384", "65536", "262144", None])
-    if stage:
-        os.environ["RG_MP3_STAGE_BYTES"] = stage
-    else:
-        os.environ.pop("RG_MP3_STAGE_BYTES", None)
-    os.environ["RG_ALBUM_PARTS"] = "0"
+    an.set_tuning(12, int(stage) if stage else 0)  # staging block bytes (tuning keys 10-13: the environment is read at rg_create only)
+    an.set_tuning(10, 1)
     want_album, want_tracks = run(an.analyze_album_files, files), run(an.analyze_track_files, files)
-    os.environ["RG_ALBUM_PARTS"] = "1"
+    an.set_tuning(10, 2)
     for rule in ("0", "120", "300"):
-        os.environ["RG_PARTS_MIN_BYTES_PER_UNIT"] = rule
+        an.set_tuning(11, int(rule) + 1)
         got_album, got_tracks = run(an.analyze_album_files, files), run(an.analyze_track_files, files)
         if got_album != want_album or got_tracks != want_tracks:
             bad += 1

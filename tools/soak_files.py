@@ -31,9 +31,9 @@ free0 = None
 for r in range(rounds):
     for label, files in sets.items():
         for mode in ("album", "tracks"):
-            for env in ({"RG_ALBUM_PARTS": "0"}, {"RG_ALBUM_PARTS": "1", "RG_PARTS_MIN_BYTES_PER_UNIT": "0"}, {"RG_ALBUM_PARTS": "1"}):
-                os.environ.pop("RG_PARTS_MIN_BYTES_PER_UNIT", None)
-                os.environ.update(env)
+            for env in ({10: 1, 11: 0}, {10: 2, 11: 1}, {10: 2, 11: 0}):  # tuning keys: parts never | every chunk a part | the default rule
+                for k, v in env.items():
+                    an.set_tuning(k, v)
                 res = an.analyze_album_files(files) if mode == "album" else an.analyze_track_files(files)
                 tr = res.tracks if mode == "album" else res
                 key = [(t.loudness_db, t.peak, t.windows) for t in tr] + ([(res.album_loudness_db, res.album_peak)] if mode == "album" else [])
