@@ -1,4 +1,8 @@
 // rg_design.cpp -- see rg_design.h
+#ifndef RG_TM_H10_CUT_DEFAULT
+#define RG_TM_H10_CUT_DEFAULT 1e-10L
+#endif
+#include <stdlib.h>
 #include "rg_design.h"
 
 #include <math.h>
@@ -355,12 +359,22 @@ void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out, uint32_
                 out->ST[(size_t)n * 12 + j] = (double)tsum[j];
             }
     }
-    // H10: first multiple of 4 after which every fast response stays below 1e-13 of its maximum
+    // H10: first multiple of 4 after which every fast response stays below `cut` of its maximum.  What the cut leaves out of a
+    // moment is bounded per window in the fix-up kernel (tau10, below) and goes into the self-check's margin: a window whose
+    // bin the neglected tail could change marks its track RG_TRACK_FLAG_IMPRECISE like a cancelling one.  1e-13 (rounds 2-5) was
+    // below the rounding of the moments themselves; 1e-10 (round 6: H10 248 -> 184 frames at 44.1 kHz, 3-4 % fewer vector
+    // instructions at L = 735) is what the bound made safe -- DESIGN.md section 7 has the flag rates per cut; RG_TM_H10_CUT (read
+    // once per process: measurement) moves it.
+    static const ld cut = [] {
+        const char *e = getenv("RG_TM_H10_CUT");
+        const ld v = e ? strtold(e, nullptr) : 0.0L;
+        return (v > 0.0L && v < 1e-3L) ? v : (ld)RG_TM_H10_CUT_DEFAULT;
+    }();
     uint32_t H10 = 0;
     for (uint32_t n = L; n-- > 0;) {
         ld m = 0;
         for (int j = 0; j < 10; ++j) m = fmaxl(m, fabsl((ld)out->T[(size_t)n * 12 + j]));
-        if (m > 1e-13L * tmax) { H10 = n + 1; break; }
+        if (m > cut * tmax) { H10 = n + 1; break; }
     }
     // A multiple of 4 (the kernel consumes 4-frame pieces and a piece must not straddle H10) -- or the whole
     // segment when the fast block outlives it: the L & 3 trailing frames then keep all 12 moments too.  (Cutting
@@ -368,6 +382,11 @@ void rg_tm_design(const rg_rate_coeffs &rc, uint32_t L, RgTmDesign *out, uint32_
     // 0.2 % errors in quiet windows after loud ones for L = 150 at 24 kHz, L = 245 at 44.1 kHz.)
     H10 = (H10 + 3u) & ~3u;
     out->H10 = H10 >= L ? L : H10;
+    for (int j = 0; j < 10; ++j) {
+        ld t2 = 0;
+        for (uint32_t n = out->H10; n < L; ++n) t2 += (ld)out->T[(size_t)n * 12 + j] * (ld)out->T[(size_t)n * 12 + j];
+        out->tau10[j] = (double)(sqrtl(t2) * 1.000001L);
+    }
 
     // Phi blocks: F^L by repeated multiplication, then squarings for the doubling rounds
     ld PY[100], PB[4];

@@ -22,6 +22,8 @@ void rg_design_rate(const rg_rate_coeffs &rc, RgRateDesign *out);
 struct RgTmDesign {
     uint32_t L = 0, W = 0, m = 1;
     uint32_t H10 = 0;         // multiple of 4, <= L rounded down to a multiple of 4 (or == that bound)
+    double tau10[10] = {0};   // what the cut at H10 leaves out: tau10[j] = sqrt(sum_{n >= H10} T[n][j]^2), so that the neglected part of
+                              // a moment, |sum_{n >= H10} z[n] T[n][j]|, is at most sqrt(sum z^2) tau10[j] (the fix-up kernel's self-check)
     uint32_t rounds = 0;      // doubling rounds for the slow (Butter) block
     uint32_t rounds_fast = 0; // rounds after which the fast (Yule) block's power is below 1e-18
     std::vector<double> T;       // [L][12]  responses in block-diagonal coordinates

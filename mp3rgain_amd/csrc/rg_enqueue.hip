@@ -168,6 +168,7 @@ int get_tm_tables(rg_ctx *c, int rate_idx, uint32_t L, RgTmDeviceTables **out, u
     g.aff_lin = D.servo ? 2.0 * D.dinf / D.beta : 0.0;
     g.aff_n = D.servo ? D.dinf * D.dinf : 0.0;
     g.aff_sig = D.servo ? 2.0 * D.dinf : 0.0;
+    for (int j = 0; j < 10; ++j) g.tau10[j] = D.tau10[j];
     if (m > 1 && rg_tm_lds_bytes(D.L, D.H10, g.block, m) > RG_TM_LDS_BYTES) {  // multi-window segments run on the LDS path only
         tb->design.ok = false;
         return RG_ERR_INVALID_ARG;

@@ -280,6 +280,15 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
     typedef Fmt<FMT> F;
     typedef const __attribute__((address_space(1))) typename F::elem gelem;
     const int lane = threadIdx.x & 63;
+    // Experiment RG_TM_LINEWIDE: in the moment-free pair loop one load instruction covers 8 rows x 128
+    // bytes (a pair of tiles) instead of 16 rows x 64, so that the two 64-byte halves of a 128-byte line are asked for by ONE
+    // instruction; LDS slot 1 then holds its rows swapped in pairs (row r at 64 (r ^ 1)): a row's eight pieces, four to each
+    // slot, fall on all 32 banks.
+#ifdef RG_TM_LINEWIDE
+    constexpr bool kLineWide = !MOM && !TAIL && FMT == RG_FMT_F32_PLANAR;
+#else
+    constexpr bool kLineWide = false;
+#endif
     // loader role: instruction q covers rows 16q .. 16q+15; this lane fetches for row 16q + (lane >> 2)
     const int lrow = lane >> 2, lslot = lane & 3;
     gelem *lfirst[4];    // the piece this lane fetches in tile 0
@@ -295,6 +304,7 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
     }
     // consumer role: row == lane
     const char *const rrow = wtile + lane * 64;
+    const char *const rrow1 = wtile + RG_TM_WAVE_TILE_BYTES + (kLineWide ? lane ^ 1 : lane) * 64;
     const int rswz = (lane >> 2) & 3;
     const uint32_t ntiles = (L + RG_TM_TILE - 1) / RG_TM_TILE;
 
@@ -345,12 +355,12 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<uint4 *>(wtile + SB * RG_TM_WAVE_TILE_BYTES + q * 1024 + lane * 16) =
+            *reinterpret_cast<uint4 *>(wtile + SB * RG_TM_WAVE_TILE_BYTES + q * 1024 + (lane ^ (kLineWide && SB ? 4 : 0)) * 16) =
                 make_uint4(stage[SB][q].x, stage[SB][q].y, stage[SB][q].z, stage[SB][q].w);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    auto read_piece = [&](int p, int slot) -> uint4 { return *reinterpret_cast<const uint4 *>(rrow + slot * RG_TM_WAVE_TILE_BYTES + 16 * (p ^ rswz)); };
+    auto read_piece = [&](int p, int slot) -> uint4 { return *reinterpret_cast<const uint4 *>((slot ? rrow1 : rrow) + 16 * (p ^ rswz)); };
 
     // One tile.  MODE 1: every piece of the tile lies below H (all 12 moments live); MODE 2: every piece lies at or
     // past H (slow pair only); MODE 0: decided per piece (the one tile H falls into, and the last tile of a row);
@@ -410,7 +420,7 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
             // L & 3 trailing frames, in this (the last) tile
             for (uint32_t n = L & ~3u; n < L; ++n) {
                 const uint32_t o = n - n0;
-                const uint32_t f = *reinterpret_cast<const uint32_t *>(rrow + SLOT * RG_TM_WAVE_TILE_BYTES + 16 * ((int)(o >> 2) ^ rswz) + 4 * (o & 3));
+                const uint32_t f = *reinterpret_cast<const uint32_t *>((SLOT ? rrow1 : rrow) + 16 * ((int)(o >> 2) ^ rswz) + 4 * (o & 3));
                 if (MODE == 4) {
                     tm_frame<FMT, 0, TAIL, true, SERVO>(st, f, pk, nullptr, K, n, len);
                 } else if (n < H) {
@@ -440,10 +450,73 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
         if (tile + NSTAGE < ntiles) load_tile(tile + NSTAGE, buf, Guarded{});  // in flight during the next NSTAGE tiles' arithmetic
         compute_tile(tile, mode, buf);
     };
-    load_tile(0, S0{}, Guarded{});
     const uint32_t full_tiles = L / RG_TM_TILE;                         // tiles with four whole pieces
     uint32_t tile = 0;
+    if constexpr (MOM) load_tile(0, S0{}, Guarded{});
     if constexpr (!MOM) {
+        if constexpr (kLineWide) {
+            // instruction q, lane j: row 8 q + (j >> 3), piece j & 7 of the pair's 32 frames (pieces 0-3 = first tile -> slot 0,
+            // 4-7 = second tile -> slot 1, swizzled as always).  The rows' addresses are 32-bit offsets from the lowest row of the
+            // wave (one scalar base: eight registers, as many as the plain loader's four pointers); a wave whose rows lie more
+            // than 2 GB apart (several tracks of a huge arena) takes the plain loader.
+            const int wrow = lane >> 3, wslot = (lane >> 2) & 1, wpos = lane & 3;
+            unsigned long long lo64 = (unsigned long long)(uintptr_t)rowp;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const unsigned long long o = __shfl_xor(lo64, d, 64);
+                lo64 = o < lo64 ? o : lo64;
+            }
+            const unsigned long long wbase = __builtin_amdgcn_readfirstlane((uint32_t)lo64) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(lo64 >> 32)) << 32);
+            const unsigned long long delta = (unsigned long long)(uintptr_t)rowp - wbase;
+            const bool near = __all(delta < (1ull << 31)) && full_tiles >= 4;
+            if (near) {
+                uint32_t woff[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int row = 8 * q + wrow;
+                    woff[q] = __shfl((uint32_t)delta, row, 64) + 64u * wslot + 16u * (wpos ^ ((row >> 2) & 3));
+                }
+                const __attribute__((address_space(1))) char *const gb = (const __attribute__((address_space(1))) char *)(uintptr_t)wbase;
+                auto pair_load = [&](const uint32_t t0) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        stage[q >> 2][q & 3] = *(const __attribute__((address_space(1))) rg_u32x4u *)(gb + (size_t)t0 * (RG_TM_TILE * 4) + woff[q]);
+                };
+                auto pair_store = [&]() {
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        *reinterpret_cast<uint4 *>(wtile + wslot * RG_TM_WAVE_TILE_BYTES + ((8 * q + wrow) ^ wslot) * 64 + wpos * 16) =
+                            make_uint4(stage[q >> 2][q & 3].x, stage[q >> 2][q & 3].y, stage[q >> 2][q & 3].z, stage[q >> 2][q & 3].w);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                };
+                pair_load(0);
+                for (; tile + 3 < full_tiles; tile += 2) {
+                    pair_store();
+                    if (tile + 5 < full_tiles) {
+                        pair_load(tile + 2);
+                    } else {  // the tiles behind the last pair go the plain way
+                        load_tile(tile + 2, S0{}, Guarded{});
+                        if (tile + 3 < ntiles) load_tile(tile + 3, S1{}, Guarded{});
+                    }
+                    compute_tile(tile, None{}, S0{});
+                    compute_tile(tile + 1, None{}, S1{});
+                }
+            } else {
+                load_tile(0, S0{}, Guarded{});
+                if (ntiles > 1) load_tile(1, S1{}, Guarded{});
+                for (; tile + 3 < full_tiles; tile += 2) {
+                    store_tile(S0{});
+                    store_tile(S1{});
+                    load_tile(tile + 2, S0{}, Whole{});
+                    load_tile(tile + 3, S1{}, Whole{});
+                    compute_tile(tile, None{}, S0{});
+                    compute_tile(tile + 1, None{}, S1{});
+                }
+            }
+        } else {
+        load_tile(0, S0{}, Guarded{});
         if (ntiles > 1) load_tile(1, S1{}, Guarded{});
         // pairs of whole tiles (the staging set is a compile-time choice: registers cannot be indexed): both to LDS, the
         // next pair's eight loads issued together, two tiles of arithmetic under them
@@ -454,6 +527,7 @@ __device__ __forceinline__ void tm_fast_path(TmLane<1> &st, typename Fmt<FMT>::p
             load_tile(tile + 3, S1{}, Whole{});
             compute_tile(tile, None{}, S0{});
             compute_tile(tile + 1, None{}, S1{});
+        }
         }
         // what is left, tile by tile: up to three whole tiles and the ragged last one; `tile` is even at every turn
         while (tile < ntiles) {
@@ -731,6 +805,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     __shared__ uint64_t pct_scan[RG_PCT_THREADS];
     __shared__ double pieces[RG_TM_BLOCK];
     __shared__ double pieces_m[RG_TM_BLOCK];  // A + sigma'G sigma of the same segments: what the sum was assembled from
+    __shared__ double pieces_e[RG_TM_BLOCK];  // bound on what the cut of the fast moments at H10 left out of the segment's sum
     __shared__ int is_last;
     // the (at most one) segment of this block that the track ends in: its start state and length, for the
     // cooperative evaluation of its quadratic term below
@@ -873,7 +948,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
         for (int j = 0; j < RG_TM_DIM; ++j) sgm[c][j] = from_below(w[c][j], 1, c * RG_TM_DIM + j);
 
     TM_FIX_STAMP(2);
-    double S = 0.0, Mseg = 0.0;
+    double S = 0.0, Mseg = 0.0, Eseg = 0.0;
     if (owner) {
         const uint64_t start = (uint64_t)seg * G.L * G.m;  // the moments cover the segment's first window (all of it when m == 1)
         const uint64_t rem = tr.frames - start;
@@ -891,6 +966,12 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
             pk = fmax(pk, r[(size_t)25 * total_recs]);
             S += r[0];
             Mseg += r[0];
+            // the fast moments stop at H10: |sum_{n >= H10} z T_j| <= sqrt(sum z^2) tau_j (Cauchy-Schwarz; r[0] is the zero-state
+            // energy, in servo form with its tiny affine terms), times 2 |sigma_j| in the window's sum
+            double st = 0.0;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) st = fma(fabs(sgm[c][j]), G.tau10[j], st);
+            Eseg = fma(2.0 * st, sqrt(fabs(r[0])) * 1.0001, Eseg);
         }
         // full segments share one Gram matrix (LDS broadcast reads, one row at a time for all channels: the
         // scheduling fences keep the compiler from hoisting all 78 reads into registers).  The segment a
@@ -966,6 +1047,7 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     }
     pieces[i] = owner ? S : 0.0;
     pieces_m[i] = owner ? Mseg : 0.0;
+    pieces_e[i] = owner ? Eseg : 0.0;
     __syncthreads();
     if (wave == 0 && part_len != 0) {
         // term p of the packed upper triangle is G[p] s_j s_q (halved on the diagonal); two terms per lane
@@ -1014,12 +1096,13 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
     if ((uint32_t)i < G.fix_windows) {
         const uint64_t widx = ((uint64_t)b * G.fix_windows + i) * G.m;  // m > 1: k == 1, the segment's first window
         if (widx < tr.n_windows) {
-            double total = 0.0, mtot = 0.0;
+            double total = 0.0, mtot = 0.0, etot = 0.0;
             for (uint32_t q = 0; q < G.k; ++q) {
                 total += pieces[warm + i * G.k + q];
                 mtot += pieces_m[warm + i * G.k + q];
+                etot += pieces_e[warm + i * G.k + q];
             }
-            if (NCH == 1) total *= 2.0;  // add_mono_sample feeds both sums (src/replaygain.rs:731-740)
+            if (NCH == 1) { total *= 2.0; etot *= 2.0; }  // add_mono_sample feeds both sums (src/replaygain.rs:731-740)
             // a sum of squares is never negative; A + 2 B.sigma + sigma'G sigma of a window whose true energy is
             // far below the energy of the filter state (the high-passed tail of a DC offset, say) can come out a
             // rounding error below zero, and log10 of that would be a NaN window.  (A NaN stays a NaN.)
@@ -1028,8 +1111,10 @@ rg_tm_fix_kernel(const RgTmGeom G, const RgTmFixTables FT, const RgTmTrack *__re
             const uint32_t n = rem < G.W ? (uint32_t)rem : G.W;
             bin = rg_window_bin(total, 0.0, n);
             // could rounding have put this window into another bin?  (NaN compares false: a NaN window is exact)
-            if (mtot > 1.0e3 * total) {
-                const double e = RG_TM_CEPS * mtot;
+            // ... or the tail of the fast moments behind H10?  (etot is far below the rounding of `total` at the design's default
+            // cut, 1e-13: the second test is then never taken)
+            if (mtot > 1.0e3 * total || etot > 1.0e-13 * total) {
+                const double e = (mtot > 1.0e3 * total ? RG_TM_CEPS * mtot : 0.0) + etot;
                 const double lo = total - e;
                 cancelled = rg_window_bin(lo < 0.0 ? 0.0 : lo, 0.0, n) != rg_window_bin(total + e, 0.0, n);
             }

@@ -112,6 +112,7 @@ struct RgTmGeom {
     uint32_t servo;        // the Butterworth stage runs in servo form and the lanes are linear (RgTmCoef)
     double aff_lin, aff_n; // servo: the affine term of a window, see RgTmCoef (0 otherwise)
     double aff_sig;        // servo: 2 d_inf -- times (start state . sum of the responses) for the window the moments cover
+    double tau10[10];      // tail norms of the fast responses behind H10 (rg_design.h): the self-check's bound on what the cut leaves out
     const double *T;       // [L][12] homogeneous responses, block-diagonal coordinates
     const double *Tlds;    // the same packed for LDS: [H10][12] then [L - H10][2] (only the slow pair)
 };
