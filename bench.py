@@ -52,7 +52,7 @@ ALGO_BYTES_PER_FRAME = 8           # 2 channels x f32, read once (SURVEY.md sect
 ALGO_FLOP_PER_FRAME = 108          # 2 x (21 + 5 + 1) FMA
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6            # MI355X FP64 vector: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 class _DevArray:

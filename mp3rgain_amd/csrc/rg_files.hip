@@ -1050,7 +1050,8 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
             d.format = RG_FMT_F32_PLANAR;
         }
         // on the decode's stream (behind the decode of the chunk after this part's), with the buffers of the next pipeline slot:
-        // one batch in flight at a time (cost model: one_shot), and no slot's pinned descriptors are waited for
+        // one batch in flight at a time (cost model: one_shot); with three or more slots (the callers' condition for parts) the
+        // slot taken here had its last descriptor copy two parts ago, so its pinned descriptors are not waited for
         c->enqueue_wait_ev = P.part_ev[2 * index];
         c->enqueue_stream = fs;
         const bool one_shot_before = c->one_shot;
@@ -1306,7 +1307,9 @@ extern "C" int rg_analyze_album_begin(rg_ctx *c, const char *const *paths, size_
         // album parts (PartsRun): one album that fits the device, decoded by the loader pipeline, nobody else's stream involved
         const bool parts_on = c->parts_on();  // RG_ALBUM_PARTS=0 / tuning key 10 = 1: never (tests, measurements)
         PartsRun parts;
-        const bool use_parts = parts_on && groups.size() <= 1 && cnt > 0 && c->gpu_mp3_decode >= 3 && !c->user_attached;
+        // (with fewer than three pipeline slots -- tuning key 3 -- a part's enqueue would find its slot's pinned descriptors still
+        // being copied behind the decode just issued and the drive thread would sit that decode out: no parts then)
+        const bool use_parts = parts_on && c->n_slots >= 3 && groups.size() <= 1 && cnt > 0 && c->gpu_mp3_decode >= 3 && !c->user_attached;
         if (use_parts)  // the parts use every slot's buffers on the decode's stream: nothing of an earlier batch may be in flight
             for (int k = 0; k < RG_SLOT_STREAMS; ++k) RG_HIP(c, hipStreamSynchronize(c->slots[k].stream));
         c->file_track_index = track_index;
@@ -1377,7 +1380,7 @@ static int analyze_tracks_group(rg_ctx *c, const char *const *paths, size_t firs
     // parts (PartsRun), track mode: every file of the group has to come through the loader pipeline for them to count
     PartsRun parts;
     parts.album = 0;
-    const bool use_parts = c->parts_on() && n > 0 && c->gpu_mp3_decode >= 3 && !c->user_attached;
+    const bool use_parts = c->parts_on() && c->n_slots >= 3 && n > 0 && c->gpu_mp3_decode >= 3 && !c->user_attached;
     if (use_parts)
         for (int k = 0; k < RG_SLOT_STREAMS; ++k) RG_HIP(c, hipStreamSynchronize(c->slots[k].stream));
     c->file_track_index = track_index;

@@ -1047,21 +1047,21 @@ extern "C" void rg_mp3_fill_device_huff(RgMp3DevHuff *o) {
         if (t > 16 && t < 24) { o->base[t] = o->base[16]; continue; }
         if (t > 24) { o->base[t] = o->base[24]; continue; }
         const size_t n = T.huff[t].e.size();
-        if (at + n > sizeof o->e / sizeof o->e[0]) abort();
+        if (at + n > sizeof o->e / sizeof o->e[0]) { o->n_entries = 0xFFFFFFFFu; return; }  // (the caller's "do not fit": rg_mp3dev_host.hip ensure_tables)
         memcpy(o->e + at, T.huff[t].e.data(), n * sizeof(uint32_t));
         at += (uint32_t)n;
     }
     o->n_entries = at;
-    if (at + 2 > RG_MP3_HUFF_LDS_ENTRIES) abort();  // two zero entries follow the tables (rg_mp3dev.hip: a table that codes nothing)
+    if (at + 2 > RG_MP3_HUFF_LDS_ENTRIES) return;  // two zero entries follow the tables (rg_mp3dev.hip: a table that codes nothing); the caller refuses
     for (uint32_t i = 0; i < at; ++i) {  // the 16-bit image (rg_mp3dev.h)
         const uint32_t e = o->e[i];
         if (e & 0x80000000u) {
             const uint32_t sub = e & 0xFFu, off = (e >> 8) & 0x7FFFFFu;
-            if (sub > 15 || off > 2047) abort();
+            if (sub > 15 || off > 2047) { o->n_entries = 0xFFFFFFFFu; return; }  // does not fit the 16-bit image: the caller refuses
             o->e16[i] = (uint16_t)(0x8000u | sub | (off << 4));
         } else {
             const uint32_t len = e & 0xFFu, xy = (e >> 8) & 0xFFu;
-            if (len > 15) abort();
+            if (len > 15) { o->n_entries = 0xFFFFFFFFu; return; }
             o->e16[i] = (uint16_t)(len | (xy << 4));
         }
     }

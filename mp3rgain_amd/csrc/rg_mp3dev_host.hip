@@ -55,7 +55,7 @@ static int ensure_tables(rg_ctx *c) {
         RG_HIP(c, e);
         RgMp3DevHuff *hf = new RgMp3DevHuff();
         rg_mp3_fill_device_huff(hf);
-        if (hf->n_entries + 2 > RG_MP3_HUFF_LDS_ENTRIES) {
+        if (hf->n_entries == 0xFFFFFFFFu || hf->n_entries + 2 > RG_MP3_HUFF_LDS_ENTRIES) {  // (the sentinel: an entry the 16-bit image cannot hold)
             const uint32_t ne = hf->n_entries;
             delete hf;
             return rg_set_err(c, RG_ERR_DEVICE, "Huffman tables (%u entries) do not fit the kernel's LDS image", ne);
