@@ -899,7 +899,38 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
             rg_f32x4 de = {0.0f, 0.0f, 0.0f, 0.0f}, dd = {0.0f, 0.0f, 0.0f, 0.0f};
             // the A operands come from LDS two instructions ahead of their use (resident they were eight registers the sums need)
             float ca[2] = {0.0f, 0.0f};
+#ifdef RG_BH_MFMA_BATCH  // experiment: the 24 matrix instructions tile by tile, eight back to back, BEFORE the sums
             if (DV) {
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) {
+                    float cw[2][4], bu[4], bv[4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        if (nt > 0) load_pair(nt, ks);
+                        cw[0][ks] = cos_at[64 * ks];
+                        cw[1][ks] = cos_at[256 + 64 * ks];
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) { bu[ks] = xa[ks] + xb[ks]; bv[ks] = xa[ks] - xb[ks]; }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const rg_f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        de = __builtin_amdgcn_mfma_f32_16x16x4f32(cw[0][ks], bu[ks], ks == 0 ? zero : de, 0, 0, 0);
+                        dd = __builtin_amdgcn_mfma_f32_16x16x4f32(cw[1][ks], bv[ks], ks == 0 ? zero : dd, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (16 * nt + mj < ncols) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) *reinterpret_cast<float2 *>(wr + 16 * nt * kRow + 2 * v) = make_float2(de[v], dd[v]);
+                    }
+                }
+            }
+            constexpr bool DVL = false;
+#else
+            constexpr bool DVL = DV;
+#endif
+            if (DVL) {
                 ca[0] = cos_at[0];
                 ca[1] = cos_at[256];
             }
@@ -910,7 +941,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                 for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
                     for (int par = 0; par < 2; ++par) {
-                        if (DV) {
+                        if (DVL) {
                             const rg_f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
                             if (par == 0) {
                                 de = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[0], xa[ks] + xb[ks], ks == 0 ? zero : de, 0, 0, 0);
@@ -942,7 +973,7 @@ rg_mp3_backhalf_kernel(const RgMp3DevTables *__restrict__ T, const RgMp3DevTrack
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                if (DV) {  // the tile's results into the rows (its last instruction has had the twelve sums behind it to finish)
+                if (DVL) {  // the tile's results into the rows (its last instruction has had the twelve sums behind it to finish)
                     if (16 * nt + mj < ncols) {
 #pragma unroll
                         for (int v = 0; v < 4; ++v) *reinterpret_cast<float2 *>(wr + 16 * nt * kRow + 2 * v) = make_float2(de[v], dd[v]);
