@@ -271,7 +271,7 @@ def mp3_end_to_end(an, nfiles: int) -> dict:
         leg["tracks_flagged_imprecise"] = {"tracks": 16, "flagged": sum(1 for r in rf if r.flags & 2),
                                            "async_pair_ms": t_async * 1e3, "synchronous_call_ms": t_sync * 1e3,
                                            "note": "decoded PCM of one of the files, 16 copies resident in HBM; the synchronous call repeats a batch "
-                                                   "that has a flagged track with it on the order-faithful kernel; profiles/r05_flag_rate.txt has "
+                                                   "that has a flagged track with it on the order-faithful kernel; profiles/r06_h10_flag_rate.txt has "
                                                    "every golden stream"}
         del dev
     except Exception as ex:  # noqa: BLE001
