@@ -192,7 +192,7 @@ int rg_set_kernel(rg_ctx *ctx, int variant);
  * keys 10-13 = routing of the file-level entry points, per context (their defaults come from the environment as it was when
  * the context was created -- RG_ALBUM_PARTS, RG_PARTS_MIN_BYTES_PER_UNIT, RG_MP3_STAGE_BYTES, RG_TRACKS_GROUP_BYTES,
  * INTEGRATION.md -- and the library never calls getenv after rg_create): key 10 = album parts: 1 =
- * never, 2 = on; key 11 = the copy-bound rule of the parts, compressed bytes per granule-channel from which a chunk
+ * never, 2 = on, 3 = on for copy-bound chunks only (not for chunks the device had to wait for the host's loaders for); key 11 = the copy-bound rule of the parts, compressed bytes per granule-channel from which a chunk
  * becomes a part, PLUS ONE (1 = every chunk); key 12 = bytes of a pinned staging block (>= 4096); key 13 = estimated PCM
  * bytes per group of files of rg_analyze_tracks / rg_analyze_album.
  * (Key 9 of ABI 4 -- windows 2..m in a kernel of their own -- is gone with that kernel: it spilled and was never faster.) */

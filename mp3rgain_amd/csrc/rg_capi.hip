@@ -392,7 +392,7 @@ extern "C" int rg_set_tuning(rg_ctx *c, int key, int64_t value) {
         case RG_TUNE_GPU_MP3_DECODE: c->gpu_mp3_decode = value > 3 ? 3 : (int)value; return RG_OK;
         case RG_TUNE_LOADER_THREADS: c->loader_threads = (unsigned)(value > 1024 ? 1024 : value); return RG_OK;
         case RG_TUNE_ALBUM_PARTS:
-            if (value > 2) return rg_set_err(c, RG_ERR_INVALID_ARG, "tuning key 10 takes 0 (default), 1 (never) or 2 (on)");
+            if (value > 3) return rg_set_err(c, RG_ERR_INVALID_ARG, "tuning key 10 takes 0 (default), 1 (never), 2 (on) or 3 (on, copy-bound chunks only)");
             c->tune_album_parts = (int)value;
             return RG_OK;
         case RG_TUNE_PARTS_MIN_BPU: c->tune_parts_min_bpu = value; return RG_OK;

@@ -195,11 +195,12 @@ struct rg_ctx {
     double hw_queue_serial = 0.0;            // rg_create's finding: time of a spinning kernel on every pipeline stream / on one (1 = own queues, 4 = one queue)
     bool trace_files = false;                // RG_TRACE_FILES
     int trace_tm = 0;                        // RG_TRACE_TM: 1 = the segment chooser's decision, 2 = every candidate
-    int tune_album_parts = 0;                // key 10: 0 = default, 1 = never, 2 = whenever the rule allows
+    int tune_album_parts = 0;                // key 10: 0 = default, 1 = never, 2 = whenever a rule allows, 3 = the copy-bound rule only
     int64_t tune_parts_min_bpu = 0;          // key 11: threshold + 1 (1 = every chunk is a part), 0 = default
     size_t tune_stage_bytes = 0;             // key 12
     size_t tune_group_bytes = 0;             // key 13
-    bool parts_on() const { return tune_album_parts ? tune_album_parts == 2 : env_parts_on; }
+    bool parts_on() const { return tune_album_parts ? tune_album_parts >= 2 : env_parts_on; }
+    bool parts_when_starved() const { return tune_album_parts != 3; }  // a chunk the device had to wait for is a part as well
     double parts_min_bpu() const { return tune_parts_min_bpu ? (double)(tune_parts_min_bpu - 1) : env_parts_min_bpu; }
     size_t stage_bytes() const { return tune_stage_bytes ? tune_stage_bytes : env_stage_bytes; }
     size_t group_bytes() const { return tune_group_bytes ? tune_group_bytes : env_group_bytes; }

@@ -615,9 +615,10 @@ int load_audio_for_impl(const std::string &decoder_cmd, int gpu_decode, const ch
 // =================================================================================================
 // The loader pipeline of tuning key 6 = 3 (the default).
 //
-// Host threads do the least an MPEG stream allows: read the file, walk its frame headers, and strip headers and side
-// information from the main data (rg_mp3_compact_stream).  Each stream's main data and slots go into a pinned staging
-// block; a block that is full (or holds enough granules to fill the GPU) is a chunk, and the calling thread sends chunks
+// Host threads do the least an MPEG stream allows: read the file, walk its frame headers (rg_mp3_walk_stream: a list of
+// frames, nothing moves), and -- once the list says how many bytes the stream needs and a place in a pinned staging block is
+// theirs -- write main data without headers and side information, and one slot per frame, straight into the block
+// (rg_mp3_gather_stream).  A block that is full (or holds enough granules to fill the GPU) is a chunk, and the calling thread sends chunks
 // to the device as they close: one H2D copy on the copy stream, then the frame parser, Huffman and back-half
 // kernels on the file stream, writing PCM straight into the analysis arena.  Three staging blocks and two device copies
 // rotate, so reading files, copying chunk k + 1 and decoding chunk k overlap.  How many frames of a stream decode is the
@@ -632,6 +633,7 @@ struct Mp3Scratch {
     size_t cap = 0;
     std::vector<uint8_t> slots;
     std::vector<uint64_t> tiles;
+    std::vector<uint64_t> frames;  // rg_mp3_walk_stream's list
 };
 struct Mp3Pipe {
     static constexpr int NSTAGE = 3;
@@ -864,7 +866,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         rg_mp3_stream_info si;
         uint64_t main_len = 0;
         const double tl1 = trace ? now() : 0.0;
-        if (mp4 || rg_mp3_compact_stream(sc.p, len, &sc.slots, &sc.tiles, &main_len, &si) != RG_MP3DEC_OK || si.audio_frames == 0) {
+        if (mp4 || rg_mp3_walk_stream(sc.p, len, &sc.frames, &main_len, &si) != RG_MP3DEC_OK || si.audio_frames == 0) {
             (*rcs)[i] = load_audio_for(cmd, 2, path, &la, &err, track_index);  // the decoder command, or the reference's probe error
             return;
         }
@@ -876,7 +878,8 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         la.result_index = (uint32_t)i;
         la.staged = true;
         const uint64_t units = (uint64_t)si.audio_frames * (la.lsf ? 1u : 2u) * si.channels;
-        const size_t slot_bytes = sc.slots.size(), tile_bytes = sc.tiles.size() * sizeof(uint64_t);
+        const size_t n_walked = sc.frames.size();
+        const size_t slot_bytes = n_walked * RG_MP3_SLOT_BYTES, tile_bytes = (n_walked + RG_MP3_FRAME_TILE - 1) / RG_MP3_FRAME_TILE * sizeof(uint64_t);
         const size_t need = align64((size_t)main_len + 8) + align64(slot_bytes) + align64(tile_bytes);
         PipeFile &f = pf[i];
         f.main_len = main_len;
@@ -947,10 +950,10 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
             dst = P.stage[chunk->stage].p;
         }
         const double tl3 = trace ? now() : 0.0;
-        memcpy(dst + f.main_off, sc.p, (size_t)main_len);
+        // main data, slots and tiles straight from the file's bytes into the block (one pass: rg_mp3dec.cpp)
+        rg_mp3_gather_stream(sc.p, sc.frames.data(), n_walked, dst + f.main_off, dst + f.slots_off, reinterpret_cast<uint64_t *>(dst + f.tiles_off));
         memset(dst + f.main_off + main_len, 0, (size_t)(f.slots_off - f.main_off - main_len));  // the bit reader looks a few bytes ahead
-        memcpy(dst + f.slots_off, sc.slots.data(), slot_bytes);
-        memcpy(dst + f.tiles_off, sc.tiles.data(), tile_bytes);
+        memset(dst + f.slots_off + slot_bytes, 0, (size_t)(f.tiles_off - f.slots_off - slot_bytes));
         if (trace) {
             const double tl4 = now();
             t_read += (uint64_t)((tl1 - tl0) * 1e6);
@@ -1016,12 +1019,15 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
     // the tracks of chunk `index` (decode enqueued, the chunk after it too) as one part of the album
     const double copy_bound_at = parts ? c->parts_min_bpu() : 0.0;
     // `ch` (may be null: nothing new) joins what is pending; `index`: the newest chunk whose files are pending or were
-    auto analyze_part = [&](const PipeChunk *ch, size_t index, bool last) -> int {
+    // `starved`: when the chunk after `ch` was ready to be sent, the device had already finished `ch`'s decode, i.e. it is the
+    // host's loaders the call is waiting for (few of them: one loader thread reads and walks 6 GB/s of VBR files, the device
+    // takes 17): the analysis of the files so far costs nothing while it waits.
+    auto analyze_part = [&](const PipeChunk *ch, size_t index, bool last, bool starved) -> int {
         if (!parts || parts->broken) return RG_OK;
         bool copy_bound = false;
         if (ch) {
             parts->pending.insert(parts->pending.end(), ch->files.begin(), ch->files.end());
-            copy_bound = ch->units && (double)ch->used / (double)ch->units >= copy_bound_at;
+            copy_bound = (ch->units && (double)ch->used / (double)ch->units >= copy_bound_at) || starved;
         }
         if (!copy_bound && !(last && parts->n_parts)) {
             if (last) parts->broken = true;  // no chunk of the album was copy-bound: the plain route, one launch over all of it
@@ -1091,7 +1097,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
                 if (next >= R.chunks.size()) {
                     if (result == RG_OK && parts) {
                         lk.unlock();
-                        const int r = analyze_part(prev, prev_index, true);
+                        const int r = analyze_part(prev, prev_index, true, false);
                         lk.lock();
                         if (r != RG_OK) result = r;
                         prev = nullptr;
@@ -1104,9 +1110,10 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
             const size_t done_now = R.files_done;
             lk.unlock();
             const double t_i = now();
+            const bool starved = parts && !parts->broken && prev && c->parts_when_starved() && hipEventQuery(P.part_ev[2 * prev_index]) == hipSuccess;
             int r = (result == RG_OK && !ch.files.empty()) ? issue(ch, next) : RG_OK;
             if (r == RG_OK && result == RG_OK && prev) {  // the device has this chunk's decode to go on with
-                r = analyze_part(prev, prev_index, false);
+                r = analyze_part(prev, prev_index, false, starved);
                 prev = nullptr;
             }
             if (r == RG_OK && result == RG_OK && !ch.files.empty()) {
@@ -1114,8 +1121,9 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
                 prev_index = next;
             }
             if (trace)
-                fprintf(stderr, "[pipeline] chunk %zu: %zu files, %.1f MB, %llu units, ready at %.1f ms (files done %zu), enqueue took %.2f ms\n", next,
-                        ch.files.size(), ch.used / 1e6, (unsigned long long)ch.units, (t_i - t_start) * 1e3, done_now, (now() - t_i) * 1e3);
+                fprintf(stderr, "[pipeline] chunk %zu: %zu files, %.1f MB, %llu units, ready at %.1f ms (files done %zu)%s, enqueue took %.2f ms\n", next,
+                        ch.files.size(), ch.used / 1e6, (unsigned long long)ch.units, (t_i - t_start) * 1e3, done_now, starved ? ", the device was idle" : "",
+                        (now() - t_i) * 1e3);
             lk.lock();
             if (r != RG_OK && result == RG_OK) result = r;
             if (r != RG_OK || ch.files.empty()) (void)hipEventRecord(P.stage[ch.stage].staged, fs);  // loaders wait on it before refilling the block
@@ -1143,8 +1151,8 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
     if (rc != RG_OK) return rc;
     RG_HIP(c, hipStreamSynchronize(fs));
     if (trace)
-        fprintf(stderr, "[pipeline] all chunks enqueued at %.1f ms, device done at %.1f ms; %u loader threads, summed: read %.1f ms, compact %.1f ms, "
-                        "waiting for a block %.1f ms, copy into the block %.1f ms\n", (t_issued - t_start) * 1e3, (now() - t_start) * 1e3, workers,
+        fprintf(stderr, "[pipeline] all chunks enqueued at %.1f ms, device done at %.1f ms; %u loader threads, summed: read %.1f ms, frame walk %.1f ms, "
+                        "waiting for a block %.1f ms, gather into the block %.1f ms\n", (t_issued - t_start) * 1e3, (now() - t_start) * 1e3, workers,
                 t_read.load() / 1e3, t_compact.load() / 1e3, t_wait.load() / 1e3, t_copy.load() / 1e3);
     const uint32_t *granules = rg_mp3dev_results(c);
     for (size_t i = 0; i < n; ++i) {

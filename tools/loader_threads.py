@@ -4,7 +4,10 @@
 (tuning key 7) limited to 1, 2, 4, 8, 16 and all usable cores.  Prints the C call's duration (best of `calls`), stereo samples/s,
 and samples/s per loader thread -- the figure that says what rg_analyze_album_node delivers with cores / 8 threads per GPU.
 
-    python tools/loader_threads.py [files] [calls]"""
+    [THREADS=1,2,4] [PARTS=3] [MP3RGAIN_AMD_LIB=...] python tools/loader_threads.py [files] [calls]
+
+THREADS: the thread counts to try (0 = all); PARTS: tuning key 10 (3 = album parts for copy-bound chunks only, i.e. without the
+parts a starved device makes)."""
 import os
 import sys
 import tempfile
@@ -22,6 +25,9 @@ calls = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 cores = len(os.sched_getaffinity(0))
 print(f"usable cores: {cores} (of {os.cpu_count()})")
 an = rg.Analyzer(0)
+if os.environ.get("PARTS"):
+    an.set_tuning(10, int(os.environ["PARTS"]))
+THREADS = [int(x) for x in os.environ.get("THREADS", "1,2,4,8,16,0").split(",")]
 for label, src in (("vbr_fixture", "tests/golden/fixtures/test_vbr.mp3"), ("dense128_joint", "tests/golden/mp3/dense_44k_joint_128.mp3"),
                    ("dense320", "tests/golden/mp3/v1_44k_stereo_long.mp3")):
     data = (ROOT / src).read_bytes()
@@ -39,7 +45,7 @@ for label, src in (("vbr_fixture", "tests/golden/fixtures/test_vbr.mp3"), ("dens
     for _ in range(4):
         an.analyze_album_files(files)
     ref = None
-    for threads in (1, 2, 4, 8, 16, 0):
+    for threads in THREADS:
         if threads > cores:
             continue
         an.set_tuning(7, threads)
