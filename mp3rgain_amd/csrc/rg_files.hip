@@ -615,10 +615,9 @@ int load_audio_for_impl(const std::string &decoder_cmd, int gpu_decode, const ch
 // =================================================================================================
 // The loader pipeline of tuning key 6 = 3 (the default).
 //
-// Host threads do the least an MPEG stream allows: read the file, walk its frame headers (rg_mp3_walk_stream: a list of
-// frames, nothing moves), and -- once the list says how many bytes the stream needs and a place in a pinned staging block is
-// theirs -- write main data without headers and side information, and one slot per frame, straight into the block
-// (rg_mp3_gather_stream).  A block that is full (or holds enough granules to fill the GPU) is a chunk, and the calling thread sends chunks
+// Host threads do the least an MPEG stream allows: read the file, walk its frame headers, and strip headers and side
+// information from the main data (rg_mp3_compact_stream).  Each stream's main data and slots go into a pinned staging
+// block; a block that is full (or holds enough granules to fill the GPU) is a chunk, and the calling thread sends chunks
 // to the device as they close: one H2D copy on the copy stream, then the frame parser, Huffman and back-half
 // kernels on the file stream, writing PCM straight into the analysis arena.  Three staging blocks and two device copies
 // rotate, so reading files, copying chunk k + 1 and decoding chunk k overlap.  How many frames of a stream decode is the
@@ -633,7 +632,6 @@ struct Mp3Scratch {
     size_t cap = 0;
     std::vector<uint8_t> slots;
     std::vector<uint64_t> tiles;
-    std::vector<uint64_t> frames;  // rg_mp3_walk_stream's list
 };
 struct Mp3Pipe {
     static constexpr int NSTAGE = 3;
@@ -710,6 +708,10 @@ struct PipeRun {
     size_t stage_want = 0;
     int hip_error = RG_OK;
     std::string hip_msg;
+    bool starved = false;       // the device was found idle when the latest chunk became ready: the host's loaders are the longer stage
+    bool tapering = false;      // the call's last chunks are being made smaller
+    size_t files_placed = 0;    // files that have their place in a chunk
+    uint64_t units_placed = 0;
 };
 
 bool read_whole_file(const char *path, Mp3Scratch *sc, size_t *len) {
@@ -866,7 +868,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         rg_mp3_stream_info si;
         uint64_t main_len = 0;
         const double tl1 = trace ? now() : 0.0;
-        if (mp4 || rg_mp3_walk_stream(sc.p, len, &sc.frames, &main_len, &si) != RG_MP3DEC_OK || si.audio_frames == 0) {
+        if (mp4 || rg_mp3_compact_stream(sc.p, len, &sc.slots, &sc.tiles, &main_len, &si) != RG_MP3DEC_OK || si.audio_frames == 0) {
             (*rcs)[i] = load_audio_for(cmd, 2, path, &la, &err, track_index);  // the decoder command, or the reference's probe error
             return;
         }
@@ -878,8 +880,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
         la.result_index = (uint32_t)i;
         la.staged = true;
         const uint64_t units = (uint64_t)si.audio_frames * (la.lsf ? 1u : 2u) * si.channels;
-        const size_t n_walked = sc.frames.size();
-        const size_t slot_bytes = n_walked * RG_MP3_SLOT_BYTES, tile_bytes = (n_walked + RG_MP3_FRAME_TILE - 1) / RG_MP3_FRAME_TILE * sizeof(uint64_t);
+        const size_t slot_bytes = sc.slots.size(), tile_bytes = sc.tiles.size() * sizeof(uint64_t);
         const size_t need = align64((size_t)main_len + 8) + align64(slot_bytes) + align64(tile_bytes);
         PipeFile &f = pf[i];
         f.main_len = main_len;
@@ -895,7 +896,18 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
                     Mp3Stage &st = P.stage[ch.stage];
                     const size_t with = ch.used + need + rg_mp3dev_track_bytes(ch.files.size() + 1) + 64;
                     // (the call's first chunks are smaller: the device has nothing to do until the first one is complete)
-                    const uint64_t unit_cap = R.open < 3 ? kPipeChunkUnits >> (3 - R.open) : kPipeChunkUnits;  // 1/8, 1/4, 1/2, then whole chunks
+                    uint64_t unit_cap = R.open < 3 ? kPipeChunkUnits >> (3 - R.open) : kPipeChunkUnits;  // 1/8, 1/4, 1/2, then whole chunks
+                    // ... and where the device waits for the loaders, the call's last chunks the other way round (each at most
+                    // half of what is left, by the files so far): what follows the last file is one chunk's copy, decode and
+                    // analysis, 3.5 ms of a 26 ms call for a whole chunk (two loader threads, 256 VBR files)
+                    if (R.starved && R.files_placed) {
+                        const uint64_t left = ch.units + (uint64_t)((double)(n - R.files_placed) * ((double)R.units_placed / (double)R.files_placed));
+                        const uint64_t taper = std::max(left / 2, kPipeChunkUnits >> 3);
+                        if (taper < unit_cap) {
+                            unit_cap = taper;
+                            R.tapering = true;  // (small chunks follow each other quickly: the device being busy then says nothing)
+                        }
+                    }
                     if (with <= st.cap && ch.units + units <= unit_cap) break;
                     if (ch.files.empty()) {  // a stream larger than a block: the block grows (nothing is in flight from it)
                         if (!grow_stage(st, with)) { hip_fail("hipHostMalloc of a staging block failed"); (*rcs)[i] = RG_ERR_DEVICE; err = "out of pinned memory"; la.staged = false; return; }
@@ -945,15 +957,21 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
             f.tiles_off = f.slots_off + align64(slot_bytes);
             chunk->used = f.tiles_off + align64(tile_bytes);
             chunk->units += units;
+            R.files_placed++;
+            R.units_placed += units;
             chunk->files.push_back(i);
             chunk->pending++;
             dst = P.stage[chunk->stage].p;
         }
         const double tl3 = trace ? now() : 0.0;
-        // main data, slots and tiles straight from the file's bytes into the block (one pass: rg_mp3dec.cpp)
-        rg_mp3_gather_stream(sc.p, sc.frames.data(), n_walked, dst + f.main_off, dst + f.slots_off, reinterpret_cast<uint64_t *>(dst + f.tiles_off));
+        // (one large copy per stream: it leaves the cache-resident scratch buffer with streaming stores.  Gathering the frames'
+        // main data straight into the block instead -- a frame list first, no compaction in place -- writes the block in
+        // pieces of a few hundred bytes, each a read-for-ownership of lines nobody will read here, and was slower from
+        // 128 kb/s up: commit a661d6a, profiles/r06_host_loader.txt)
+        memcpy(dst + f.main_off, sc.p, (size_t)main_len);
         memset(dst + f.main_off + main_len, 0, (size_t)(f.slots_off - f.main_off - main_len));  // the bit reader looks a few bytes ahead
-        memset(dst + f.slots_off + slot_bytes, 0, (size_t)(f.tiles_off - f.slots_off - slot_bytes));
+        memcpy(dst + f.slots_off, sc.slots.data(), slot_bytes);
+        memcpy(dst + f.tiles_off, sc.tiles.data(), tile_bytes);
         if (trace) {
             const double tl4 = now();
             t_read += (uint64_t)((tl1 - tl0) * 1e6);
@@ -1110,7 +1128,8 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
             const size_t done_now = R.files_done;
             lk.unlock();
             const double t_i = now();
-            const bool starved = parts && !parts->broken && prev && c->parts_when_starved() && hipEventQuery(P.part_ev[2 * prev_index]) == hipSuccess;
+            const bool observed = parts && !parts->broken && prev && c->parts_when_starved();
+            const bool starved = observed && hipEventQuery(P.part_ev[2 * prev_index]) == hipSuccess;
             int r = (result == RG_OK && !ch.files.empty()) ? issue(ch, next) : RG_OK;
             if (r == RG_OK && result == RG_OK && prev) {  // the device has this chunk's decode to go on with
                 r = analyze_part(prev, prev_index, false, starved);
@@ -1125,6 +1144,7 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
                         ch.files.size(), ch.used / 1e6, (unsigned long long)ch.units, (t_i - t_start) * 1e3, done_now, starved ? ", the device was idle" : "",
                         (now() - t_i) * 1e3);
             lk.lock();
+            if (observed && !R.tapering) R.starved = starved;  // the latest finding counts
             if (r != RG_OK && result == RG_OK) result = r;
             if (r != RG_OK || ch.files.empty()) (void)hipEventRecord(P.stage[ch.stage].staged, fs);  // loaders wait on it before refilling the block
             ch.issued = true;
@@ -1151,8 +1171,8 @@ int load_many_pipelined(rg_ctx *c, const char *const *paths, size_t n, std::vect
     if (rc != RG_OK) return rc;
     RG_HIP(c, hipStreamSynchronize(fs));
     if (trace)
-        fprintf(stderr, "[pipeline] all chunks enqueued at %.1f ms, device done at %.1f ms; %u loader threads, summed: read %.1f ms, frame walk %.1f ms, "
-                        "waiting for a block %.1f ms, gather into the block %.1f ms\n", (t_issued - t_start) * 1e3, (now() - t_start) * 1e3, workers,
+        fprintf(stderr, "[pipeline] all chunks enqueued at %.1f ms, device done at %.1f ms; %u loader threads, summed: read %.1f ms, compact %.1f ms, "
+                        "waiting for a block %.1f ms, copy into the block %.1f ms\n", (t_issued - t_start) * 1e3, (now() - t_start) * 1e3, workers,
                 t_read.load() / 1e3, t_compact.load() / 1e3, t_wait.load() / 1e3, t_copy.load() / 1e3);
     const uint32_t *granules = rg_mp3dev_results(c);
     for (size_t i = 0; i < n; ++i) {

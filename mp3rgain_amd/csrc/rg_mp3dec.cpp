@@ -74,26 +74,6 @@ struct Header {
     int samples;      // PCM frames per channel: 1152 or 576
 };
 
-// [version bits 0, 2, 3][bit rate index][sampling rate index]: bytes of a frame without its padding byte
-struct FrameBytesTable {
-    uint16_t v[4][16][4];
-    FrameBytesTable() {
-        memset(v, 0, sizeof v);
-        for (int ver = 0; ver < 4; ++ver)
-            for (int br = 1; br < 15; ++br)
-                for (int sr = 0; sr < 3; ++sr) {
-                    if (ver == 1) continue;
-                    const int kbps = ver == 3 ? kBitrateV1L3[br] : kBitrateV2L3[br];
-                    const int rate = (int)(kRateV1[sr] >> (ver == 3 ? 0 : (ver == 2 ? 1 : 2)));
-                    v[ver][br][sr] = (uint16_t)((ver == 3 ? 144 : 72) * kbps * 1000 / rate);
-                }
-    }
-};
-inline int frame_bytes_of(int ver, int br, int sr) {
-    static const FrameBytesTable t;
-    return t.v[ver][br][sr];
-}
-
 bool parse_header(const uint8_t *p, Header *h) {
     if (p[0] != 0xFF || (p[1] & 0xE0) != 0xE0) return false;
     const int ver = (p[1] >> 3) & 3, layer = (p[1] >> 1) & 3;
@@ -111,7 +91,7 @@ bool parse_header(const uint8_t *p, Header *h) {
     h->mode_ext = (p[3] >> 4) & 3;
     h->channels = h->mode == 3 ? 1 : 2;
     h->samples = h->lsf ? 576 : 1152;
-    h->frame_bytes = frame_bytes_of(ver, br, sr) + h->padding;  // (72 or 144) * bit rate / sampling rate, from a table: the division was a quarter of the frame walk
+    h->frame_bytes = (h->lsf ? 72 : 144) * h->bitrate_kbps * 1000 / (int)h->rate + h->padding;
     h->side_bytes = h->lsf ? (h->channels == 1 ? 9 : 17) : (h->channels == 1 ? 17 : 32);
     return h->frame_bytes >= 4 + (h->crc ? 2 : 0) + h->side_bytes;
 }
@@ -923,11 +903,8 @@ int walk_frames(const uint8_t *d, size_t len, rg_mp3_stream_info *info, F &&on_f
     info->channels = (uint32_t)first.channels;
     info->mpeg_version = (uint32_t)first.version;
     info->samples_per_frame = (uint32_t)first.samples;
-    size_t ahead = pos;  // the walk is a chain of dependent loads a frame apart (header -> length -> next header), each a miss in the
-                         // first-level cache on a buffer read() has just filled: the lines in front of it are asked for early
     while (pos + 4 <= len) {
         Header hh;
-        for (const size_t to = pos + 2048 < len ? pos + 2048 : len; ahead < to; ahead += 64) __builtin_prefetch(d + ahead);
         if (!parse_header(d + pos, &hh) || hh.rate != first.rate || hh.version != first.version) {
             const size_t nx = find_sync(d, len, pos + 1, &hh, true);
             if (nx + 4 > len) break;
@@ -1160,58 +1137,6 @@ int rg_mp3_compact_stream(uint8_t *data, size_t len, std::vector<uint8_t> *slots
     return RG_MP3DEC_OK;
 }
 
-// The same in two passes, for the file route's loader threads (rg_files.hip), which know where a stream's bytes go only once they
-// know how many there are: rg_mp3_walk_stream lists the frames and moves nothing -- one word per frame,
-// offset << 18 | frame bytes << 6 | offset of the main data inside the frame -- and rg_mp3_gather_stream writes main data, slots
-// and tiles where they are wanted (the pinned staging block), byte for byte what rg_mp3_compact_stream leaves.  One pass over
-// the stream's bytes instead of two, and no vector grows per frame.
-int rg_mp3_walk_stream(const uint8_t *data, size_t len, std::vector<uint64_t> *frames, uint64_t *main_len_out, rg_mp3_stream_info *out) {
-    RG_NEED_FMA();
-    if (!data || !frames || !main_len_out || !out) return fail(RG_MP3DEC_ERR_ARG, "null argument");
-    g_err[0] = 0;
-    frames->clear();
-    uint64_t at = 0;
-    const int rc = walk_frames(data, len, out, [&](const uint8_t *f, const Header &h) {
-        const uint32_t main_start = 4u + (h.crc ? 2u : 0u) + (uint32_t)h.side_bytes;
-        frames->push_back((uint64_t)(f - data) << 18 | (uint64_t)h.frame_bytes << 6 | main_start);
-        at += (uint64_t)h.frame_bytes - main_start;
-    });
-    if (rc != RG_MP3DEC_OK) return rc;
-    *main_len_out = at;
-    out->audio_frames = (uint32_t)frames->size();                          // walked; the device decides how many of them decode
-    out->frames = (uint64_t)frames->size() * out->samples_per_frame;      // upper bound
-    return RG_MP3DEC_OK;
-}
-
-// main_out: the stream's main data; slots_out: n_frames slots of RG_MP3_SLOT_BYTES; tiles_out: one word per RG_MP3_FRAME_TILE
-// frames.  `data` must be readable 42 bytes past the start of any frame (the loaders' buffers end in 64 zero bytes).
-void rg_mp3_gather_stream(const uint8_t *data, const uint64_t *frames, size_t n_frames, uint8_t *main_out, uint8_t *slots_out, uint64_t *tiles_out) {
-    uint64_t at = 0;
-    for (size_t k = 0; k < n_frames; ++k) {
-        const uint64_t w = frames[k];
-        const uint8_t *f = data + (w >> 18);
-        const uint32_t frame_bytes = (uint32_t)(w >> 6) & 0xFFFu, main_start = (uint32_t)w & 63u;
-        if (k % RG_MP3_FRAME_TILE == 0) tiles_out[k / RG_MP3_FRAME_TILE] = at;
-        uint8_t *slot = slots_out + k * RG_MP3_SLOT_BYTES;
-        const uint32_t side_at = 4u + ((f[1] & 1u) ? 0u : 2u), side_bytes = main_start - side_at;
-        // header, side information, zeros: whole words, the side information's length is one of three
-        uint64_t q[5];
-        memcpy(q, f + side_at - 4, 40);       // (the 4 bytes in front of the side information are overwritten below)
-        memcpy(q, f, 4);
-        if (side_bytes == 32) {
-            q[4] &= 0x00000000FFFFFFFFull;
-        } else if (side_bytes == 17) {
-            q[2] &= 0x000000FFFFFFFFFFull; q[3] = 0; q[4] = 0;
-        } else {  // 9
-            q[1] &= 0x000000FFFFFFFFFFull; q[2] = 0; q[3] = 0; q[4] = 0;
-        }
-        memcpy(slot, q, 40);
-        const uint32_t main_len = frame_bytes - main_start;
-        memcpy(main_out + at, f + main_start, main_len);
-        at += main_len;
-    }
-}
-
 // Test hook: the two frame indexers must tell the same story.  Runs rg_mp3_index_stream (slots interpreted during the
 // walk) and rg_mp3_compact_stream + rg_mp3_frame_records over the slots afterwards (what rg_mp3_frames_kernel does on the
 // device) and compares main data and records.  0 = identical, 1 = different, < 0 = the stream has no audio.
@@ -1228,22 +1153,6 @@ extern "C" int rg_mp3_index_selfcheck(const void *data, size_t len) {
     if (rc != rc2) return 1;
     if (rc != RG_MP3DEC_OK) return rc;
     if (main_len != main_a.size() || (main_len != 0 && memcmp(copy.data(), main_a.data(), main_len) != 0)) return 1;
-    {   // the two-pass form leaves the same bytes
-        std::vector<uint8_t> padded((const uint8_t *)data, (const uint8_t *)data + len);
-        padded.resize(len + 64, 0);
-        std::vector<uint64_t> frames;
-        uint64_t main_len_c = 0;
-        rg_mp3_stream_info ic;
-        if (rg_mp3_walk_stream(padded.data(), len, &frames, &main_len_c, &ic) != RG_MP3DEC_OK) return 1;
-        if (main_len_c != main_len || frames.size() * RG_MP3_SLOT_BYTES != slots.size() || memcmp(&ic, &ib, sizeof ic) != 0) return 1;
-        std::vector<uint8_t> main_c(main_len_c + 1, 0xA5), slots_c(slots.size() + 1, 0xA5);
-        std::vector<uint64_t> tiles_c(tiles.size() + 1, 0xA5A5A5A5A5A5A5A5ull);
-        rg_mp3_gather_stream(padded.data(), frames.data(), frames.size(), main_c.data(), slots_c.data(), tiles_c.data());
-        if (main_c[main_len_c] != 0xA5 || slots_c[slots.size()] != 0xA5 || tiles_c[tiles.size()] != 0xA5A5A5A5A5A5A5A5ull) return 1;
-        if (main_len_c && memcmp(main_c.data(), copy.data(), main_len_c) != 0) return 1;
-        if (!slots.empty() && memcmp(slots_c.data(), slots.data(), slots.size()) != 0) return 1;
-        if (!tiles.empty() && memcmp(tiles_c.data(), tiles.data(), tiles.size() * sizeof(uint64_t)) != 0) return 1;
-    }
     uint64_t have = 0;
     uint32_t decoded = 0;
     const size_t nframes = slots.size() / RG_MP3_SLOT_BYTES;

@@ -119,10 +119,6 @@ int rg_mp3_index_stream(const void *data, size_t len, std::vector<uint8_t> *main
 // `tiles`: for every RG_MP3_FRAME_TILE frames, the main-data bytes that precede the tile's first frame.
 int rg_mp3_compact_stream(uint8_t *data, size_t len, std::vector<uint8_t> *slots, std::vector<uint64_t> *tiles, uint64_t *main_len,
                           rg_mp3_stream_info *info);
-// the same in two passes (the loader threads of the file route): the frames listed, nothing moved; then main data, slots and
-// tiles written where they are wanted.  frames[k] = offset << 18 | frame bytes << 6 | offset of the main data in the frame.
-int rg_mp3_walk_stream(const uint8_t *data, size_t len, std::vector<uint64_t> *frames, uint64_t *main_len, rg_mp3_stream_info *info);
-void rg_mp3_gather_stream(const uint8_t *data, const uint64_t *frames, size_t n_frames, uint8_t *main_out, uint8_t *slots_out, uint64_t *tiles_out);
 extern "C" {
 #endif
 // host: fill the table blocks (rg_mp3dec.cpp)

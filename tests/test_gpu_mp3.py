@@ -377,7 +377,8 @@ def test_loader_pipeline_with_tiny_staging_blocks(oracle, tmp_path, monkeypatch)
 def test_album_parts_give_the_plain_route_results(tmp_path, monkeypatch):
     """Album parts (rg_files.hip: PartsRun): the tracks of a decoded chunk are analysed while later chunks are copied and decoded,
     and the album is the fold of the parts' packs.  With tiny staging blocks (dozens of chunks) and every chunk made a part, only
-    copy-bound chunks (the default rule: the rest waits and joins a later part), and no parts at all, an album of 45 files --
+    copy-bound chunks (the default rule: the rest waits and joins a later part -- unless the device had to wait for it), and no
+    parts at all, an album of 45 files --
     mono and stereo, 8 to 48 kHz, one file longer than a block -- must come out the same, field by field; a WAV file among
     them (not the pipeline's) sends the whole album down the plain route."""
     import mp3rgain_amd as rg
@@ -435,6 +436,19 @@ def test_album_parts_give_the_plain_route_results(tmp_path, monkeypatch):
             an.set_tuning(11, rule + 1)
             assert tkey(an.analyze_track_files(files)) == t_plain, rule
             assert tkey(an.analyze_track_files(with_missing)) == t_plain_missing, rule
+        # A device that waits for the host (one loader thread and dozens of small chunks, none of them copy-bound by the rule):
+        # the chunks it waited for become parts as well and the call's last chunks shrink (key 10 = 2, the default); key 10 = 3
+        # keeps to the copy-bound rule, i.e. the plain route here.  Which chunks are which depends on timing; the results do not.
+        an.set_tuning(7, 1)
+        an.set_tuning(11, 10**9 + 1)
+        for mode in (2, 3, 0):
+            an.set_tuning(10, mode)
+            for _ in range(3):
+                assert key(an.analyze_album_files(files)) == plain, mode
+            assert tkey(an.analyze_track_files(with_missing)) == t_plain_missing, mode
+        an.set_tuning(7, 0)
+        with pytest.raises(rg.ReplayGainError):
+            an.set_tuning(10, 4)
 
 
 def test_analyze_tracks_in_groups_bounded_by_memory(_ctx, tmp_path, monkeypatch):

@@ -53,10 +53,11 @@ for a in range(n_albums):
         files.insert(rnd.randrange(len(files) + 1), tmp / "missing.mp3")
     stage = rnd.choice(["16384", "65536", "262144", None])
     an.set_tuning(12, int(stage) if stage else 0)  # staging block bytes (tuning keys 10-13: the environment is read at rg_create only)
+    an.set_tuning(7, rnd.choice([0, 1, 2]))       # loader threads: with one or two the device waits for the host, and the chunks it waited for are parts
     an.set_tuning(10, 1)
     want_album, want_tracks = run(an.analyze_album_files, files), run(an.analyze_track_files, files)
     an.set_tuning(10, 2)
-    for rule in ("0", "120", "300"):
+    for rule in ("0", "120", "300", "1000000000"):
         an.set_tuning(11, int(rule) + 1)
         got_album, got_tracks = run(an.analyze_album_files, files), run(an.analyze_track_files, files)
         if got_album != want_album or got_tracks != want_tracks:
@@ -66,5 +67,5 @@ for a in range(n_albums):
     for p in files:
         if p.exists():
             p.unlink()
-print(f"{n_albums} random albums (seed {seed}; whole, truncated, damaged and missing files; staging blocks of 16 KB to 128 MB; parts forced, by rule, at 300 bytes per unit): {bad} differ from the plain route (album and track mode, results and errors)")
+print(f"{n_albums} random albums (seed {seed}; whole, truncated, damaged and missing files; staging blocks of 16 KB to 128 MB; loader threads all / 1 / 2; parts forced, by rule, at 300 bytes per unit, for starved chunks only): {bad} differ from the plain route (album and track mode, results and errors)")
 sys.exit(1 if bad else 0)

@@ -4,10 +4,10 @@
 (tuning key 7) limited to 1, 2, 4, 8, 16 and all usable cores.  Prints the C call's duration (best of `calls`), stereo samples/s,
 and samples/s per loader thread -- the figure that says what rg_analyze_album_node delivers with cores / 8 threads per GPU.
 
-    [THREADS=1,2,4] [PARTS=3] [MP3RGAIN_AMD_LIB=...] python tools/loader_threads.py [files] [calls]
+    [THREADS=1,2,4] [MODES=3,2] [MP3RGAIN_AMD_LIB=...] python tools/loader_threads.py [files] [calls]
 
-THREADS: the thread counts to try (0 = all); PARTS: tuning key 10 (3 = album parts for copy-bound chunks only, i.e. without the
-parts a starved device makes)."""
+THREADS: the thread counts to try (0 = all); MODES: values of tuning key 10 to compare call by call (3 = album parts for
+copy-bound chunks only: no parts for the chunks a starved device waited for and no smaller chunks at the call's end; 2 = both)."""
 import os
 import sys
 import tempfile
@@ -25,8 +25,7 @@ calls = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 cores = len(os.sched_getaffinity(0))
 print(f"usable cores: {cores} (of {os.cpu_count()})")
 an = rg.Analyzer(0)
-if os.environ.get("PARTS"):
-    an.set_tuning(10, int(os.environ["PARTS"]))
+MODES = [int(x) for x in os.environ["MODES"].split(",")] if os.environ.get("MODES") else [None]
 THREADS = [int(x) for x in os.environ.get("THREADS", "1,2,4,8,16,0").split(",")]
 for label, src in (("vbr_fixture", "tests/golden/fixtures/test_vbr.mp3"), ("dense128_joint", "tests/golden/mp3/dense_44k_joint_128.mp3"),
                    ("dense320", "tests/golden/mp3/v1_44k_stereo_long.mp3")):
@@ -49,17 +48,22 @@ for label, src in (("vbr_fixture", "tests/golden/fixtures/test_vbr.mp3"), ("dens
         if threads > cores:
             continue
         an.set_tuning(7, threads)
-        best = 1e9
-        for _ in range(calls):
-            tm = {}
-            res = an.analyze_album_files(files, timing=tm)
-            best = min(best, tm["c_call_seconds"])
-        ref = ref if ref is not None else res.album_loudness_db
-        assert res.album_loudness_db == ref
+        times = {m: [] for m in MODES}
+        for _ in range(calls):  # the modes call by call in turn: what disturbs one disturbs the other
+            for m in MODES:
+                if m is not None:
+                    an.set_tuning(10, m)
+                tm = {}
+                res = an.analyze_album_files(files, timing=tm)
+                times[m].append(tm["c_call_seconds"])
+                ref = ref if ref is not None else res.album_loudness_db
+                assert res.album_loudness_db == ref
         n = threads or cores
-        rate = nfiles * si.frames / best
-        print(f"   loader threads {('all = %d' % cores) if threads == 0 else threads:>9}: {best * 1e3:8.2f} ms  {rate / 1e9:7.2f} G stereo samples/s  "
-              f"{rate / n / 1e9:6.2f} G per thread  ({nfiles * len(stream) / best / 1e9:5.2f} GB/s of files)", flush=True)
+        for m in MODES:
+            best, med = min(times[m]), sorted(times[m])[len(times[m]) // 2]
+            rate = nfiles * si.frames / best
+            print(f"   loader threads {('all = %d' % cores) if threads == 0 else threads:>9}{'' if m is None else ' (key 10 = %d)' % m}: {best * 1e3:8.2f} ms (median {med * 1e3:6.2f})  "
+                  f"{rate / 1e9:7.2f} G stereo samples/s  {rate / n / 1e9:6.2f} G per thread  ({nfiles * len(stream) / best / 1e9:5.2f} GB/s of files)", flush=True)
     an.set_tuning(7, 0)
     for p in files:
         p.unlink()

@@ -1,8 +1,13 @@
 // tools/ubench/host_loader.cpp -- what one loader thread of the file route spends per file, without a GPU: read(), the frame walk
 // and the copies into the staging block (an ordinary allocation here; pinned memory on the GPU box is the same kind of memory).
 //
-//   g++ -O2 -std=c++17 tools/ubench/host_loader.cpp -Imp3rgain_amd/csrc -Iinclude -Lmp3rgain_amd -lmp3rgain_amd -Wl,-rpath,$PWD/mp3rgain_amd -o build_ab/host_loader
-//   build_ab/host_loader FILE [copies] [reps]
+//   g++ -O2 -std=c++17 tools/ubench/host_loader.cpp -Imp3rgain_amd/csrc -Iinclude -Lmp3rgain_amd -lmp3rgain_amd -Wl,-rpath,'$ORIGIN/../mp3rgain_amd' -o build_ab/host_loader
+//   build_ab/host_loader FILE [copies] [reps]            (TMPDIR = where the copies go)
+//
+// -DTWO_PASS (against a library built from commit a661d6a, which has rg_mp3_walk_stream / rg_mp3_gather_stream): the loader in
+// two passes -- a frame list first, then main data and slots gathered straight into the staging block, with ordinary and with
+// streaming stores -- beside the shipped one (compaction in place in the scratch buffer, one large copy).  profiles/
+// r06_host_loader.txt: read() is half of a file's time and the rest differs by a tenth either way; the shipped form stays.
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -22,10 +27,10 @@
 
 int rg_mp3_compact_stream(uint8_t *data, size_t len, std::vector<uint8_t> *slots, std::vector<uint64_t> *tiles, uint64_t *main_len,
                           rg_mp3_stream_info *out);
-#ifndef HEAD_ONLY
+#ifdef TWO_PASS
 int rg_mp3_walk_stream(const uint8_t *data, size_t len, std::vector<uint64_t> *frames, uint64_t *main_len, rg_mp3_stream_info *out);
 void rg_mp3_gather_stream(const uint8_t *data, const uint64_t *frames, size_t n_frames, uint8_t *main_out, uint8_t *slots_out, uint64_t *tiles_out);
-#else  // a library without the two-pass form (-DHEAD_ONLY, ONLY_COMPACT=1): the set-up's walk through the one-pass form
+#else  // the library as shipped has the one-pass form only: the set-up's walk goes through it
 int rg_mp3_walk_stream(const uint8_t *data, size_t len, std::vector<uint64_t> *frames, uint64_t *main_len, rg_mp3_stream_info *out) {
     std::vector<uint8_t> copy(data, data + len), slots;
     copy.resize(len + 64, 0);
@@ -135,7 +140,11 @@ int main(int argc, char **argv) {
     size_t stage_at = 0;
     std::vector<uint64_t> tiles, frames;
     printf("%s: %.2f MB per file, %zu frames x %d\n", argv[1], stream.size() / 1e6, fr.size(), rep_body);
-    const int nvar = getenv("ONLY_COMPACT") ? 1 : 3;
+    #ifdef TWO_PASS
+    const int nvar = 3;
+#else
+    const int nvar = 1;
+#endif
     for (int variant = 0; variant < nvar; ++variant) {
         double best[4] = {1e9, 1e9, 1e9, 1e9};
         uint64_t check = 0;
@@ -176,7 +185,7 @@ int main(int argc, char **argv) {
         printf("  %-22s read %7.1f us  walk %7.1f us  copy %7.1f us  = %7.1f us per file  (%.2f GB/s)  [%llu]\n", variant == 2 ? "walk + gather (nt)" : variant ? "walk + gather" : "compact + memcpy",
                best[0] / copies * 1e6, best[1] / copies * 1e6, best[2] / copies * 1e6, best[3] / copies * 1e6, bytes / best[3] / 1e9, (unsigned long long)check);
     }
-#ifndef HEAD_ONLY
+#ifdef TWO_PASS
     {   // the two gathers leave the same bytes
         const size_t len = read_file(paths[0].c_str(), &buf);
         uint64_t main_len = 0;
