@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """File-route soak (GPU box): albums of 1 / 12 / 40 / 256 files, album and track mode, parts forced / by rule / off, again and
-again on one context: results identical every time, free device memory steady after the first rounds.
+again on one context, with all / one / two loader threads in turn: results identical every time, free device memory steady after the first rounds.
     python tools/soak_files.py [rounds]"""
 import os, sys, tempfile
 from pathlib import Path
@@ -29,6 +29,7 @@ for label, src, n in (("1x320k", "tests/golden/mp3/v1_44k_stereo_long.mp3", 1), 
 ref = {}
 free0 = None
 for r in range(rounds):
+    an.set_tuning(7, (0, 1, 2)[r % 3])  # loader threads: all / one / two (with few the device waits for the host: other chunks become parts)
     for label, files in sets.items():
         for mode in ("album", "tracks"):
             for env in ({10: 1, 11: 0}, {10: 2, 11: 1}, {10: 2, 11: 0}):  # tuning keys: parts never | every chunk a part | the default rule
